@@ -1,0 +1,116 @@
+/*
+ * oracle/skw_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the arithmetic the reference's Whisper node executes.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; nothing under streamkit_amd/ links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference keeps this arithmetic in un-vendored
+ * third-party code (whisper.cpp via whisper-rs 0.15.1 / whisper-rs-sys 0.14.1,
+ * /root/reference/plugins/native/whisper/Cargo.lock:1174-1185; rubato 0.16.2,
+ * /root/reference/Cargo.lock:3708-3711), ships no model weights, and none of its
+ * tests pins a value on this path.  What is restated here is
+ * whisper.cpp's published algorithm (log_mel_spectrogram, whisper_encode_internal,
+ * whisper_decode_internal, whisper_process_logits, whisper_full_with_state) and
+ * rubato's FastFixedIn/Linear, anchored on the reference's own call sites:
+ *   plugins/native/whisper/src/lib.rs:404-494  (VAD framing + segment cuts)
+ *   plugins/native/whisper/src/lib.rs:582-702  (FullParams + full() + segments)
+ *   crates/nodes/src/audio/filters/resampler.rs:231-244, 384-514, 543-688
+ * and on the behavioural goldens derivable from those files alone
+ * (tests/golden/, SURVEY.md §8c last row).
+ */
+#ifndef SKW_ORACLE_H
+#define SKW_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct skwo_model skwo_model;
+
+typedef struct {
+    int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, ftype;
+} skwo_hparams;
+
+/* whisper_full_params subset that the reference sets (lib.rs:624-641) plus the
+ * whisper.cpp defaults that shape greedy decoding */
+typedef struct {
+    int32_t lang_id;            /* index into whisper's language table; "en" = 0 */
+    int32_t translate;          /* lib.rs:626 -> false */
+    int32_t suppress_blank;     /* lib.rs:633 */
+    int32_t suppress_nst;       /* lib.rs:634 */
+    int32_t no_timestamps;      /* whisper.cpp default false */
+    int32_t single_segment;     /* default false */
+    int32_t max_tokens;         /* default 0 */
+    float   max_initial_ts;     /* default 1.0 */
+    float   entropy_thold;      /* default 2.4 */
+    float   logprob_thold;      /* default -1.0 */
+    float   no_speech_thold;    /* default 0.6 */
+    int32_t n_threads;
+} skwo_params;
+
+typedef struct {
+    int64_t t0, t1;             /* centiseconds, as whisper_full_get_segment_t0/t1 */
+    int32_t tok_begin, tok_end; /* [begin,end) into the token array */
+    int32_t text_off, text_len; /* into the text buffer */
+} skwo_segment;
+
+typedef struct {
+    int32_t id, tid;
+    float p, plog, pt, ptsum;
+} skwo_token;
+
+typedef struct {
+    int32_t n_segments, n_tokens, n_windows, n_decode_steps;
+    int32_t fallback_requested;  /* a window failed the T=0 pass (whisper.cpp would resample at T>0) */
+    float   min_margin;          /* smallest top1-top2 logit margin over all sampled steps */
+    skwo_segment* segments;
+    skwo_token* tokens;          /* all result tokens in order (timestamps included) */
+    char* text;                  /* concatenated segment texts (no separators) */
+    int32_t text_len;
+} skwo_result;
+
+skwo_model* skwo_load(const char* path, char* err, int errlen);
+void skwo_free(skwo_model*);
+void skwo_get_hparams(const skwo_model*, skwo_hparams* out);
+const char* skwo_token_str(const skwo_model*, int id, int* len);
+void skwo_default_params(skwo_params* p);
+
+/* K1: whisper.cpp log_mel_spectrogram. Returns malloc'd [n_mel][n_len]; caller frees with skwo_free_buf */
+float* skwo_log_mel(const skwo_model*, const float* pcm, int n_samples, int* n_len, int* n_len_org);
+void skwo_free_buf(void*);
+
+/* K2-K6: encoder over mel frames [seek, seek+3000). enc_out: [n_audio_ctx][n_state] f32 (after ln_post).
+ * cross_k/cross_v (optional, may be NULL): [n_text_layer][n_audio_ctx][n_state] f32 holding f16-rounded values */
+int skwo_encode(const skwo_model*, const float* mel, int n_len, int seek, int n_threads,
+                float* enc_out, float* cross_k, float* cross_v);
+
+/* debug taps for kernel-level parity tests */
+int skwo_conv_stem(const skwo_model*, const float* mel, int n_len, int seek, int n_threads, float* x0 /*[n_ctx][n_state]*/);
+
+/* K7-K10: run the decoder on `n_tokens` tokens appended at position n_past for ONE sequence whose
+ * cross K/V were produced by skwo_encode; returns logits of the last token. State is opaque. */
+typedef struct skwo_dec skwo_dec;
+skwo_dec* skwo_dec_new(const skwo_model*, const float* cross_k, const float* cross_v);
+void skwo_dec_free(skwo_dec*);
+void skwo_dec_reset(skwo_dec*);
+int skwo_dec_step(skwo_dec*, const int32_t* tokens, int n_tokens, int n_past, int n_threads, float* logits /*[n_vocab]*/);
+
+/* K11-K12 + W4: whisper_full_with_state, greedy best_of=1, T=0 pass */
+int skwo_full(const skwo_model*, const skwo_params*, const float* pcm, int n_samples, skwo_result* out);
+void skwo_result_free(skwo_result*);
+
+/* teacher-forced logits (for margin diagnostics): runs window at `seek` with given token prefix */
+
+/* R1-R3: rubato FastFixedIn<f32>, PolynomialDegree::Linear, as driven by resampler.rs */
+typedef struct skwo_resampler skwo_resampler;
+skwo_resampler* skwo_resampler_new(double ratio, int chunk_frames, int channels);
+void skwo_resampler_free(skwo_resampler*);
+/* planar in [ch][chunk_frames] -> planar out [ch][cap]; returns frames written per channel */
+int skwo_resampler_process(skwo_resampler*, const float* in_planar, float* out_planar, int out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
