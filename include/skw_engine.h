@@ -1,0 +1,114 @@
+/*
+ * skw_engine.h — C ABI of the MI355X Whisper engine (libskw_engine.so).
+ *
+ * This is the drop-in boundary for the arithmetic the reference reaches through
+ * whisper-rs (FFI over whisper.cpp's C API).  Each entry point names the
+ * reference call it replaces; a Rust host binds these with a ~40-line
+ * `extern "C"` block (INTEGRATION.md shows it next to the whisper-rs calls it
+ * displaces).  Plain pointers and sizes only — no torch, no C++ types.
+ *
+ *   reference (plugins/native/whisper/src/lib.rs)            this library
+ *   ---------------------------------------------            ----------------------------
+ *   WhisperContext::new_with_params(path, params)  :354-363  skw_model_load(path, gpu_device)
+ *   context.create_state()                         :377-379  skw_ctx_create(model, max_batch, ...)
+ *   FullParams::new(Greedy{best_of:1}) + setters   :624-641  skw_full_params (skw_full_default_params)
+ *   whisper_state.full(params, &samples)           :644-646  skw_full_batch(ctx, params, pcm[], n[], n_clips)
+ *   state.as_iter() / segment.to_str() /
+ *     start_timestamp() / end_timestamp()          :650-660  skw_result.segments[i].{text,t0,t1}
+ *
+ * skw_full_batch is the batched form of `full`: n_clips independent calls of
+ * whisper_full_with_state (greedy, temperature 0) executed together on one GPU.
+ * The kernels fail loudly (non-zero return + message) when no gfx950 device is
+ * present; there is no CPU fallback in this library.
+ */
+#ifndef SKW_ENGINE_H
+#define SKW_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct skw_model skw_model;
+typedef struct skw_ctx skw_ctx;
+
+typedef struct {
+    int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, ftype;
+} skw_hparams;
+
+/* the whisper_full_params fields the reference sets (lib.rs:624-641) + the whisper.cpp defaults that shape greedy decoding */
+typedef struct {
+    int32_t lang_id;          /* whisper_lang_id(language); "en" = 0 */
+    int32_t translate;
+    int32_t suppress_blank;
+    int32_t suppress_nst;
+    int32_t no_timestamps;
+    int32_t single_segment;
+    int32_t max_tokens;
+    float   max_initial_ts;
+    float   entropy_thold;
+    float   logprob_thold;
+    float   no_speech_thold;
+    int32_t n_threads;        /* accepted for ABI parity with the reference param; unused on the GPU */
+} skw_full_params;
+
+typedef struct {
+    int64_t t0, t1;             /* centiseconds: whisper_full_get_segment_t0/t1 */
+    int32_t tok_begin, tok_end; /* [begin,end) into skw_result.tokens */
+    int32_t text_off, text_len; /* into skw_result.text */
+} skw_segment;
+
+typedef struct { int32_t id, tid; float p, plog, pt, ptsum; } skw_token;
+
+typedef struct {
+    int32_t n_segments, n_tokens, n_windows, n_decode_steps;
+    int32_t fallback_requested; /* windows whose T=0 pass whisper.cpp would have retried at T>0 (not resampled here) */
+    float   min_margin;         /* smallest top1-top2 admissible-logit margin seen (diagnostic) */
+    skw_segment* segments;
+    skw_token* tokens;
+    char* text;                 /* concatenated segment texts, NUL terminated */
+    int32_t text_len;
+} skw_result;
+
+/* ---- lifetime ---- */
+int  skw_device_count(void);
+skw_model* skw_model_load(const char* ggml_path, int device, char* err, size_t errlen);
+void skw_model_free(skw_model*);
+void skw_model_get_hparams(const skw_model*, skw_hparams* out);
+const char* skw_model_token_text(const skw_model*, int id, int* len);
+int  skw_model_lang_id(const char* lang); /* whisper_lang_id; -1 if unknown */
+
+skw_ctx* skw_ctx_create(skw_model*, int max_batch, int max_samples_per_clip, char* err, size_t errlen);
+void skw_ctx_free(skw_ctx*);
+const char* skw_ctx_last_error(const skw_ctx*);
+
+void skw_full_default_params(skw_full_params*);
+
+/* ---- the hot path ---- */
+/* pcm[i]: 16 kHz mono f32, n_samples[i] samples; host pointers (pcm_on_device = 0) or device pointers (= 1).
+ * results[i] is filled and must be released with skw_result_free. n_clips <= max_batch. Returns 0 on success. */
+int  skw_full_batch(skw_ctx*, const skw_full_params*, const float* const* pcm, const int32_t* n_samples, int n_clips,
+                    int pcm_on_device, skw_result* results);
+void skw_result_free(skw_result*);
+
+/* timing of the last skw_full_batch (milliseconds, GPU events on the engine's stream) */
+typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t n_windows, n_decode_steps, n_tokens; } skw_timing;
+void skw_ctx_last_timing(const skw_ctx*, skw_timing* out);
+/* the HIP stream the engine launches on (opaque hipStream_t) */
+void* skw_ctx_stream(const skw_ctx*);
+
+/* ---- stage taps (used by the parity tests and by hosts that only need a front end) ---- */
+/* K1: log-mel of one clip; mel_out [n_mel][n_len] f32 (whisper.cpp layout); caller provides cap floats */
+int skw_log_mel(skw_ctx*, const float* pcm_host, int n_samples, float* mel_out, size_t cap, int* n_len, int* n_len_org);
+/* K2: conv stem + positional embedding for the window at `seek`; x0 [n_audio_ctx][n_state] f32 */
+int skw_conv_stem(skw_ctx*, const float* pcm_host, int n_samples, int seek, float* x0);
+/* K2-K6: encoder output (after ln_post) [n_audio_ctx][n_state] f32 and, when non-null, cross K/V [n_text_layer][n_audio_ctx][n_state] f32 */
+int skw_encode(skw_ctx*, const float* pcm_host, int n_samples, int seek, float* enc_out, float* cross_k, float* cross_v);
+/* K7-K10: after skw_encode, run the decoder on tokens[0..n) from position 0 and return the last token's logits [n_vocab] */
+int skw_decode_logits(skw_ctx*, const int32_t* tokens, int n_tokens, float* logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

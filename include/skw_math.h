@@ -37,14 +37,15 @@
 #include <string.h>
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-#define SKW_HD __host__ __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#define SKW_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define SKW_HD static inline
 #endif
 
 /* ---- bit casts ---------------------------------------------------------- */
-SKW_HD uint32_t skw_f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-SKW_HD float skw_bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+SKW_HD uint32_t skw_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+SKW_HD float skw_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
 /* ---- f16 conversion (IEEE binary16, round-to-nearest-even) -------------- */
 /* Software form; device code may use the hardware cast, which is bit-identical
@@ -159,14 +160,17 @@ SKW_HD float skw_logf(float x) {
 #define SKW_GELU_COEF_A 0.044715f
 #define SKW_SQRT_2_OVER_PI 0.79788456080286535587989211986876f
 
-#ifndef __HIP_DEVICE_COMPILE__
 #include <math.h>
-static inline uint16_t skw_gelu_table_entry(uint16_t i) {
+#if defined(__HIPCC__)
+#define SKW_H __host__ inline
+#else
+#define SKW_H static inline
+#endif
+SKW_H uint16_t skw_gelu_table_entry(uint16_t i) {
     float x = skw_f16_to_f32(i);
     float g = 0.5f * x * (1.0f + tanhf(SKW_SQRT_2_OVER_PI * x * (1.0f + SKW_GELU_COEF_A * x * x)));
     return skw_f32_to_f16(g);
 }
-#endif
 
 /* gelu through the table: returns an f32 (f16-valued unless x >= 10) */
 SKW_HD float skw_gelu_lookup(float x, const uint16_t* table) {

@@ -238,7 +238,7 @@ const char* skwo_token_str(const skwo_model* m, int id, int* len) { if (id < 0 |
 void skwo_free_buf(void* p) { free(p); }
 void skwo_default_params(skwo_params* p) {
     memset(p, 0, sizeof *p);
-    p->lang_id = 0; p->translate = 0; p->suppress_blank = 1; p->suppress_nst = 1; p->no_timestamps = 0; p->single_segment = 0; p->max_tokens = 0;
+    p->lang_id = 0; p->translate = 0; p->suppress_blank = 1; p->suppress_nst = 0; /* whisper_full_default_params */ p->no_timestamps = 0; p->single_segment = 0; p->max_tokens = 0;
     p->max_initial_ts = 1.0f; p->entropy_thold = 2.4f; p->logprob_thold = -1.0f; p->no_speech_thold = 0.6f; p->n_threads = 0;
 }
 
@@ -329,6 +329,20 @@ float* skwo_log_mel(const skwo_model* m, const float* pcm, int n_samples, int* n
     return mel;
 }
 
+/* ------------------------------------------------------- debug taps */
+#define MAX_TAPS 64
+static struct { char name[32]; float* data; size_t n; } g_taps[MAX_TAPS];
+static int g_n_taps = 0, g_taps_on = 0;
+void skwo_debug_enable(int on) { g_taps_on = on; for (int i = 0; i < g_n_taps; ++i) free(g_taps[i].data); g_n_taps = 0; }
+static void tap(const char* name, const float* d, size_t n) {
+    if (!g_taps_on || g_n_taps == MAX_TAPS) return;
+    snprintf(g_taps[g_n_taps].name, 32, "%s", name); g_taps[g_n_taps].data = (float*)malloc(n * 4); memcpy(g_taps[g_n_taps].data, d, n * 4); g_taps[g_n_taps].n = n; g_n_taps++;
+}
+long skwo_debug_get(const char* name, float* out, size_t cap) {
+    for (int i = 0; i < g_n_taps; ++i) if (!strcmp(g_taps[i].name, name)) { if (out && cap >= g_taps[i].n) memcpy(out, g_taps[i].data, g_taps[i].n * 4); return (long)g_taps[i].n; }
+    return -1;
+}
+
 /* ------------------------------------------------------- arithmetic core */
 /* C[m][n] = k-ascending chain acc = fma(A[m][k], Wt[k][n], acc), acc0 = 0.
  * A must already hold f16-representable values (ggml converts src1 rows to f16 before ggml_vec_dot_f16). */
@@ -408,13 +422,17 @@ static void linear(const float* A, long lda, int rows, const lin_t* L, float* ou
 }
 
 /* ggml_soft_max_ext row: wp = s*scale; max; p = expf(wp-max); sum (double); p *= (float)(1/sum) */
-static void softmax_row(float* s, int n, float scale) {
+static float *g_dbg_max = NULL, *g_dbg_inv = NULL; /* [row] when taps are on */
+static void softmax_row2(float* s, int n, float scale, float* omax, float* oinv);
+static void softmax_row(float* s, int n, float scale) { softmax_row2(s, n, scale, NULL, NULL); }
+static void softmax_row2(float* s, int n, float scale, float* omax, float* oinv) {
     float mx = -INFINITY;
     for (int i = 0; i < n; ++i) { s[i] = s[i] * scale; if (s[i] > mx) mx = s[i]; }
     double sum = 0.0;
     for (int i = 0; i < n; ++i) { float v = skw_expf(s[i] - mx); s[i] = v; sum += (double)v; }
     const float inv = (float)(1.0 / sum);
     for (int i = 0; i < n; ++i) s[i] = s[i] * inv;
+    if (omax) *omax = mx; if (oinv) *oinv = inv;
 }
 
 /* --------------------------------------------- K2: conv stem (+pos emb) */
@@ -461,30 +479,43 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
     for (int l = 0; l < m->hp.n_audio_layer; ++l) {
         const enc_layer_t* L = &m->enc[l];
         layer_norm(x, n_ctx, d, &L->attn_ln, y); round_f16_inplace(y, (size_t)n_ctx * d);
+        if (l == 0) tap("l0.ln1", y, (size_t)n_ctx * d);
         linear(y, d, n_ctx, &L->q, q, d); linear(y, d, n_ctx, &L->k, kk, d); linear(y, d, n_ctx, &L->v, v, d);
         round_f16_inplace(q, (size_t)n_ctx * d);   /* src1 of mul_mat(K,Q) -> f16 */
         round_f16_inplace(kk, (size_t)n_ctx * d);  /* ggml_cast(K, f16) */
         round_f16_inplace(v, (size_t)n_ctx * d);   /* ggml_cast(V, f16) */
+        if (l == 0) { tap("l0.q", q, (size_t)n_ctx * d); tap("l0.k", kk, (size_t)n_ctx * d); tap("l0.v", v, (size_t)n_ctx * d); }
+        if (l == 0 && g_taps_on) { g_dbg_max = (float*)calloc((size_t)nh * n_ctx, 4); g_dbg_inv = (float*)calloc((size_t)nh * n_ctx, 4); }
         for (int h = 0; h < nh; ++h) {
 #pragma omp parallel for schedule(static)
             for (int j = 0; j < n_ctx; ++j) for (int c = 0; c < dh; ++c) { kt[(size_t)c * n_ctx + j] = kk[(size_t)j * d + h * dh + c]; vh[(size_t)j * dh + c] = v[(size_t)j * d + h * dh + c]; }
             gemm_chain(q + h * dh, d, n_ctx, kt, n_ctx, n_ctx, dh, S, n_ctx);
+            float* spd = NULL;
+            if (l == 0 && h == 0 && g_taps_on) { int Tp = (n_ctx + 31) & ~31; spd = (float*)calloc((size_t)64 * Tp, 4); for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)i * Tp + j] = S[(size_t)i * n_ctx + j] * KQscale; for (int i = 0; i < 32; ++i) for (int j = n_ctx; j < Tp; ++j) spd[(size_t)i * Tp + j] = -INFINITY; }
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < n_ctx; ++i) { float* s = S + (size_t)i * n_ctx; softmax_row(s, n_ctx, KQscale); for (int j = 0; j < n_ctx; ++j) s[j] = skw_round_f16(s[j]); }
+            for (int i = 0; i < n_ctx; ++i) { float* s = S + (size_t)i * n_ctx; float mx, iv; softmax_row2(s, n_ctx, KQscale, &mx, &iv); if (g_dbg_max) { g_dbg_max[(size_t)h * n_ctx + i] = mx; g_dbg_inv[(size_t)h * n_ctx + i] = iv; } for (int j = 0; j < n_ctx; ++j) s[j] = skw_round_f16(s[j]); }
+            if (spd) { int Tp = (n_ctx + 31) & ~31; for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)(32 + i) * Tp + j] = S[(size_t)i * n_ctx + j]; tap("l0.SP", spd, (size_t)64 * Tp); free(spd); }
             gemm_chain(S, n_ctx, n_ctx, vh, dh, dh, n_ctx, oh, dh);
+            if (l == 0 && g_taps_on) { static float* a32 = NULL; if (h == 0) a32 = (float*)calloc((size_t)n_ctx * d, 4); for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) a32[(size_t)i * d + h * dh + c] = oh[(size_t)i * dh + c]; if (h == nh - 1) { tap("l0.att32", a32, (size_t)n_ctx * d); free(a32); } }
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) att[(size_t)i * d + h * dh + c] = skw_round_f16(oh[(size_t)i * dh + c]);
         }
+        if (l == 0) tap("l0.att", att, (size_t)n_ctx * d);
+        if (g_dbg_max) { tap("l0.rmax", g_dbg_max, (size_t)nh * n_ctx); tap("l0.rinv", g_dbg_inv, (size_t)nh * n_ctx); free(g_dbg_max); free(g_dbg_inv); g_dbg_max = g_dbg_inv = NULL; }
         linear(att, d, n_ctx, &L->o, y, d);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < (size_t)n_ctx * d; ++i) x[i] = y[i] + x[i];
+        if (l == 0) tap("l0.x1", x, (size_t)n_ctx * d);
         layer_norm(x, n_ctx, d, &L->mlp_ln, y); round_f16_inplace(y, (size_t)n_ctx * d);
+        if (l == 0) tap("l0.ln2", y, (size_t)n_ctx * d);
         linear(y, d, n_ctx, &L->fc1, hbuf, 4 * d);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < (size_t)n_ctx * 4 * d; ++i) hbuf[i] = skw_round_f16(skw_gelu_lookup(hbuf[i], m->gelu_tab));
+        if (l == 0) tap("l0.h", hbuf, (size_t)n_ctx * 4 * d);
         linear(hbuf, 4 * d, n_ctx, &L->fc2, y, d);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < (size_t)n_ctx * d; ++i) x[i] = y[i] + x[i];
+        if (l == 0) tap("l0.x2", x, (size_t)n_ctx * d);
     }
     layer_norm(x, n_ctx, d, &m->ln_post, enc_out);
     if (cross_k && cross_v) { /* whisper_build_graph_cross */
@@ -791,4 +822,19 @@ int skwo_resampler_process(skwo_resampler* r, const float* in_planar, float* out
     }
     r->last_index = idx - (double)cs;
     return n;
+}
+
+/* arithmetic-contract probes: the CPU side of tests/test_gpu_math.py */
+void skwo_math(const skwo_model* m, int kind, const float* in, float* out, long n) {
+    for (long i = 0; i < n; ++i) {
+        float x = in[i], y;
+        if (kind == 0) y = skw_expf(x);
+        else if (kind == 1) y = skw_logf(x);
+        else if (kind == 2 || kind == 3) y = skw_round_f16(x);
+        else if (kind == 4) y = skw_gelu_lookup(x, m->gelu_tab);
+        else if (kind == 5) y = 1.0f / sqrtf(x + 1e-5f);
+        else if (kind == 6) y = (float)(1.0 / (double)x);
+        else y = (float)log10((double)x);
+        out[i] = y;
+    }
 }

@@ -21,6 +21,7 @@
  */
 #ifndef SKW_ORACLE_H
 #define SKW_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -102,6 +103,10 @@ int skwo_full(const skwo_model*, const skwo_params*, const float* pcm, int n_sam
 void skwo_result_free(skwo_result*);
 
 /* teacher-forced logits (for margin diagnostics): runs window at `seek` with given token prefix */
+
+/* debug taps of encoder layer 0 (l0.ln1, l0.q, l0.k, l0.v, l0.att, l0.x1, l0.ln2, l0.h, l0.x2), natural layouts */
+void skwo_debug_enable(int on);
+long skwo_debug_get(const char* name, float* out, size_t cap);
 
 /* R1-R3: rubato FastFixedIn<f32>, PolynomialDegree::Linear, as driven by resampler.rs */
 typedef struct skwo_resampler skwo_resampler;

@@ -1,0 +1,666 @@
+// skw_engine.hip — host side of libskw_engine.so: GGML model loading, device workspace,
+// and the batched restatement of whisper_full_with_state (greedy, T = 0) on top of skw_kernels.
+//
+// Reference call sites this replaces: /root/reference/plugins/native/whisper/src/lib.rs
+//   :354-363 model load, :377-379 state, :624-646 params + full(), :650-660 segment readout.
+#include "../../include/skw_engine.h"
+#include "../../include/skw_math.h"
+#include "skw_kernels.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define WHISPER_SAMPLE_RATE 16000
+#define WHISPER_N_FFT 400
+#define WHISPER_HOP 160
+#define WHISPER_CHUNK_SIZE 30
+
+static const char* const g_lang[] = {"en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi", "fi", "vi",
+    "he", "uk", "el", "ms", "cs", "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la", "mi", "ml", "cy", "sk", "te", "fa", "lv", "bn", "sr", "az",
+    "sl", "kn", "et", "mk", "br", "eu", "is", "hy", "ne", "mn", "bs", "kk", "sq", "sw", "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be",
+    "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo", "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue"};
+static const int g_n_lang = (int)(sizeof(g_lang) / sizeof(g_lang[0]));
+
+static const char* const NST_LIST[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
+    "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))",
+    "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
+static const int N_NST_LIST = (int)(sizeof(NST_LIST) / sizeof(NST_LIST[0]));
+
+static void set_err(char* err, size_t n, const char* fmt, ...) {
+    if (!err || !n) return;
+    va_list ap; va_start(ap, fmt); vsnprintf(err, n, fmt, ap); va_end(ap);
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(errbuf, 512, "HIP error '%s' at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
+
+struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0; };
+struct DevLN { float* w = nullptr; float* b = nullptr; };
+struct EncLayer { DevLN attn_ln, mlp_ln; DevLin q, k, v, o, fc1, fc2; };
+struct DecLayer { DevLN attn_ln, cross_ln, mlp_ln; DevLin q, k, v, o, cq, ck, cv, co, fc1, fc2; };
+
+struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; };
+
+struct skw_model {
+    skw_hparams hp{};
+    int device = 0;
+    std::vector<std::string> tok_str;
+    int tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
+    int tok_space = -1, tok_sp_dash = -1, tok_sp_quote = -1; std::vector<int> nst_ids; int n_lang = 99;
+    // device
+    float *filters = nullptr, *hann = nullptr, *sin_t = nullptr, *cos_t = nullptr; int n_fft_bins = 201;
+    uint16_t* gelu_tab = nullptr;
+    float* e_pe = nullptr; DevLin conv1, conv2; DevLN ln_post; std::vector<EncLayer> enc;
+    float* d_pe = nullptr; DevLin te; DevLN d_ln; std::vector<DecLayer> dec;
+    std::vector<void*> allocs;
+};
+
+template <typename T> static T* dev_upload(skw_model* m, const T* h, size_t n) {
+    T* d = nullptr; if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice); m->allocs.push_back(d); return d;
+}
+static RawT* find_t(std::vector<RawT>& ts, const std::string& name) { for (auto& t : ts) if (t.name == name) return &t; return nullptr; }
+static const float* as_f32(RawT* t, std::vector<float>& tmp) {
+    if (t->type == 0) return (const float*)t->data.data();
+    tmp.resize(t->n); const uint16_t* h = (const uint16_t*)t->data.data(); for (size_t i = 0; i < t->n; ++i) tmp[i] = skw_f16_to_f32(h[i]); return tmp.data();
+}
+// f16 weight [n_out][n_in] (or conv [oc][ic][kw]) -> device [n_out][k_pad] with the contraction axis in kperm order
+static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname, const char* bname, DevLin* L, char* err, size_t errlen) {
+    RawT* w = find_t(ts, wname);
+    if (!w) { set_err(err, errlen, "missing tensor %s", wname.c_str()); return false; }
+    if (w->type != 1) { set_err(err, errlen, "tensor %s: only f16 matmul weights are supported (ggml type %d)", wname.c_str(), w->type); return false; }
+    int n_in, n_out, kw = 1, ic = 0;
+    if (w->n_dims == 2) { n_in = w->ne[0]; n_out = w->ne[1]; }
+    else if (w->n_dims == 3) { kw = w->ne[0]; ic = w->ne[1]; n_in = kw * ic; n_out = w->ne[2]; }
+    else { set_err(err, errlen, "tensor %s: bad dims", wname.c_str()); return false; }
+    const int k_pad = (n_in + 31) & ~31;
+    std::vector<uint16_t> h((size_t)n_out * k_pad, 0);
+    const uint16_t* src = (const uint16_t*)w->data.data();
+    for (int o = 0; o < n_out; ++o) {
+        uint16_t* dst = h.data() + (size_t)o * k_pad;
+        if (w->n_dims == 2) for (int i = 0; i < n_in; ++i) dst[skw_kperm(i)] = src[(size_t)o * n_in + i];
+        else for (int c = 0; c < ic; ++c) for (int t = 0; t < kw; ++t) dst[skw_kperm(t * ic + c)] = src[((size_t)o * ic + c) * kw + t];
+    }
+    L->n_in = n_in; L->n_out = n_out; L->k_pad = k_pad;
+    L->w = (half_t*)dev_upload(m, h.data(), h.size());
+    if (!L->w) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; }
+    L->b = nullptr;
+    if (bname) {
+        RawT* b = find_t(ts, bname);
+        if (!b) { set_err(err, errlen, "missing tensor %s", bname); return false; }
+        std::vector<float> tmp; L->b = dev_upload(m, as_f32(b, tmp), b->n);
+    }
+    return true;
+}
+static bool up_ln(skw_model* m, std::vector<RawT>& ts, const std::string& wname, const std::string& bname, DevLN* L, char* err, size_t errlen) {
+    RawT* w = find_t(ts, wname); RawT* b = find_t(ts, bname);
+    if (!w || !b) { set_err(err, errlen, "missing tensor %s / %s", wname.c_str(), bname.c_str()); return false; }
+    std::vector<float> t1, t2; L->w = dev_upload(m, as_f32(w, t1), w->n); L->b = dev_upload(m, as_f32(b, t2), b->n); return L->w && L->b;
+}
+
+extern "C" int skw_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int skw_model_lang_id(const char* lang) { if (!lang) return -1; for (int i = 0; i < g_n_lang; ++i) if (!strcmp(g_lang[i], lang)) return i; return -1; }
+
+extern "C" skw_model* skw_model_load(const char* path, int device, char* err, size_t errlen) {
+    int ndev = skw_device_count();
+    if (ndev <= 0) { set_err(err, errlen, "no HIP device available: libskw_engine requires an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= ndev) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", device, ndev); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "hipSetDevice(%d) failed", device); return nullptr; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_err(err, errlen, "Failed to load Whisper model from '%s': cannot open file", path); return nullptr; }
+    int32_t magic = 0;
+    if (fread(&magic, 4, 1, f) != 1 || magic != 0x67676d6c) { fclose(f); set_err(err, errlen, "Failed to load Whisper model from '%s': bad magic", path); return nullptr; }
+    skw_model* m = new skw_model(); m->device = device;
+    auto fail = [&](const char* msg) -> skw_model* { set_err(err, errlen, "Failed to load Whisper model from '%s': %s", path, msg); fclose(f); skw_model_free(m); return nullptr; };
+    if (fread(&m->hp, 4, 11, f) != 11) return fail("short hparams");
+    int32_t nm = 0, nf = 0;
+    if (fread(&nm, 4, 1, f) != 1 || fread(&nf, 4, 1, f) != 1) return fail("short mel filter header");
+    std::vector<float> filt((size_t)nm * nf);
+    if (fread(filt.data(), 4, filt.size(), f) != filt.size()) return fail("short mel filters");
+    m->n_fft_bins = nf;
+    if (nm != m->hp.n_mels) return fail("mel filter count differs from n_mels");
+    int32_t nv = 0; if (fread(&nv, 4, 1, f) != 1) return fail("short vocab");
+    const int NV = m->hp.n_vocab; m->tok_str.assign(NV, std::string());
+    for (int i = 0; i < nv; ++i) {
+        uint32_t len = 0; if (fread(&len, 4, 1, f) != 1) return fail("short vocab");
+        std::string s(len, '\0'); if (len && fread(&s[0], 1, len, f) != len) return fail("short vocab");
+        if (i < NV) m->tok_str[i] = s;
+    }
+    m->tok_eot = 50256; m->tok_sot = 50257; m->tok_translate = 50357; m->tok_transcribe = 50358; m->tok_solm = 50359;
+    m->tok_prev = 50360; m->tok_nosp = 50361; m->tok_not = 50362; m->tok_beg = 50363;
+    if (NV >= 51865) {
+        m->tok_eot++; m->tok_sot++; const int dt = NV - 51865;
+        m->tok_translate += 1 + dt; m->tok_transcribe += 1 + dt; m->tok_solm += 1 + dt; m->tok_prev += 1 + dt; m->tok_nosp += 1 + dt; m->tok_not += 1 + dt; m->tok_beg += 1 + dt;
+        m->n_lang = 99 + dt;
+    }
+    for (int i = nv; i < NV; ++i) {
+        char buf[64];
+        if (i > m->tok_beg) snprintf(buf, sizeof buf, "[_TT_%d]", i - m->tok_beg);
+        else if (i == m->tok_eot) snprintf(buf, sizeof buf, "[_EOT_]");
+        else if (i == m->tok_sot) snprintf(buf, sizeof buf, "[_SOT_]");
+        else if (i == m->tok_translate) snprintf(buf, sizeof buf, "[_TRANSLATE_]");
+        else if (i == m->tok_transcribe) snprintf(buf, sizeof buf, "[_TRANSCRIBE_]");
+        else if (i == m->tok_solm) snprintf(buf, sizeof buf, "[_SOLM_]");
+        else if (i == m->tok_prev) snprintf(buf, sizeof buf, "[_PREV_]");
+        else if (i == m->tok_nosp) snprintf(buf, sizeof buf, "[_NOSP_]");
+        else if (i == m->tok_not) snprintf(buf, sizeof buf, "[_NOT_]");
+        else if (i == m->tok_beg) snprintf(buf, sizeof buf, "[_BEG_]");
+        else if (i > m->tok_sot && i <= m->tok_sot + m->n_lang) snprintf(buf, sizeof buf, "[_LANG_%s]", g_lang[std::min(i - m->tok_sot - 1, g_n_lang - 1)]);
+        else snprintf(buf, sizeof buf, "[_extra_token_%d]", i);
+        m->tok_str[i] = buf;
+    }
+    { // token_to_id lookups performed by whisper_process_logits (a later duplicate string wins, as std::map::operator[] does)
+        std::map<std::string, int> t2i; for (int i = 0; i < NV; ++i) t2i[m->tok_str[i]] = i;
+        auto get = [&](const std::string& s) { auto it = t2i.find(s); return it == t2i.end() ? -1 : it->second; };
+        m->tok_space = get(" "); m->tok_sp_dash = get(" -"); m->tok_sp_quote = get(" '");
+        for (int j = 0; j < N_NST_LIST; ++j) for (int sp = 0; sp < 2; ++sp) { int id = get(std::string(sp ? " " : "") + NST_LIST[j]); if (id >= 0) m->nst_ids.push_back(id); }
+    }
+    std::vector<RawT> ts;
+    for (;;) {
+        int32_t nd, len, tt; if (fread(&nd, 4, 1, f) != 1) break;
+        if (fread(&len, 4, 1, f) != 1 || fread(&tt, 4, 1, f) != 1) return fail("short tensor header");
+        RawT t; t.n_dims = nd; t.type = tt; t.n = 1;
+        if (nd < 1 || nd > 4 || len < 0 || len > 255) return fail("corrupt tensor header");
+        for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
+        t.name.resize(len); if (len && fread(&t.name[0], 1, len, f) != (size_t)len) return fail("short tensor name");
+        size_t esz = tt == 0 ? 4 : tt == 1 ? 2 : 0;
+        if (!esz) { std::string msg = "tensor " + t.name + ": unsupported ggml type (quantised models are not supported yet)"; return fail(msg.c_str()); }
+        t.data.resize(t.n * esz); if (fread(t.data.data(), 1, t.data.size(), f) != t.data.size()) return fail("short tensor data");
+        ts.push_back(std::move(t));
+    }
+    fclose(f); f = nullptr;
+    auto fail2 = [&]() -> skw_model* { skw_model_free(m); return nullptr; };
+    // tables
+    m->filters = dev_upload(m, filt.data(), filt.size());
+    {
+        std::vector<float> sn(WHISPER_N_FFT), cs(WHISPER_N_FFT), hn(WHISPER_N_FFT);
+        for (int i = 0; i < WHISPER_N_FFT; ++i) { double theta = (2 * M_PI * i) / WHISPER_N_FFT; sn[i] = sinf(theta); cs[i] = cosf(theta); hn[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / (WHISPER_N_FFT))); }
+        m->sin_t = dev_upload(m, sn.data(), sn.size()); m->cos_t = dev_upload(m, cs.data(), cs.size()); m->hann = dev_upload(m, hn.data(), hn.size());
+        std::vector<uint16_t> gt(65536); for (int i = 0; i < 65536; ++i) gt[i] = skw_gelu_table_entry((uint16_t)i);
+        m->gelu_tab = dev_upload(m, gt.data(), gt.size());
+    }
+    std::vector<float> tmp;
+    RawT* t;
+    if (!(t = find_t(ts, "encoder.positional_embedding"))) { set_err(err, errlen, "missing encoder.positional_embedding"); return fail2(); }
+    m->e_pe = dev_upload(m, as_f32(t, tmp), t->n);
+    if (!(t = find_t(ts, "decoder.positional_embedding"))) { set_err(err, errlen, "missing decoder.positional_embedding"); return fail2(); }
+    m->d_pe = dev_upload(m, as_f32(t, tmp), t->n);
+    bool ok = true;
+    ok = ok && up_lin(m, ts, "encoder.conv1.weight", "encoder.conv1.bias", &m->conv1, err, errlen);
+    ok = ok && up_lin(m, ts, "encoder.conv2.weight", "encoder.conv2.bias", &m->conv2, err, errlen);
+    ok = ok && up_ln(m, ts, "encoder.ln_post.weight", "encoder.ln_post.bias", &m->ln_post, err, errlen);
+    m->enc.resize(m->hp.n_audio_layer);
+    for (int l = 0; l < m->hp.n_audio_layer && ok; ++l) {
+        EncLayer& L = m->enc[l]; std::string p = "encoder.blocks." + std::to_string(l) + ".";
+        ok = ok && up_ln(m, ts, p + "attn_ln.weight", p + "attn_ln.bias", &L.attn_ln, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.query.weight", (p + "attn.query.bias").c_str(), &L.q, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.key.weight", nullptr, &L.k, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.value.weight", (p + "attn.value.bias").c_str(), &L.v, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.out.weight", (p + "attn.out.bias").c_str(), &L.o, err, errlen);
+        ok = ok && up_ln(m, ts, p + "mlp_ln.weight", p + "mlp_ln.bias", &L.mlp_ln, err, errlen);
+        ok = ok && up_lin(m, ts, p + "mlp.0.weight", (p + "mlp.0.bias").c_str(), &L.fc1, err, errlen);
+        ok = ok && up_lin(m, ts, p + "mlp.2.weight", (p + "mlp.2.bias").c_str(), &L.fc2, err, errlen);
+    }
+    ok = ok && up_lin(m, ts, "decoder.token_embedding.weight", nullptr, &m->te, err, errlen);
+    ok = ok && up_ln(m, ts, "decoder.ln.weight", "decoder.ln.bias", &m->d_ln, err, errlen);
+    m->dec.resize(m->hp.n_text_layer);
+    for (int l = 0; l < m->hp.n_text_layer && ok; ++l) {
+        DecLayer& L = m->dec[l]; std::string p = "decoder.blocks." + std::to_string(l) + ".";
+        ok = ok && up_ln(m, ts, p + "attn_ln.weight", p + "attn_ln.bias", &L.attn_ln, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.query.weight", (p + "attn.query.bias").c_str(), &L.q, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.key.weight", nullptr, &L.k, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.value.weight", (p + "attn.value.bias").c_str(), &L.v, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.out.weight", (p + "attn.out.bias").c_str(), &L.o, err, errlen);
+        ok = ok && up_ln(m, ts, p + "cross_attn_ln.weight", p + "cross_attn_ln.bias", &L.cross_ln, err, errlen);
+        ok = ok && up_lin(m, ts, p + "cross_attn.query.weight", (p + "cross_attn.query.bias").c_str(), &L.cq, err, errlen);
+        ok = ok && up_lin(m, ts, p + "cross_attn.key.weight", nullptr, &L.ck, err, errlen);
+        ok = ok && up_lin(m, ts, p + "cross_attn.value.weight", (p + "cross_attn.value.bias").c_str(), &L.cv, err, errlen);
+        ok = ok && up_lin(m, ts, p + "cross_attn.out.weight", (p + "cross_attn.out.bias").c_str(), &L.co, err, errlen);
+        ok = ok && up_ln(m, ts, p + "mlp_ln.weight", p + "mlp_ln.bias", &L.mlp_ln, err, errlen);
+        ok = ok && up_lin(m, ts, p + "mlp.0.weight", (p + "mlp.0.bias").c_str(), &L.fc1, err, errlen);
+        ok = ok && up_lin(m, ts, p + "mlp.2.weight", (p + "mlp.2.bias").c_str(), &L.fc2, err, errlen);
+    }
+    if (!ok) return fail2();
+    if ((m->hp.n_audio_state / m->hp.n_audio_head) != 64 || (m->hp.n_text_state / m->hp.n_text_head) != 64 || m->hp.n_audio_state % 64 || m->hp.n_audio_state > 1536) {
+        set_err(err, errlen, "unsupported model geometry (head dim must be 64, state <= 1536)"); return fail2();
+    }
+    hipDeviceSynchronize();
+    return m;
+}
+extern "C" void skw_model_free(skw_model* m) { if (!m) return; hipSetDevice(m->device); for (void* p : m->allocs) hipFree(p); delete m; }
+extern "C" void skw_model_get_hparams(const skw_model* m, skw_hparams* out) { *out = m->hp; }
+extern "C" const char* skw_model_token_text(const skw_model* m, int id, int* len) {
+    if (id < 0 || id >= m->hp.n_vocab) { if (len) *len = 0; return ""; }
+    if (len) *len = (int)m->tok_str[id].size(); return m->tok_str[id].c_str();
+}
+extern "C" void skw_full_default_params(skw_full_params* p) {
+    memset(p, 0, sizeof *p); p->lang_id = 0; p->suppress_blank = 1; p->suppress_nst = 0; p->max_initial_ts = 1.0f; p->entropy_thold = 2.4f; p->logprob_thold = -1.0f; p->no_speech_thold = 0.6f;
+}
+
+// ------------------------------------------------------------------ context / workspace
+struct skw_ctx {
+    skw_model* m = nullptr; int max_batch = 0, max_samples = 0, n_len_max = 0, Tpad = 0;
+    hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
+    char errbuf[512] = {0};
+    std::vector<void*> allocs;
+    // front end
+    float* pcm = nullptr; long* pcm_off = nullptr; int* n_samples = nullptr; int* n_len = nullptr; float* mel = nullptr; float* clip_max = nullptr;
+    int *clip_idx = nullptr, *seek = nullptr;
+    half_t* im2col = nullptr; half_t* h1 = nullptr;
+    // encoder
+    float* x = nullptr; half_t* y16 = nullptr; half_t *Qh = nullptr, *Kh = nullptr, *Vt = nullptr; half_t* hbuf = nullptr; float* enc_out32 = nullptr;
+    half_t *crossK = nullptr, *crossV = nullptr;
+    // decoder
+    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; int* n_active = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
+    SkwSeqState* h_st = nullptr; SkwTokenOut* h_toks = nullptr; int* h_n_active = nullptr; // pinned
+    int max_tok = 0;
+    skw_timing timing{};
+    int last_enc_B = 0;
+};
+template <typename T> static T* ws_alloc(skw_ctx* c, size_t n, bool zero = false) {
+    T* d = nullptr; if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr; if (zero) (void)hipMemset(d, 0, n * sizeof(T)); c->allocs.push_back(d); return d;
+}
+extern "C" const char* skw_ctx_last_error(const skw_ctx* c) { return c->errbuf; }
+extern "C" void* skw_ctx_stream(const skw_ctx* c) { return (void*)c->stream; }
+extern "C" void skw_ctx_last_timing(const skw_ctx* c, skw_timing* out) { *out = c->timing; }
+
+extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples, char* err, size_t errlen) {
+    if (!m || max_batch < 1) { set_err(err, errlen, "bad arguments"); return nullptr; }
+    if (hipSetDevice(m->device) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return nullptr; }
+    skw_ctx* c = new skw_ctx(); c->m = m; c->max_batch = max_batch;
+    if (max_samples <= 0) max_samples = WHISPER_SAMPLE_RATE * 31;
+    c->max_samples = max_samples;
+    c->n_len_max = (max_samples + WHISPER_SAMPLE_RATE * 30 + 2 * (WHISPER_N_FFT / 2) - WHISPER_N_FFT) / WHISPER_HOP + 1;
+    const skw_hparams& hp = m->hp; const int B = max_batch, nc = hp.n_audio_ctx, T = 2 * nc, d = hp.n_audio_state, dt = hp.n_text_state;
+    c->Tpad = (nc + 31) & ~31;
+    bool ok = true;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+    for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+#define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
+    WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
+    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false);
+    WS(im2col, half_t, (size_t)B * T * 256, false); WS(h1, half_t, (size_t)B * (T + 2) * d, true);
+    WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
+    WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
+    WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
+    WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * nc * dt, false);
+    WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
+    WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
+    WS(logits, float, (size_t)B * hp.n_vocab, false);
+    c->max_tok = hp.n_text_ctx / 2;
+    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, 1, true); WS(static_mask, uint8_t, hp.n_vocab, true);
+#undef WS
+    ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_n_active, sizeof(int)) == hipSuccess;
+    if (!ok) { set_err(err, errlen, "workspace allocation failed (max_batch %d)", max_batch); skw_ctx_free(c); return nullptr; }
+    hipDeviceSynchronize();
+    return c;
+}
+extern "C" void skw_ctx_free(skw_ctx* c) {
+    if (!c) return; hipSetDevice(c->m->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_n_active) hipHostFree(c->h_n_active);
+    for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------ debug taps (encoder layer 0, natural layouts; enabled by skw_debug_enable)
+static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on = false;
+extern "C" void skw_debug_enable(int on) { g_taps_on = on != 0; g_taps.clear(); }
+extern "C" long skw_debug_get(const char* name, float* out, size_t cap) {
+    auto it = g_taps.find(name); if (it == g_taps.end()) return -1; if (out && cap >= it->second.size()) memcpy(out, it->second.data(), it->second.size() * 4); return (long)it->second.size();
+}
+enum TapLayout { TAP_F32, TAP_F16_KPERM, TAP_HEADS, TAP_VT };
+static void tap(skw_ctx* c, const char* name, const void* dev, int rows, int cols, TapLayout lay) {
+    if (!g_taps_on) return;
+    hipStreamSynchronize(c->stream);
+    std::vector<float>& o = g_taps[name]; o.assign((size_t)rows * cols, 0.f);
+    const int H = c->m->hp.n_audio_head, Tpad = c->Tpad;
+    if (lay == TAP_F32) { hipMemcpy(o.data(), dev, o.size() * 4, hipMemcpyDeviceToHost); return; }
+    if (lay == TAP_F16_KPERM) {
+        std::vector<uint16_t> h((size_t)rows * cols); hipMemcpy(h.data(), dev, h.size() * 2, hipMemcpyDeviceToHost);
+        for (int r = 0; r < rows; ++r) for (int i = 0; i < cols; ++i) o[(size_t)r * cols + i] = skw_f16_to_f32(h[(size_t)r * cols + skw_kperm(i)]);
+    } else if (lay == TAP_HEADS) {   // [(h)*Tpad + i][kperm(d)] for batch 0
+        std::vector<uint16_t> h((size_t)H * Tpad * 64); hipMemcpy(h.data(), dev, h.size() * 2, hipMemcpyDeviceToHost);
+        for (int r = 0; r < rows; ++r) for (int n = 0; n < cols; ++n) o[(size_t)r * cols + n] = skw_f16_to_f32(h[((size_t)(n >> 6) * Tpad + r) * 64 + skw_kperm(n & 63)]);
+    } else {                          // V^T: [(h*64 + c)][kperm(key)] row stride Tpad
+        std::vector<uint16_t> h((size_t)H * 64 * Tpad); hipMemcpy(h.data(), dev, h.size() * 2, hipMemcpyDeviceToHost);
+        for (int r = 0; r < rows; ++r) for (int n = 0; n < cols; ++n) o[(size_t)r * cols + n] = skw_f16_to_f32(h[((size_t)n) * Tpad + skw_kperm(r)]);
+    }
+}
+
+// ------------------------------------------------------------------ GEMM helpers
+static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
+    SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
+}
+
+// front end for `n` clips already described in c->pcm_off / n_samples / n_len (device): mel + normalisation
+static void run_mel(skw_ctx* c, int n) {
+    skw_model* m = c->m; SkwMelTables t{m->hann, m->sin_t, m->cos_t, m->filters, m->hp.n_mels, m->n_fft_bins};
+    skw_mel_frames(c->pcm, c->pcm_off, c->n_samples, c->n_len, n, c->n_len_max, t, c->mel, c->stream);
+    skw_mel_normalize(c->mel, c->n_len, n, c->n_len_max, m->hp.n_mels, c->clip_max, c->stream);
+}
+// conv stem for Bw window slots (clip_idx/seek on device) -> c->x [Bw*nc][d]
+static void run_conv(skw_ctx* c, int Bw) {
+    skw_model* m = c->m; const int nc = m->hp.n_audio_ctx, T = 2 * nc, d = m->hp.n_audio_state;
+    skw_mel_im2col(c->mel, c->clip_idx, c->seek, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
+    SkwGemmArgs a = gemm_args(c->im2col, 256, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
+    skw_gemm(a, c->stream);
+    SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d; b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;
+    skw_gemm(b, c->stream);
+}
+// encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
+static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
+    skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, M = Bw * nc;
+    for (int l = 0; l < hp.n_audio_layer; ++l) {
+        const EncLayer& L = m->enc[l];
+        skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, c->y16, nullptr, c->stream);
+        if (l == 0) tap(c, "l0.ln1", c->y16, nc, d, TAP_F16_KPERM);
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.q, M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; skw_gemm(a, c->stream); }
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.k, M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; skw_gemm(a, c->stream); }
+        { // V^T via the swapped product: rows = features (weights as the A operand), columns = tokens
+            SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt; a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
+            skw_gemm(a, c->stream);
+        }
+        if (l == 0) { tap(c, "l0.q", c->Qh, nc, d, TAP_HEADS); tap(c, "l0.k", c->Kh, nc, d, TAP_HEADS); tap(c, "l0.v", c->Vt, nc, d, TAP_VT); }
+        float* dbg = nullptr;
+        if (l == 0 && g_taps_on) { hipMalloc((void**)&dbg, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc + 64)); hipMemset(dbg, 0, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc)); }
+        float* dbg2 = nullptr;
+        if (dbg) { hipMalloc((void**)&dbg2, sizeof(float) * 64 * c->Tpad); hipMemset(dbg2, 0, sizeof(float) * 64 * c->Tpad); }
+        skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2);
+        if (dbg2) { tap(c, "l0.SP", dbg2, 64, c->Tpad, TAP_F32); hipFree(dbg2); }
+        if (dbg) { tap(c, "l0.att32", dbg, nc, d, TAP_F32); tap(c, "l0.rmax", dbg + (size_t)nc * d, H, nc, TAP_F32); tap(c, "l0.rinv", dbg + (size_t)nc * d + (size_t)H * nc, H, nc, TAP_F32); hipFree(dbg); }
+        if (l == 0) tap(c, "l0.att", c->y16, nc, d, TAP_F16_KPERM);
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.o, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; skw_gemm(a, c->stream); }
+        if (l == 0) tap(c, "l0.x1", c->x, nc, d, TAP_F32);
+        skw_layernorm(c->x, M, d, L.mlp_ln.w, L.mlp_ln.b, c->y16, nullptr, c->stream);
+        if (l == 0) tap(c, "l0.ln2", c->y16, nc, d, TAP_F16_KPERM);
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.fc1, M, c->hbuf, 4L * d, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; skw_gemm(a, c->stream); }
+        if (l == 0) tap(c, "l0.h", c->hbuf, nc, 4 * d, TAP_F16_KPERM);
+        { SkwGemmArgs a = gemm_args(c->hbuf, 4L * d, L.fc2, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; skw_gemm(a, c->stream); }
+        if (l == 0) tap(c, "l0.x2", c->x, nc, d, TAP_F32);
+    }
+    skw_layernorm(c->x, M, d, m->ln_post.w, m->ln_post.b, c->y16, want_f32_out ? c->enc_out32 : nullptr, c->stream);
+    if (cross) {
+        const int dt = hp.n_text_state; const float Kscale = (float)pow((double)((float)dt / hp.n_text_head), -0.25);
+        for (int l = 0; l < hp.n_text_layer; ++l) {
+            const DecLayer& L = m->dec[l];
+            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; skw_gemm(a, c->stream); }
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.cv, M, cv, dt, EPI_F16_PLAIN); skw_gemm(a, c->stream); }
+        }
+    }
+    c->last_enc_B = Bw;
+}
+
+// one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
+__global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; }
+static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
+    skw_model* m = c->m; const skw_hparams& hp = m->hp; const int dt = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, ntc = hp.n_text_ctx;
+    const float KQscale = (float)pow((double)((float)dt / H), -0.25);
+    hipStream_t s = c->stream;
+    skw_dec_embed(m->te.w, m->d_pe, &c->st[0].cur_token, &c->st[0].cur_pos, Bw, dt, c->dx, s);
+    for (int l = 0; l < hp.n_text_layer; ++l) {
+        const DecLayer& L = m->dec[l];
+        half_t* sk = c->selfK + (size_t)l * c->max_batch * ntc * dt; half_t* sv = c->selfV + (size_t)l * c->max_batch * ntc * dt;
+        half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
+        skw_layernorm(c->dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, c->dy16, nullptr, s);
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.q, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.k, Bw, sk + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.v, Bw, sv + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); skw_gemm_smallm(a, s); }
+        skw_dec_self_attn(c->dq16, sk, sv, &c->st[0].cur_pos, Bw, H, dt, ntc, c->datt16, s);
+        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+        skw_layernorm(c->dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, c->dy16, nullptr, s);
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.cq, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
+        skw_dec_cross_attn(c->dq16, ck, cv, Bw, H, dt, nc, c->datt16, s);
+        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.co, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+        skw_layernorm(c->dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, c->dy16, nullptr, s);
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.fc1, Bw, c->dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dh16, 4L * dt, L.fc2, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+    }
+    if (want_logits) {
+        skw_layernorm(c->dx, Bw, dt, m->d_ln.w, m->d_ln.b, c->dy16, nullptr, s);
+        SkwGemmArgs a = gemm_args(c->dy16, dt, m->te, Bw, c->logits, hp.n_vocab, EPI_F32); skw_gemm_smallm(a, s);
+    }
+}
+
+static void build_static_mask(skw_ctx* c, const skw_full_params* p) {
+    if (c->static_mask_nst == (p->suppress_nst ? 1 : 0)) return;
+    skw_model* m = c->m; std::vector<uint8_t> mask(m->hp.n_vocab, 0);
+    mask[m->tok_not] = 1; mask[m->tok_sot] = 1; mask[m->tok_nosp] = 1; mask[m->tok_solm] = 1; mask[m->tok_translate] = 1; mask[m->tok_transcribe] = 1; mask[m->tok_prev] = 1;
+    for (int i = 0; i < m->n_lang; ++i) mask[m->tok_sot + 1 + i] = 1;
+    if (p->suppress_nst) { for (int id : m->nst_ids) mask[id] = 1; if (m->tok_sp_dash >= 0) mask[m->tok_sp_dash] = 1; if (m->tok_sp_quote >= 0) mask[m->tok_sp_quote] = 1; }
+    hipMemcpyAsync(c->static_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, c->stream); hipStreamSynchronize(c->stream);
+    c->static_mask_nst = p->suppress_nst ? 1 : 0;
+}
+
+struct SeqAcc { std::vector<skw_segment> seg; std::vector<skw_token> tok; std::string text; };
+
+// whisper_sequence_score: avg_logprobs + entropy of the last 32 tokens
+static void sequence_score(const SkwTokenOut* tk, int result_len, double* avg_logprobs, double* entropy) {
+    *avg_logprobs = -INFINITY; *entropy = 0.0; if (result_len == 0) return;
+    double result = 0.0; for (int i = 0; i < result_len; ++i) result += tk[i].plog;
+    *avg_logprobs = result / result_len;
+    std::map<int, int> cnts; int cnt = 0; for (int i = std::max(0, result_len - 32); i < result_len; ++i) { cnts[tk[i].id]++; cnt++; }
+    double e = 0.0; for (auto& kv : cnts) { double pp = kv.second / (double)cnt; e -= pp * log(pp); } *entropy = e;
+}
+
+static int load_clips(skw_ctx* c, const float* const* pcm, const int32_t* n_samples, int n, int on_device, std::vector<int>& n_len, std::vector<int>& n_len_org) {
+    char* errbuf = c->errbuf;
+    std::vector<long> off(n); std::vector<int> ns(n); n_len.resize(n); n_len_org.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (n_samples[i] < 0 || n_samples[i] > c->max_samples) { snprintf(errbuf, 512, "clip %d has %d samples; context was created for at most %d", i, n_samples[i], c->max_samples); return -1; }
+        off[i] = (long)i * c->max_samples; ns[i] = n_samples[i];
+        n_len[i] = (int)(((long)n_samples[i] + WHISPER_SAMPLE_RATE * 30 + 2 * (WHISPER_N_FFT / 2) - WHISPER_N_FFT) / WHISPER_HOP);
+        n_len_org[i] = 1 + (n_samples[i] + WHISPER_N_FFT / 2 - WHISPER_N_FFT) / WHISPER_HOP;
+        if (n_samples[i] > 0) HIPCHK(hipMemcpyAsync(c->pcm + off[i], pcm[i], sizeof(float) * n_samples[i], on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->pcm_off, off.data(), sizeof(long) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->n_samples, ns.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->n_len, n_len.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // host vectors go out of scope
+    return 0;
+}
+
+extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
+    char* errbuf = c->errbuf; errbuf[0] = 0;
+    if (n_clips < 1 || n_clips > c->max_batch) { snprintf(errbuf, 512, "n_clips %d outside [1, %d]", n_clips, c->max_batch); return -1; }
+    HIPCHK(hipSetDevice(c->m->device));
+    skw_model* m = c->m; const skw_hparams& hp = m->hp; const int NV = hp.n_vocab;
+    for (int i = 0; i < n_clips; ++i) { memset(&results[i], 0, sizeof(skw_result)); results[i].min_margin = INFINITY; }
+    std::vector<int> n_len, n_len_org;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (load_clips(c, pcm, n_samples, n_clips, pcm_on_device, n_len, n_len_org)) return -1;
+    build_static_mask(c, p);
+    run_mel(c, n_clips);
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0;
+
+    std::vector<int> seek(n_clips, 0); std::vector<SeqAcc> acc(n_clips);
+    int32_t prompt[8]; int n_prompt = 0;
+    prompt[n_prompt++] = m->tok_sot;
+    if (NV >= 51865) { prompt[n_prompt++] = m->tok_sot + 1 + p->lang_id; prompt[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
+    if (p->no_timestamps) prompt[n_prompt++] = m->tok_not;
+    SkwLogitParams lp{}; lp.n_vocab = NV; lp.tok_eot = m->tok_eot; lp.tok_sot = m->tok_sot; lp.tok_translate = m->tok_translate; lp.tok_transcribe = m->tok_transcribe; lp.tok_solm = m->tok_solm;
+    lp.tok_prev = m->tok_prev; lp.tok_nosp = m->tok_nosp; lp.tok_not = m->tok_not; lp.tok_beg = m->tok_beg; lp.n_lang = m->n_lang; lp.tok_space = m->tok_space; lp.tok_sp_dash = m->tok_sp_dash; lp.tok_sp_quote = m->tok_sp_quote;
+    lp.suppress_blank = p->suppress_blank; lp.suppress_nst = p->suppress_nst; lp.no_timestamps = p->no_timestamps; lp.single_segment = p->single_segment; lp.max_tokens = p->max_tokens;
+    lp.tid0_initial = -1;
+    if (p->max_initial_ts > 0.0f) { const float precision = (float)WHISPER_CHUNK_SIZE / hp.n_audio_ctx; lp.tid0_initial = (int)roundf(p->max_initial_ts / precision); }
+    lp.n_max = hp.n_text_ctx / 2 - 4;
+
+    while (true) {
+        // clips that still have audio to decode ("if only 1 second left, then stop"; "input is too short")
+        std::vector<int> act; for (int i = 0; i < n_clips; ++i) if (n_len_org[i] >= 100 && seek[i] + 100 < n_len_org[i]) act.push_back(i);
+        if (act.empty()) break;
+        const int Bw = (int)act.size();
+        std::vector<int> sk(Bw); for (int j = 0; j < Bw; ++j) sk[j] = seek[act[j]];
+        HIPCHK(hipMemcpyAsync(c->clip_idx, act.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->seek, sk.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        run_conv(c, Bw);
+        run_encoder(c, Bw, false, true);
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        // decoder state
+        for (int j = 0; j < Bw; ++j) {
+            SkwSeqState& s = c->h_st[j]; memset(&s, 0, sizeof s);
+            s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = n_prompt; s.min_margin = INFINITY;
+        }
+        HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
+        *c->h_n_active = Bw;
+        HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        for (int t = 0; t < n_prompt; ++t) {
+            hipLaunchKernelGGL(k_set_tokens, dim3(Bw), dim3(1), 0, c->stream, c->st, prompt[t], t);
+            run_decoder_step(c, Bw, t, t == n_prompt - 1);
+            tot_steps++;
+        }
+        for (int i = 0; i < lp.n_max; ++i) {
+            skw_dec_sample(c->logits, c->static_mask, lp, c->st, c->toks, c->max_tok, Bw, c->n_active, c->stream);
+            HIPCHK(hipMemcpyAsync(c->h_n_active, c->n_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (*c->h_n_active <= 0 || i == lp.n_max - 1) break;
+            run_decoder_step(c, Bw, n_prompt + i, true);
+            tot_steps++;
+        }
+        HIPCHK(hipMemcpyAsync(c->h_st, c->st, sizeof(SkwSeqState) * Bw, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_toks, c->toks, sizeof(SkwTokenOut) * Bw * c->max_tok, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        { float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[2], c->ev[3]); hipEventElapsedTime(&b, c->ev[3], c->ev[4]); enc_ms += a; dec_ms += b; }
+        tot_windows += Bw;
+        // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
+        for (int j = 0; j < Bw; ++j) {
+            const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];
+            R.n_windows++; R.n_decode_steps += n_prompt > 0 ? 1 : 0; R.n_decode_steps += std::max(0, s.n_tokens - 1);
+            bool failed = s.failed != 0; int n_tok = s.n_tokens; const int result_len = s.result_len;
+            double avg_logprobs = -INFINITY, entropy = 0.0;
+            if (!failed) { n_tok = result_len; sequence_score(tk, result_len, &avg_logprobs, &entropy); if (result_len > 32 && entropy < p->entropy_thold) failed = true; }
+            if (failed || (avg_logprobs < p->logprob_thold && s.no_speech_prob < p->no_speech_thold)) R.fallback_requested++;
+            if (s.min_margin < R.min_margin) R.min_margin = s.min_margin;
+            int seek_delta = s.seek_delta;
+            const bool is_no_speech = (s.no_speech_prob > p->no_speech_thold && avg_logprobs < p->logprob_thold);
+            if (n_tok > 0 && !is_no_speech) {
+                int i0 = 0; int64_t t0 = seek[ci] + 2 * (tk[0].tid - m->tok_beg); std::string text;
+                auto push = [&](int64_t a, int64_t b, int from, int to) {
+                    skw_segment sg{}; sg.t0 = a; sg.t1 = b; sg.tok_begin = (int)A.tok.size();
+                    for (int q = from; q < to; ++q) { skw_token o{tk[q].id, tk[q].tid, tk[q].p, tk[q].plog, tk[q].pt, tk[q].ptsum}; A.tok.push_back(o); }
+                    sg.tok_end = (int)A.tok.size(); sg.text_off = (int)A.text.size(); sg.text_len = (int)text.size(); A.text += text; A.seg.push_back(sg);
+                };
+                for (int i = 0; i < n_tok; ++i) {
+                    if (tk[i].id < m->tok_eot) text += m->tok_str[tk[i].id];
+                    if (tk[i].id > m->tok_beg && !p->single_segment) {
+                        const int64_t t1 = seek[ci] + 2 * (tk[i].tid - m->tok_beg);
+                        if (!text.empty()) push(t0, t1, i0, i + 1);
+                        text.clear();
+                        while (i < n_tok && tk[i].id > m->tok_beg) i++;
+                        i--; t0 = t1; i0 = i + 1;
+                    }
+                }
+                if (!text.empty()) push(t0, seek[ci] + seek_delta, i0, n_tok);
+            }
+            const bool single_timestamp_ending = n_tok > 1 && tk[n_tok - 2].id < m->tok_beg && tk[n_tok - 1].id > m->tok_beg;
+            if (single_timestamp_ending) seek_delta = std::min(n_len_org[ci] - seek[ci], WHISPER_CHUNK_SIZE * 100);
+            seek[ci] += seek_delta;
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_clips; ++i) {
+        skw_result& R = results[i]; SeqAcc& A = acc[i];
+        R.n_segments = (int)A.seg.size(); R.n_tokens = (int)A.tok.size(); R.text_len = (int)A.text.size();
+        R.segments = (skw_segment*)malloc(sizeof(skw_segment) * std::max<size_t>(1, A.seg.size())); memcpy(R.segments, A.seg.data(), sizeof(skw_segment) * A.seg.size());
+        R.tokens = (skw_token*)malloc(sizeof(skw_token) * std::max<size_t>(1, A.tok.size())); memcpy(R.tokens, A.tok.data(), sizeof(skw_token) * A.tok.size());
+        R.text = (char*)malloc(A.text.size() + 1); memcpy(R.text, A.text.data(), A.text.size()); R.text[A.text.size()] = 0;
+        tot_tokens += R.n_tokens;
+    }
+    { float a = 0, t = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&t, c->ev[0], c->ev[5]);
+      c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms; c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps; c->timing.n_tokens = tot_tokens; }
+    return 0;
+}
+extern "C" void skw_result_free(skw_result* r) { if (!r) return; free(r->segments); free(r->tokens); free(r->text); memset(r, 0, sizeof *r); }
+
+// ------------------------------------------------------------------ stage taps
+__global__ void k_transpose_mel(const float* mel, int n_len, int n_mel, float* out) {   // [frame][mel] -> [mel][frame]
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)n_len * n_mel) return; int fr = (int)(i / n_mel), j = (int)(i % n_mel); out[(long)j * n_len + fr] = mel[i];
+}
+extern "C" int skw_log_mel(skw_ctx* c, const float* pcm_host, int n_samples, float* mel_out, size_t cap, int* n_len_o, int* n_len_org_o) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    std::vector<int> n_len, n_len_org; const float* pp[1] = {pcm_host}; int32_t ns[1] = {n_samples};
+    if (load_clips(c, pp, ns, 1, 0, n_len, n_len_org)) return -1;
+    run_mel(c, 1);
+    const size_t n = (size_t)n_len[0] * c->m->hp.n_mels;
+    if (cap < n) { snprintf(errbuf, 512, "mel_out too small: need %zu floats", n); return -1; }
+    float* tmp = nullptr; HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
+    hipLaunchKernelGGL(k_transpose_mel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mel, n_len[0], c->m->hp.n_mels, tmp);
+    HIPCHK(hipMemcpyAsync(mel_out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); hipFree(tmp);
+    *n_len_o = n_len[0]; *n_len_org_o = n_len_org[0]; return 0;
+}
+static int tap_prepare(skw_ctx* c, const float* pcm_host, int n_samples, int seek) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    std::vector<int> n_len, n_len_org; const float* pp[1] = {pcm_host}; int32_t ns[1] = {n_samples};
+    if (load_clips(c, pp, ns, 1, 0, n_len, n_len_org)) return -1;
+    run_mel(c, 1);
+    int zero = 0; HIPCHK(hipMemcpyAsync(c->clip_idx, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream)); HIPCHK(hipMemcpyAsync(c->seek, &seek, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    run_conv(c, 1); return 0;
+}
+extern "C" int skw_conv_stem(skw_ctx* c, const float* pcm_host, int n_samples, int seek, float* x0) {
+    char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
+    HIPCHK(hipMemcpyAsync(x0, c->x, sizeof(float) * c->m->hp.n_audio_ctx * c->m->hp.n_audio_state, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0;
+}
+__global__ void k_h2f_copy(const half_t* src, float* dst, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = (float)src[i]; }
+extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int seek, float* enc_out, float* cross_k, float* cross_v) {
+    char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
+    const skw_hparams& hp = c->m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, dt = hp.n_text_state;
+    run_encoder(c, 1, true, true);
+    HIPCHK(hipMemcpyAsync(enc_out, c->enc_out32, sizeof(float) * nc * d, hipMemcpyDeviceToHost, c->stream));
+    if (cross_k && cross_v) {
+        const long n = (long)nc * dt; float* tmp = nullptr; HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
+        for (int l = 0; l < hp.n_text_layer; ++l) for (int kv = 0; kv < 2; ++kv) {
+            const half_t* src = (kv ? c->crossV : c->crossK) + (size_t)l * c->max_batch * nc * dt;
+            hipLaunchKernelGGL(k_h2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, tmp, n);
+            HIPCHK(hipMemcpyAsync((kv ? cross_v : cross_k) + (size_t)l * n, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        hipFree(tmp);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream)); return 0;
+}
+extern "C" int skw_decode_logits(skw_ctx* c, const int32_t* tokens, int n_tokens, float* logits) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (n_tokens < 1 || n_tokens > c->m->hp.n_text_ctx) { snprintf(errbuf, 512, "bad n_tokens"); return -1; }
+    for (int t = 0; t < n_tokens; ++t) {
+        hipLaunchKernelGGL(k_set_tokens, dim3(1), dim3(1), 0, c->stream, c->st, tokens[t], t);
+        run_decoder_step(c, 1, t, t == n_tokens - 1);
+    }
+    HIPCHK(hipMemcpyAsync(logits, c->logits, sizeof(float) * c->m->hp.n_vocab, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0;
+}
+
+// ------------------------------------------------------------------ arithmetic-contract probes (tests/test_gpu_math.py)
+__global__ void k_math_probe(int kind, const float* in, float* out, long n, const uint16_t* gelu_tab) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    float x = in[i], y;
+    if (kind == 0) y = skw_expf(x);
+    else if (kind == 1) y = skw_logf(x);
+    else if (kind == 2) y = (float)((half_t)x);
+    else if (kind == 3) y = skw_round_f16(x);
+    else if (kind == 4) { if (x <= -10.0f) y = 0.0f; else if (x >= 10.0f) y = x; else { half_t h = (half_t)x; uint16_t b = __builtin_bit_cast(uint16_t, h); uint16_t o = gelu_tab[b]; y = (float)__builtin_bit_cast(half_t, o); } }
+    else if (kind == 5) y = 1.0f / sqrtf(x + 1e-5f);
+    else if (kind == 6) y = (float)(1.0 / (double)x);
+    else y = (float)log10((double)x);
+    out[i] = y;
+}
+extern "C" int skw_debug_math(skw_ctx* c, int kind, const float* in, float* out, long n) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    float *di = nullptr, *dout = nullptr; HIPCHK(hipMalloc((void**)&di, n * 4)); HIPCHK(hipMalloc((void**)&dout, n * 4));
+    HIPCHK(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, di, dout, n, c->m->gelu_tab);
+    HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost)); hipFree(di); hipFree(dout); return 0;
+}

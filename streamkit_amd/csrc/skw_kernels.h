@@ -1,0 +1,100 @@
+// skw_kernels.h — launchers for the hand-written gfx950 kernels of the Whisper hot path.
+//
+// Arithmetic contract: include/skw_math.h.  All dense contractions run on
+// v_mfma_f32_16x16x4_f32 (f16-valued operands widened to f32, f32 accumulate),
+// which is bit-for-bit a k-ascending fmaf chain, so results do not depend on
+// tiling.  Every f16 GEMM operand keeps its contraction axis in "kperm" order
+// (see skw_kperm) so that one 16-byte load hands a lane the eight k values its
+// MFMA slot consumes in the next eight instructions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+
+// position (in memory) of logical contraction index k: within each aligned block of 32,
+// the 8 values with k % 4 == q are contiguous at [8q, 8q+8).
+__host__ __device__ __forceinline__ int skw_kperm(int k) { return (k & ~31) | ((k & 3) << 3) | ((k >> 2) & 7); }
+
+enum SkwEpi : int {
+    EPI_F32 = 0,        // C f32 [m][n] = (acc + bias[n]) (+ res[m][n])
+    EPI_F16_KPERM = 1,  // C f16 [m][kperm(n)] = f16((acc + bias[n]) * scale)
+    EPI_GELU_F16_KPERM = 2, // C f16 [m][kperm(n)] = f16(gelu(acc + bias[n]))
+    EPI_CONV2 = 3,      // C f32 [m][n] = pe[(m % n_ctx)][n] + gelu(acc + bias[n])
+    EPI_HEADS_F16 = 4,  // Q/K for attention: C f16 [(b*H+h)*Tpad + i][kperm(d)], m=(b,i), n=(h,d); f16((acc+bias)*scale)
+    EPI_VT_F16 = 5,     // swapped call (m = feature, n = token): C f16 [(b*H+h)*64 + c][kperm(key)] (row stride Tpad); f16(acc + bias[m])
+    EPI_F16_PLAIN = 6,  // C f16 [m][n] = f16((acc + bias[n]) * scale)   (decoder K/V caches, cross K/V)
+    EPI_GELU_F16_KPERM_ROWPAD = 7, // conv1: like 2 but row index remapped m -> (m / T) * (T + 2) + (m % T) + 1 (one zero row of padding per clip side)
+};
+
+struct SkwGemmArgs {
+    const half_t* A; long lda;      // [M][K] f16, K axis kperm'ed, lda in elements (multiple of 8)
+    int a_rows_per_batch; long a_batch_stride; // when a_rows_per_batch > 0: row m lives at A + (m / rpb) * a_batch_stride + (m % rpb) * lda
+    const half_t* W; long ldw;      // [N][K] f16, K axis kperm'ed
+    int M, N, K;                    // K multiple of 32 (zero padded by the producer)
+    void* C; long ldc;
+    const float* bias;              // may be null
+    const float* res; long ldres;   // EPI_F32 residual (may be null; may alias C)
+    float scale;                    // EPI_F16*/HEADS (1.0f = none; multiply is skipped when has_scale == 0)
+    int has_scale;
+    const uint16_t* gelu_tab;       // EPI_GELU*, EPI_CONV2
+    const float* pe; int n_ctx;     // EPI_CONV2: pe [n_ctx][N]; EPI_HEADS/VT: rows per batch item
+    int H; int Tpad;                // EPI_HEADS / EPI_VT
+    int epi;
+};
+
+// big-M GEMM (LDS-tiled 128x128 block, 4 waves)
+void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
+// small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
+void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
+
+// LayerNorm over rows of f32 x[rows][d] (ggml_norm + mul + add); out16: f16 kperm'ed (may be null); out32: f32 (may be null)
+void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s);
+
+// Encoder self-attention, exact three-pass softmax. Qh/Kh: [(b*H+h)*Tpad + i][64 kperm], Vt: [(b*H+h)*64 + c][Tpad kperm],
+// out: f16 [b*n_ctx + i][kperm(h*64 + c)] with row stride ld_out
+void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg = nullptr, float* dbg2 = nullptr);
+
+// log-mel front end
+struct SkwMelTables { const float* hann; const float* sin_t; const float* cos_t; const float* filters; int n_mel; int n_fft_bins; };
+// raw log10 mel: mel_raw [b][frame][n_mel] f32 for frames < n_calc[b]; frames beyond get log10(1e-10)
+void skw_mel_frames(const float* pcm, const long* pcm_off, const int* n_samples, const int* n_len, int B, int n_len_max, SkwMelTables t, float* mel_raw, hipStream_t s);
+// per-clip max -> clamp (max-8) and (x+4)/4, in place; tmp: [B] doubles
+void skw_mel_normalize(float* mel, const int* n_len, int B, int n_len_max, int n_mel, float* clip_max, hipStream_t s);
+// build conv1's im2col rows for the window starting at seek[b]: out f16 [b*T + t][256 kperm] (k = tap*n_mel + c, zero padded to 256)
+void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, half_t* out, hipStream_t s);
+
+// ---------------- decoder ----------------
+// x[b][d] = f32(te[tok[b]][kperm(i)]) + pe[pos[b]][i]
+void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
+// self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
+// n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s);
+// cross attention: ck/cv f16 plain [b][n_ctx][d]
+void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
+
+// per-sequence decoding state kept on the device (whisper_decoder + the bits of whisper_full_with_state's loop that depend on it)
+struct SkwSeqState {
+    int32_t active;        // still decoding
+    int32_t failed, completed;
+    int32_t has_ts, seek_delta, result_len;
+    int32_t n_tokens;      // sampled tokens so far (i)
+    int32_t seek, seek_end;
+    int32_t n_prompt;
+    float no_speech_prob;
+    float min_margin;
+    int32_t cur_token;     // token to feed next
+    int32_t cur_pos;       // its position
+    int32_t pad[2];
+};
+struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum; };
+struct SkwLogitParams {
+    int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
+    int n_lang; int tok_space, tok_sp_dash, tok_sp_quote;
+    int suppress_blank, suppress_nst, no_timestamps, single_segment, max_tokens;
+    int tid0_initial;   // round(max_initial_ts / precision), <0 disables
+    int n_max;          // n_text_ctx/2 - 4
+};
+// whisper_process_logits + whisper_sample_token(best) + the per-token state update of whisper_full_with_state.
+// logits: [B][n_vocab] (modified in place), static_mask: [n_vocab] bytes (1 = always suppressed: specials, langs, nst list when enabled)
+void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active, hipStream_t s);

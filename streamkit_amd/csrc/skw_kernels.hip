@@ -1,0 +1,739 @@
+// skw_kernels.hip — hand-written gfx950 (CDNA4) kernels for the Whisper hot path.
+// Compile with -ffp-contract=off: every fused multiply-add in here is explicit (see include/skw_math.h).
+//
+// What each kernel restates (whisper.cpp routine; reference call site
+// /root/reference/plugins/native/whisper/src/lib.rs:644-646 `whisper_state.full`):
+//   k_mel_*            log_mel_spectrogram + worker (K1)
+//   k_gemm*            ggml_mul_mat with f16 src0 / f16-converted src1, f32 accumulate (K2, K4-K6, K8-K10)
+//   k_layernorm        ggml_norm + ggml_mul + ggml_add (K3)
+//   k_attn_encoder     KQ = mul_mat(K,Q); soft_max_ext; mul_mat(V, KQ_soft_max) (K4)
+//   k_dec_*            whisper_decode_internal pieces (K7-K9), whisper_process_logits + greedy (K11)
+#include "skw_kernels.h"
+#include "../../include/skw_math.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+// f32 -> f16 of an ALREADY ROUNDED f32 value.  The empty asm makes the operand opaque: without it hipcc folds
+// `(half)(a * b)` / `(half)(a + b)` into v_fma_mixlo_f16, which rounds the exact product once (to f16) instead of
+// twice (f32, then f16) and so differs from ggml's f32 -> f16 conversion of an f32 result on ties-after-rounding.
+__device__ __forceinline__ half_t f2h(float f) { asm("" : "+v"(f)); return (half_t)f; }   // v_cvt_f16_f32, RNE
+__device__ __forceinline__ float gelu_dev(float x, const uint16_t* tab) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f) return x;
+    half_t h = f2h(x); uint16_t bits = __builtin_bit_cast(uint16_t, h);
+    uint16_t o = tab[bits];
+    return h2f(__builtin_bit_cast(half_t, o));
+}
+
+union H8 { uint4 u; half_t h[8]; };
+
+// ------------------------------------------------------------------ epilogues
+template <int EPI>
+__device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, float v) {
+    if (EPI == EPI_F32) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.res) v = v + a.res[(long)m * a.ldres + n];
+        ((float*)a.C)[(long)m * a.ldc + n] = v;
+    } else if (EPI == EPI_F16_KPERM) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(v);
+    } else if (EPI == EPI_GELU_F16_KPERM) {
+        if (a.bias) v = v + a.bias[n];
+        ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+    } else if (EPI == EPI_GELU_F16_KPERM_ROWPAD) {
+        if (a.bias) v = v + a.bias[n];
+        long row = (long)(m / a.n_ctx) * (a.n_ctx + 2) + (m % a.n_ctx) + 1;
+        ((half_t*)a.C)[row * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+    } else if (EPI == EPI_CONV2) {
+        if (a.bias) v = v + a.bias[n];
+        float g = gelu_dev(v, a.gelu_tab);
+        ((float*)a.C)[(long)m * a.ldc + n] = a.pe[(long)(m % a.n_ctx) * a.N + n] + g;
+    } else if (EPI == EPI_HEADS_F16) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        int b = m / a.n_ctx, i = m % a.n_ctx, h = n >> 6, d = n & 63;
+        ((half_t*)a.C)[((long)(b * a.H + h) * a.Tpad + i) * 64 + skw_kperm(d)] = f2h(v);
+    } else if (EPI == EPI_VT_F16) {
+        if (a.bias) v = v + a.bias[m];
+        int b = n / a.n_ctx, key = n % a.n_ctx, h = m >> 6, c = m & 63;
+        ((half_t*)a.C)[((long)(b * a.H + h) * 64 + c) * a.Tpad + skw_kperm(key)] = f2h(v);
+    } else if (EPI == EPI_F16_PLAIN) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+    }
+}
+
+// ------------------------------------------------------------------ big-M GEMM
+// C[m][n] = chain_k A[m][k] * W[n][k]; 128x128 block tile, 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16x4 tiles.
+// LDS rows are 32 halves (one kperm block) + 8 halves of padding (80 B) -> conflict-free ds_read_b128.
+#define G_BM 128
+#define G_BN 128
+#define G_LDS_ROW 40   // halves
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(SkwGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) half_t lds[2][2][G_BM * G_LDS_ROW];   // [buf][A/B][rows*40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbn = (a.N + G_BN - 1) / G_BN, nbm = (a.M + G_BM - 1) / G_BM, nblk = nbn * nbm;
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles
+    int bid = blockIdx.x;
+    { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }
+    const int bm = bid / nbn, bn = bid % nbn;       // n-tiles of one m-tile adjacent -> A panel reused from L2
+    const int m0 = bm * G_BM, n0 = bn * G_BN;
+    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: 512 16-byte chunks per operand tile, 2 per thread per operand
+    uint4 stA[2], stB[2];
+    const int nk = a.K >> 5;
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            int gm = m0 + row, gn = n0 + row;
+            long aoff = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
+            stA[i] = (gm < a.M) ? *(const uint4*)(a.A + aoff + (kb << 5) + kc * 8) : make_uint4(0, 0, 0, 0);
+            stB[i] = (gn < a.N) ? *(const uint4*)(a.W + (long)gn * a.ldw + (kb << 5) + kc * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            *(uint4*)(&lds[buf][0][row * G_LDS_ROW + kc * 8]) = stA[i];
+            *(uint4*)(&lds[buf][1][row * G_LDS_ROW + kc * 8]) = stB[i];
+        }
+    };
+    gload(0); lstore(0); __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nk) gload(kb + 1);
+        H8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t].u = *(const uint4*)(&lds[buf][0][(wr * 64 + t * 16 + r16) * G_LDS_ROW + kq * 8]);
+            fb[t].u = *(const uint4*)(&lds[buf][1][(wc * 64 + t * 16 + r16) * G_LDS_ROW + kq * 8]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { av[t] = h2f(fa[t].h[e]); bv[t] = h2f(fb[t].h[e]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(av[i], bv[j], acc[i][j]);
+        }
+        if (kb + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m0 + wr * 64 + i * 16 + kq * 4 + r, n = n0 + wc * 64 + j * 16 + r16;
+                if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------ small-M GEMM (decode, M <= 64)
+// One wave per 16-column strip, MT row tiles; fragments straight from global memory (16 B per lane per 32 k).
+template <int EPI, int MT>
+__global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    const int n0 = strip * 16;
+    if (n0 >= a.N) return;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int gn = n0 + r16;
+    const bool nok = gn < a.N;
+    const half_t* wp = a.W + (long)(nok ? gn : 0) * a.ldw + kq * 8;
+    const half_t* ap[MT]; bool aok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { int gm = t * 16 + r16; aok[t] = gm < a.M; ap[t] = a.A + (long)(aok[t] ? gm : 0) * a.lda + kq * 8; }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K >> 5;
+    H8 fw, fa[MT], fw2, fa2[MT];
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    fw.u = nok ? *(const uint4*)(wp) : z;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[t].u = aok[t] ? *(const uint4*)(ap[t]) : z;
+    for (int kb = 0; kb < nk; ++kb) {
+        if (kb + 1 < nk) {
+            fw2.u = nok ? *(const uint4*)(wp + ((kb + 1) << 5)) : z;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fa2[t].u = aok[t] ? *(const uint4*)(ap[t] + ((kb + 1) << 5)) : z;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float bv = h2f(fw.h[e]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = MFMA16(h2f(fa[t].h[e]), bv, acc[t]);
+        }
+        fw = fw2;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[t] = fa2[t];
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int m = t * 16 + kq * 4 + r, n = n0 + r16;
+            if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[t][r]);
+        }
+}
+
+template <int EPI> static void launch_gemm(const SkwGemmArgs& a, hipStream_t s) {
+    int nbn = (a.N + G_BN - 1) / G_BN, nbm = (a.M + G_BM - 1) / G_BM;
+    hipLaunchKernelGGL(k_gemm<EPI>, dim3(nbn * nbm), dim3(256), 0, s, a);
+}
+void skw_gemm(const SkwGemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_F32: launch_gemm<EPI_F32>(a, s); break;
+        case EPI_F16_KPERM: launch_gemm<EPI_F16_KPERM>(a, s); break;
+        case EPI_GELU_F16_KPERM: launch_gemm<EPI_GELU_F16_KPERM>(a, s); break;
+        case EPI_GELU_F16_KPERM_ROWPAD: launch_gemm<EPI_GELU_F16_KPERM_ROWPAD>(a, s); break;
+        case EPI_CONV2: launch_gemm<EPI_CONV2>(a, s); break;
+        case EPI_HEADS_F16: launch_gemm<EPI_HEADS_F16>(a, s); break;
+        case EPI_VT_F16: launch_gemm<EPI_VT_F16>(a, s); break;
+        case EPI_F16_PLAIN: launch_gemm<EPI_F16_PLAIN>(a, s); break;
+    }
+}
+template <int EPI> static void launch_gemm_small(const SkwGemmArgs& a, hipStream_t s) {
+    int strips = (a.N + 15) / 16, blocks = (strips + 3) / 4;
+    int mt = (a.M + 15) / 16;
+    if (mt <= 1) hipLaunchKernelGGL((k_gemm_smallm<EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemm_smallm<EPI, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL((k_gemm_smallm<EPI, 3>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_smallm<EPI, 4>), dim3(blocks), dim3(256), 0, s, a);
+}
+void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
+    switch (a.epi) {
+        case EPI_F32: launch_gemm_small<EPI_F32>(a, s); break;
+        case EPI_F16_KPERM: launch_gemm_small<EPI_F16_KPERM>(a, s); break;
+        case EPI_GELU_F16_KPERM: launch_gemm_small<EPI_GELU_F16_KPERM>(a, s); break;
+        case EPI_F16_PLAIN: launch_gemm_small<EPI_F16_PLAIN>(a, s); break;
+        default: break;
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// one wave per row; d <= 1536
+__global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * d;
+    float v[24];
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; float t = (i < d) ? xr[i] : 0.0f; v[c] = t; sum += (double)t; }
+    sum = wave_sum_f64(sum);
+    const float mean = (float)(sum / (double)d);
+    double sum2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; if (i < d) { float t = v[c] - mean; v[c] = t; sum2 += (double)(t * t); } }
+    sum2 = wave_sum_f64(sum2);
+    const float variance = (float)(sum2 / (double)d);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+        int i = lane + 64 * c;
+        if (i < d) {
+            float t = v[c] * scale; t = t * w[i]; t = t + b[i];
+            if (out16) out16[(long)row * d + skw_kperm(i)] = f2h(t);
+            if (out32) out32[(long)row * d + i] = t;
+        }
+    }
+}
+void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+}
+
+// ------------------------------------------------------------------ encoder attention (three-pass exact softmax)
+#define AT_KROW 72   // halves per K row in LDS (64 + 8 pad = 144 B)
+#define AT_VROW 40   // halves per V^T row in LDS (32 + 8 pad = 80 B)
+__global__ __launch_bounds__(256, 2) void k_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
+                                                         int H, int n_ctx, int Tpad, float kq_scale, float* dbg, float* dbg2) {
+    __shared__ __attribute__((aligned(16))) half_t ldsK[2][32 * AT_KROW];
+    __shared__ __attribute__((aligned(16))) half_t ldsV[2][64 * AT_VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * H + h;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool wave_on = q0 < n_ctx;
+    // Q fragments (B operand): lane (q = r16, kq = g) holds Q[q][d = 32*blk + 4*e + g]
+    float qf[2][16];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qi = q0 + qt * 16 + r16; if (qi >= n_ctx) qi = n_ctx - 1;
+        const half_t* qp = Qh + (bh * Tpad + qi) * 64 + g * 8;
+        H8 x0, x1; x0.u = *(const uint4*)qp; x1.u = *(const uint4*)(qp + 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qf[qt][e] = h2f(x0.h[e]); qf[qt][8 + e] = h2f(x1.h[e]); }
+    }
+    const int nkb = Tpad >> 5;
+    // staging maps
+    const int krow = tid >> 3, kcc = tid & 7;   // K: 32 rows x 8 chunks
+    const int vrow = tid >> 2, vcc = tid & 3;   // V^T: 64 rows x 4 chunks
+    const half_t* kg = Kh + (bh * Tpad + krow) * 64 + kcc * 8;
+    const half_t* vg = Vt + (bh * 64 + vrow) * Tpad + vcc * 8;
+    // MFMA row rho (= r16) of a 16-key tile holds key kappa = 4*(rho&3) + (rho>>2)
+    const int kappa = 4 * (r16 & 3) + (r16 >> 2);
+
+    float rmax[2] = {-INFINITY, -INFINITY};
+    double rsum[2] = {0.0, 0.0};
+    float rinv[2] = {0.f, 0.f};
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) oacc[qt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int pass = 0; pass < 3; ++pass) {
+        uint4 stK, stV;
+        stK = *(const uint4*)kg; if (pass == 2) stV = *(const uint4*)vg;
+        *(uint4*)(&ldsK[0][krow * AT_KROW + kcc * 8]) = stK;
+        if (pass == 2) *(uint4*)(&ldsV[0][vrow * AT_VROW + vcc * 8]) = stV;
+        __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < nkb) { stK = *(const uint4*)(kg + (long)(kb + 1) * 32 * 64); if (pass == 2) stV = *(const uint4*)(vg + (kb + 1) * 32); }
+            if (wave_on) {
+                // S^T tiles: sacc[qt][kt]: lane (q = r16, g) reg r <-> key 16*kt + 4*r + g
+                f32x4 sacc[2][2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) sacc[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    H8 k0, k1;
+                    const half_t* kp = &ldsK[buf][(kt * 16 + kappa) * AT_KROW + g * 8];
+                    k0.u = *(const uint4*)kp; k1.u = *(const uint4*)(kp + 32);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float kv = h2f(k0.h[e]);
+                        sacc[0][kt] = MFMA16(kv, qf[0][e], sacc[0][kt]);
+                        sacc[1][kt] = MFMA16(kv, qf[1][e], sacc[1][kt]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float kv = h2f(k1.h[e]);
+                        sacc[0][kt] = MFMA16(kv, qf[0][8 + e], sacc[0][kt]);
+                        sacc[1][kt] = MFMA16(kv, qf[1][8 + e], sacc[1][kt]);
+                    }
+                }
+                // scale + mask
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int key = kb * 32 + kt * 16 + 4 * r + g;
+                            float sv = sacc[qt][kt][r] * kq_scale;
+                            sacc[qt][kt][r] = (key < n_ctx) ? sv : -INFINITY;
+                        }
+                if (dbg2 && pass == 0 && b == 0 && h == 0 && blockIdx.x == 0 && wave == 0) {
+                    for (int qt = 0; qt < 2; ++qt) for (int kt = 0; kt < 2; ++kt) for (int r = 0; r < 4; ++r) dbg2[(long)(qt * 16 + r16) * Tpad + kb * 32 + kt * 16 + 4 * r + g] = sacc[qt][kt][r];
+                }
+                if (pass == 0) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rmax[qt] = fmaxf(rmax[qt], sacc[qt][kt][r]);
+                } else if (pass == 1) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rsum[qt] += (double)skw_expf(sacc[qt][kt][r] - rmax[qt]);
+                } else {
+                    H8 vf[4];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) vf[ct].u = *(const uint4*)(&ldsV[buf][(ct * 16 + r16) * AT_VROW + g * 8]);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float p = skw_expf(sacc[qt][kt][r] - rmax[qt]) * rinv[qt];
+                                p = h2f(f2h(p));
+                                if (dbg2 && b == 0 && h == 0 && blockIdx.x == 0 && wave == 0) dbg2[(long)(32 + qt * 16 + r16) * Tpad + kb * 32 + kt * 16 + 4 * r + g] = p;
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct) oacc[qt][ct] = MFMA16(p, h2f(vf[ct].h[kt * 4 + r]), oacc[qt][ct]);
+                            }
+                }
+            }
+            if (kb + 1 < nkb) {
+                *(uint4*)(&ldsK[buf ^ 1][krow * AT_KROW + kcc * 8]) = stK;
+                if (pass == 2) *(uint4*)(&ldsV[buf ^ 1][vrow * AT_VROW + vcc * 8]) = stV;
+            }
+            __syncthreads();
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { rmax[qt] = fmaxf(rmax[qt], __shfl_xor(rmax[qt], 16, 64)); rmax[qt] = fmaxf(rmax[qt], __shfl_xor(rmax[qt], 32, 64)); }
+        } else if (pass == 1) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { rsum[qt] += __shfl_xor(rsum[qt], 16, 64); rsum[qt] += __shfl_xor(rsum[qt], 32, 64); rinv[qt] = (float)(1.0 / rsum[qt]); }
+        }
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int qi = q0 + qt * 16 + g * 4 + r; int c = ct * 16 + r16;
+                if (qi < n_ctx) out[((long)b * n_ctx + qi) * ld_out + skw_kperm(h * 64 + c)] = f2h(oacc[qt][ct][r]);
+                if (dbg && qi < n_ctx && b == 0) { dbg[(long)qi * (H * 64) + h * 64 + c] = oacc[qt][ct][r]; if (ct == 0 && r == 0 && g == 0) { dbg[(long)n_ctx * H * 64 + (long)h * n_ctx + q0 + qt * 16 + r16] = rmax[qt]; dbg[(long)n_ctx * H * 64 + (long)(H + h) * n_ctx + q0 + qt * 16 + r16] = rinv[qt]; } }
+            }
+}
+void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2) {
+    dim3 grid((n_ctx + 127) / 128, H, B);
+    hipLaunchKernelGGL(k_attn_encoder, grid, dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), dbg, dbg2);
+}
+
+// ------------------------------------------------------------------ log-mel front end (K1)
+// one 128-thread block per frame; restates whisper.cpp fft()/dft() operation by operation (f32, no contraction)
+__global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long* pcm_off, const int* n_samples, const int* n_len, int n_len_max,
+                                                    SkwMelTables t, float* mel_raw) {
+    __shared__ float x[400];
+    __shared__ float bufA[800], bufB[800];
+    const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ns_raw = n_samples[b], nl = n_len[b];
+    if (i >= nl) return;
+    float* outp = mel_raw + ((long)b * n_len_max + i) * t.n_mel;
+    const int ns = ns_raw + 200;
+    int n_calc = ns / 160 + 1; if (n_calc > nl) n_calc = nl;
+    if (i >= n_calc) { if (tid < t.n_mel) outp[tid] = (float)log10(1e-10); return; }
+    const float* p = pcm + pcm_off[b];
+    const int offset = i * 160;
+    int lim = ns - offset; if (lim > 400) lim = 400;
+    for (int j = tid; j < 400; j += 128) {
+        float v = 0.0f;
+        if (j < lim) {
+            int pp = offset + j; float sm;
+            if (pp < 200) { int q = 200 - pp; sm = (q < ns_raw) ? p[q] : 0.0f; }
+            else { int q = pp - 200; sm = (q < ns_raw) ? p[q] : 0.0f; }
+            v = t.hann[j] * sm;
+        }
+        x[j] = v;
+    }
+    __syncthreads();
+    // 16 leaf DFTs of length 25: leaf o holds x[o + 16 n]
+    for (int u = tid; u < 400; u += 128) {
+        int o = u / 25, k = u % 25;
+        float re = 0.0f, im = 0.0f;
+        for (int n = 0; n < 25; ++n) {
+            int idx = (k * n * 16) % 400;
+            float xin = x[o + 16 * n];
+            re += xin * t.cos_t[idx];
+            im -= xin * t.sin_t[idx];
+        }
+        bufA[2 * (o * 25 + k)] = re; bufA[2 * (o * 25 + k) + 1] = im;
+    }
+    __syncthreads();
+    float* src = bufA; float* dst = bufB;
+    for (int N = 50; N <= 400; N <<= 1) {
+        const int half_n = N >> 1, groups = 400 / N, step = 400 / N;
+        for (int u = tid; u < 200; u += 128) {
+            int gi = u / half_n, k = u % half_n;
+            int idx = k * step;
+            float re = t.cos_t[idx], im = -t.sin_t[idx];
+            const float* ev = src + 2 * (gi * half_n + k); const float* od = src + 2 * ((gi + groups) * half_n + k);
+            float er = ev[0], ei = ev[1], orr = od[0], oi = od[1];
+            float* o0 = dst + 2 * (gi * N + k); float* o1 = dst + 2 * (gi * N + k + half_n);
+            o0[0] = (er + re * orr) - im * oi;
+            o0[1] = (ei + re * oi) + im * orr;
+            o1[0] = (er - re * orr) + im * oi;
+            o1[1] = (ei - re * oi) - im * orr;
+        }
+        __syncthreads();
+        float* tmp = src; src = dst; dst = tmp;
+    }
+    // power spectrum into x[0..200]
+    for (int j = tid; j < 201; j += 128) { float re = src[2 * j], im = src[2 * j + 1]; x[j] = re * re + im * im; }
+    __syncthreads();
+    if (tid < t.n_mel) {
+        const float* fl = t.filters + (long)tid * t.n_fft_bins;
+        double sum = 0.0; int k = 0;
+        for (k = 0; k < t.n_fft_bins - 3; k += 4) {
+            float s4 = x[k] * fl[k] + x[k + 1] * fl[k + 1] + x[k + 2] * fl[k + 2] + x[k + 3] * fl[k + 3];
+            sum += (double)s4;
+        }
+        for (; k < t.n_fft_bins; ++k) sum += (double)(x[k] * fl[k]);
+        sum = log10(sum > 1e-10 ? sum : 1e-10);
+        outp[tid] = (float)sum;
+    }
+}
+void skw_mel_frames(const float* pcm, const long* pcm_off, const int* n_samples, const int* n_len, int B, int n_len_max, SkwMelTables t, float* mel_raw, hipStream_t s) {
+    hipLaunchKernelGGL(k_mel_frames, dim3(n_len_max, B), dim3(128), 0, s, pcm, pcm_off, n_samples, n_len, n_len_max, t, mel_raw);
+}
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__global__ void k_mel_max(const float* mel, const int* n_len, int n_len_max, int n_mel, unsigned* clip_max_ord) {
+    const int b = blockIdx.y; const long n = (long)n_len[b] * n_mel; const float* p = mel + (long)b * n_len_max * n_mel;
+    float m = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, p[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&clip_max_ord[b], f2ord(m));
+}
+__global__ void k_mel_norm(float* mel, const int* n_len, int n_len_max, int n_mel, const unsigned* clip_max_ord) {
+    const int b = blockIdx.y; const long n = (long)n_len[b] * n_mel; float* p = mel + (long)b * n_len_max * n_mel;
+    double mmax = (double)ord2f(clip_max_ord[b]) - 8.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = p[i]; if ((double)v < mmax) v = (float)mmax;
+        p[i] = (float)(((double)v + 4.0) / 4.0);
+    }
+}
+void skw_mel_normalize(float* mel, const int* n_len, int B, int n_len_max, int n_mel, float* clip_max, hipStream_t s) {
+    hipMemsetAsync(clip_max, 0, sizeof(unsigned) * B, s);
+    hipLaunchKernelGGL(k_mel_max, dim3(64, B), dim3(256), 0, s, mel, n_len, n_len_max, n_mel, (unsigned*)clip_max);
+    hipLaunchKernelGGL(k_mel_norm, dim3(64, B), dim3(256), 0, s, mel, n_len, n_len_max, n_mel, (const unsigned*)clip_max);
+}
+// conv1 im2col: out[(bw*T + t)][kperm(k)], k = tap*n_mel + c (k < 3*n_mel), zero padded to 256
+__global__ void k_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int n_len_max, int n_mel, int T, half_t* out) {
+    const int bw = blockIdx.y, t = blockIdx.x, k = threadIdx.x;   // 256 threads
+    const int clip = clip_idx[bw], sk = seek[bw], nl = n_len[clip];
+    float v = 0.0f;
+    if (k < 3 * n_mel) {
+        int tap = k / n_mel, c = k % n_mel; int tt = t - 1 + tap; int fr = sk + tt;
+        if (tt >= 0 && tt < T && fr < nl) v = mel[((long)clip * n_len_max + fr) * n_mel + c];
+    }
+    out[((long)bw * T + t) * 256 + skw_kperm(k)] = f2h(v);
+}
+void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, half_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mel_im2col, dim3(T, Bw), dim3(256), 0, s, mel, clip_idx, seek, n_len, n_len_max, n_mel, T, out);
+}
+
+// ------------------------------------------------------------------ decoder pieces
+__global__ void k_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int d, float* x) {
+    const int b = blockIdx.x; const int tk = tok[b * (int)(sizeof(SkwSeqState) / 4)]; const int ps = pos[b * (int)(sizeof(SkwSeqState) / 4)];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(long)b * d + i] = h2f(te[(long)tk * d + skw_kperm(i)]) + pe[(long)ps * d + i];
+}
+void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_embed, dim3(B), dim3(256), 0, s, te, pe, tok, pos, d, x);
+}
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0]; for (int i = 1; i < nw; ++i) r = fmaxf(r, sh[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+    v = wave_sum_f64(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0; for (int i = 0; i < nw; ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+// generic single-query attention over n_kv keys with plain f16 K/V rows (row stride ldkv halves), head dim 64.
+// scores: s_j = chain_d q[d] K[j][d]; softmax (ggml_soft_max_ext, scale 1); out[c] = chain_j f16(p_j) V[j][c]
+__global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, half_t* out, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                       // [n_kv_max]
+    __shared__ float shf[8]; __shared__ double shd[8]; __shared__ float qs[64];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
+    if (tid < 64) qs[tid] = h2f(q[(long)b * ldq + h * 64 + tid]);
+    __syncthreads();
+    const half_t* K = kbase + (long)b * batch_stride + h * 64;
+    const half_t* V = vbase + (long)b * batch_stride + h * 64;
+    float lmax = -INFINITY;
+    for (int j = tid; j < n_kv; j += blockDim.x) {
+        const half_t* kr = K + (long)j * ldkv;
+        float a = 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) { H8 kk; kk.u = *(const uint4*)(kr + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qs[c8 * 8 + e], h2f(kk.h[e]), a); }
+        sc[j] = a; lmax = fmaxf(lmax, a);
+    }
+    const float mx = block_max(lmax, shf);
+    double lsum = 0.0;
+    for (int j = tid; j < n_kv; j += blockDim.x) { float e = skw_expf(sc[j] - mx); sc[j] = e; lsum += (double)e; }
+    const double tot = block_sum_f64(lsum, shd);
+    const float inv = (float)(1.0 / tot);
+    for (int j = tid; j < n_kv; j += blockDim.x) sc[j] = h2f(f2h(sc[j] * inv));
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.0f; const half_t* vp = V + tid;
+        int j = 0;
+        for (; j + 8 <= n_kv; j += 8) {
+            float v0 = h2f(vp[(long)(j + 0) * ldkv]), v1 = h2f(vp[(long)(j + 1) * ldkv]), v2 = h2f(vp[(long)(j + 2) * ldkv]), v3 = h2f(vp[(long)(j + 3) * ldkv]);
+            float v4 = h2f(vp[(long)(j + 4) * ldkv]), v5 = h2f(vp[(long)(j + 5) * ldkv]), v6 = h2f(vp[(long)(j + 6) * ldkv]), v7 = h2f(vp[(long)(j + 7) * ldkv]);
+            a = __builtin_fmaf(sc[j + 0], v0, a); a = __builtin_fmaf(sc[j + 1], v1, a); a = __builtin_fmaf(sc[j + 2], v2, a); a = __builtin_fmaf(sc[j + 3], v3, a);
+            a = __builtin_fmaf(sc[j + 4], v4, a); a = __builtin_fmaf(sc[j + 5], v5, a); a = __builtin_fmaf(sc[j + 6], v6, a); a = __builtin_fmaf(sc[j + 7], v7, a);
+        }
+        for (; j < n_kv; ++j) a = __builtin_fmaf(sc[j], h2f(vp[(long)j * ldkv]), a);
+        out[(long)b * ldo + skw_kperm(h * 64 + tid)] = f2h(a);
+    }
+}
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_attn, dim3(H, B), dim3(256), n_text_ctx * sizeof(float), s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, out, (long)d);
+}
+void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_attn, dim3(H, B), dim3(256), n_ctx * sizeof(float), s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
+                       (const int*)nullptr, 0, n_ctx, out, (long)d);
+}
+
+// ------------------------------------------------------------------ K11: logits -> token (+ state update)
+struct ArgBest { float v; int i; };
+__device__ __forceinline__ ArgBest better(ArgBest a, ArgBest b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ ArgBest block_argbest(ArgBest x, ArgBest* sh) {
+    for (int o = 32; o > 0; o >>= 1) { ArgBest y; y.v = __shfl_xor(x.v, o, 64); y.i = __shfl_xor(x.i, o, 64); x = better(x, y); }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = x;
+    __syncthreads();
+    ArgBest r = sh[0]; for (int i = 1; i < nw; ++i) r = better(r, sh[i]);
+    __syncthreads();
+    return r;
+}
+// log-softmax statistics of the admissible logits in [lo,hi): returns max and logsumexp
+__device__ void block_lse(const float* lg, int lo, int hi, float* sh_f, double* sh_d, float* out_max, float* out_lse) {
+    float m = -INFINITY;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) m = fmaxf(m, lg[i]);
+    m = block_max(m, sh_f);
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) { float v = lg[i]; if (v > -INFINITY) acc += (double)skw_expf(v - m); }
+    acc = block_sum_f64(acc, sh_d);
+    *out_max = m;
+    *out_lse = (acc > 0.0) ? skw_logf((float)acc) + m : -INFINITY;
+}
+
+__global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
+                                                     int max_tok, int* n_active) {
+    __shared__ float sh_f[16]; __shared__ double sh_d[16]; __shared__ ArgBest sh_a[16];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    SkwSeqState* st = &st_all[b];
+    if (!st->active) return;   // uniform per block
+    float* lg = logits_all + (long)b * p.n_vocab;
+    const int NV = p.n_vocab;
+    SkwTokenOut* toks = toks_all + (long)b * max_tok;
+    const int n_tok = st->n_tokens;
+    const bool is_initial = n_tok == 0;
+    float mx, lse;
+    if (is_initial) {   // no_speech_prob from the unfiltered distribution
+        block_lse(lg, 0, NV, sh_f, sh_d, &mx, &lse);
+        if (tid == 0) st->no_speech_prob = skw_expf(lg[p.tok_nosp] - lse);
+    }
+    const int last_id = n_tok > 0 ? toks[n_tok - 1].id : -1;
+    const int pen_id = n_tok > 1 ? toks[n_tok - 2].id : -1;
+    const bool last_ts = n_tok > 0 && last_id >= p.tok_beg;
+    const bool pen_ts = n_tok < 2 || pen_id >= p.tok_beg;
+    const int has_ts = st->has_ts; const int ts_lo = has_ts ? p.tok_beg + st->seek_delta / 2 : 0;
+    for (int i = tid; i < NV; i += nt) {
+        bool kill = static_mask[i] != 0;
+        if (is_initial && p.suppress_blank && (i == p.tok_eot || i == p.tok_space)) kill = true;
+        if (p.no_timestamps && i >= p.tok_beg) kill = true;
+        if (last_ts) { if (pen_ts) { if (i >= p.tok_beg) kill = true; } else { if (i < p.tok_eot) kill = true; } }
+        if (is_initial && p.tid0_initial >= 0 && i >= p.tok_beg + p.tid0_initial + 1) kill = true;
+        if (has_ts && i >= p.tok_beg && i < ts_lo) kill = true;
+        if (kill) lg[i] = -INFINITY;
+    }
+    __syncthreads();
+    block_lse(lg, 0, NV, sh_f, sh_d, &mx, &lse);
+    // timestamp mass rule, on logprobs = logits - lse
+    float ts_logprob = -INFINITY;
+    {
+        float m = -INFINITY;
+        for (int i = p.tok_beg + tid; i < NV; i += nt) { float v = lg[i]; if (v > -INFINITY) m = fmaxf(m, v - lse); }
+        m = block_max(m, sh_f);
+        double acc = 0.0;
+        for (int i = p.tok_beg + tid; i < NV; i += nt) { float v = lg[i]; if (v > -INFINITY) acc += (double)skw_expf((v - lse) - m); }
+        acc = block_sum_f64(acc, sh_d);
+        if (acc > 0.0) ts_logprob = skw_logf((float)acc) + m;
+    }
+    float max_text = -INFINITY;
+    for (int i = tid; i < p.tok_beg; i += nt) { float v = lg[i]; if (v > -INFINITY) max_text = fmaxf(max_text, v - lse); }
+    max_text = block_max(max_text, sh_f);
+    const bool force_ts = ts_logprob > max_text;
+    const int lo = force_ts ? p.tok_beg : 0;
+    if (force_ts) { for (int i = tid; i < p.tok_beg; i += nt) lg[i] = -INFINITY; __syncthreads(); }
+    // best token over probs = expf(logprob), first index wins ties; timestamp statistics
+    ArgBest best = {0.0f, 0}, bts = {0.0f, 0x7fffffff};
+    double sum_ts = 0.0; float top1 = -INFINITY, top2 = -INFINITY;
+    for (int i = lo + tid; i < NV; i += nt) {
+        float v = lg[i];
+        if (v > -INFINITY) {
+            float pr = skw_expf(v - lse);
+            ArgBest c = {pr, i}; if (pr > best.v || (pr == best.v && i < best.i)) best = c;
+            if (i >= p.tok_beg) { sum_ts += (double)pr; if (pr > bts.v || (pr == bts.v && pr > 0.0f && i < bts.i)) { bts.v = pr; bts.i = i; } }
+            if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
+        }
+    }
+    best = block_argbest(best, sh_a);
+    bts = block_argbest(bts, sh_a);
+    sum_ts = block_sum_f64(sum_ts, sh_d);
+    // margin between the two largest admissible logits
+    float t1 = block_max(top1, sh_f);
+    float cand = (top1 == t1) ? top2 : top1;   // exact duplicates of the max report a margin of 0 via top2 only within a thread; fine for diagnostics
+    float t2 = block_max(cand, sh_f);
+    if (tid != 0) return;
+    SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = lg[best.i] - lse;
+    tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
+    if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
+    if (t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;
+    const int i = n_tok;
+    if (i < max_tok) toks[i] = tk;
+    st->n_tokens = i + 1;
+    int failed = 0, completed = 0;
+    if (tk.id > p.tok_beg) {
+        const int sd_new = 2 * (tk.id - p.tok_beg);
+        if (st->has_ts && st->seek_delta > sd_new && st->result_len < i) failed = 1;
+        else { st->seek_delta = sd_new; st->result_len = i + 1; st->has_ts = 1; }
+    }
+    if (!failed && (tk.id == p.tok_eot || (p.max_tokens > 0 && i >= p.max_tokens) || (st->has_ts && st->seek + st->seek_delta + 100 >= st->seek_end))) {
+        if (st->result_len == 0 && !p.no_timestamps) {
+            if (st->seek + st->seek_delta + 100 >= st->seek_end) st->result_len = i + 1; else failed = 1;
+        }
+        if (!failed) {
+            if (p.single_segment || p.no_timestamps) { st->result_len = i + 1; st->seek_delta = 100 * 30; }
+            completed = 1;
+        }
+    }
+    if (!failed && !completed && i == p.n_max - 1 && (st->result_len == 0 || st->seek_delta < 100 * 30 / 2)) failed = 1;
+    if (!failed && !completed && i + 1 >= p.n_max) completed = 1;   // loop bound reached (whisper.cpp leaves the for loop)
+    st->failed = failed; st->completed = completed;
+    st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
+    if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
+}
+void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active);
+}

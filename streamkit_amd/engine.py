@@ -1,0 +1,218 @@
+"""ctypes binding of libskw_engine.so (include/skw_engine.h) — the MI355X Whisper engine.
+
+The library is the product; this module is plumbing for tests and bench.py.  It refuses to run
+without the compiled HIP library: there is no Python / CPU fallback for any kernel.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskw_engine.so")
+_LIB = None
+
+
+class HParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_vocab", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+                                         "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "n_mels", "ftype")]
+
+
+class FullParams(C.Structure):
+    _fields_ = [("lang_id", C.c_int32), ("translate", C.c_int32), ("suppress_blank", C.c_int32), ("suppress_nst", C.c_int32),
+                ("no_timestamps", C.c_int32), ("single_segment", C.c_int32), ("max_tokens", C.c_int32),
+                ("max_initial_ts", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float),
+                ("no_speech_thold", C.c_float), ("n_threads", C.c_int32)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("t0", C.c_int64), ("t1", C.c_int64), ("tok_begin", C.c_int32), ("tok_end", C.c_int32),
+                ("text_off", C.c_int32), ("text_len", C.c_int32)]
+
+
+class Token(C.Structure):
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_segments", C.c_int32), ("n_tokens", C.c_int32), ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32),
+                ("fallback_requested", C.c_int32), ("min_margin", C.c_float),
+                ("segments", C.POINTER(Segment)), ("tokens", C.POINTER(Token)), ("text", C.c_void_p), ("text_len", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("mel_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libskw_engine.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.skw_device_count.restype = C.c_int
+        L.skw_model_load.restype = C.c_void_p
+        L.skw_model_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.skw_model_free.argtypes = [C.c_void_p]
+        L.skw_model_get_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
+        L.skw_model_token_text.restype = C.c_void_p
+        L.skw_model_token_text.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.skw_model_lang_id.argtypes = [C.c_char_p]
+        L.skw_ctx_create.restype = C.c_void_p
+        L.skw_ctx_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.skw_ctx_free.argtypes = [C.c_void_p]
+        L.skw_ctx_last_error.restype = C.c_char_p
+        L.skw_ctx_last_error.argtypes = [C.c_void_p]
+        L.skw_ctx_stream.restype = C.c_void_p
+        L.skw_ctx_stream.argtypes = [C.c_void_p]
+        L.skw_ctx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.skw_full_default_params.argtypes = [C.POINTER(FullParams)]
+        L.skw_full_batch.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(Result)]
+        L.skw_result_free.argtypes = [C.POINTER(Result)]
+        L.skw_log_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.skw_conv_stem.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.skw_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.skw_decode_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.skw_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        L.skw_debug_enable.argtypes = [C.c_int]
+        L.skw_debug_get.restype = C.c_long
+        L.skw_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+        _LIB = L
+    return _LIB
+
+
+def _result_to_dict(r):
+    text = C.string_at(r.text, r.text_len) if r.text else b""
+    toks = [(r.tokens[i].id, r.tokens[i].tid, r.tokens[i].p, r.tokens[i].plog) for i in range(r.n_tokens)]
+    segs = [dict(t0=r.segments[i].t0, t1=r.segments[i].t1,
+                 tokens=[t[0] for t in toks[r.segments[i].tok_begin:r.segments[i].tok_end]],
+                 text=text[r.segments[i].text_off:r.segments[i].text_off + r.segments[i].text_len]) for i in range(r.n_segments)]
+    return dict(segments=segs, tokens=toks, n_windows=r.n_windows, n_decode_steps=r.n_decode_steps,
+                fallback_requested=r.fallback_requested, min_margin=r.min_margin)
+
+
+class Model:
+    def __init__(self, path, device=0):
+        L = lib()
+        err = C.create_string_buffer(512)
+        self.h = L.skw_model_load(path.encode(), device, err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        self.hp = HParams()
+        L.skw_model_get_hparams(self.h, C.byref(self.hp))
+
+    def token_bytes(self, i):
+        n = C.c_int()
+        p = lib().skw_model_token_text(self.h, i, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def close(self):
+        if self.h:
+            lib().skw_model_free(self.h)
+            self.h = None
+
+
+class Context:
+    def __init__(self, model, max_batch=1, max_samples=0):
+        err = C.create_string_buffer(512)
+        self.model = model
+        self.h = lib().skw_ctx_create(model.h, max_batch, max_samples, err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("skw engine: " + lib().skw_ctx_last_error(self.h).decode())
+
+    def default_params(self):
+        p = FullParams()
+        lib().skw_full_default_params(C.byref(p))
+        return p
+
+    def full_batch(self, clips, params=None, device_ptrs=None, n_samples=None):
+        """clips: list of 1-D float32 numpy arrays (host), or device_ptrs + n_samples for HBM-resident PCM."""
+        p = params or self.default_params()
+        if device_ptrs is not None:
+            n = len(device_ptrs)
+            ptrs = (C.c_void_p * n)(*device_ptrs)
+            ns = (C.c_int32 * n)(*n_samples)
+            on_dev = 1
+        else:
+            clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+            n = len(clips)
+            ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
+            ns = (C.c_int32 * n)(*[c.size for c in clips])
+            on_dev = 0
+        res = (Result * n)()
+        self._check(lib().skw_full_batch(self.h, C.byref(p), ptrs, ns, n, on_dev, res))
+        out = [_result_to_dict(res[i]) for i in range(n)]
+        for i in range(n):
+            lib().skw_result_free(C.byref(res[i]))
+        return out
+
+    def timing(self):
+        t = Timing()
+        lib().skw_ctx_last_timing(self.h, C.byref(t))
+        return {f: getattr(t, f) for f, _ in t._fields_}
+
+    def stream(self):
+        return lib().skw_ctx_stream(self.h)
+
+    def log_mel(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        hp = self.model.hp
+        cap = hp.n_mels * ((pcm.size + 480000) // 160 + 8)
+        out = np.empty(cap, dtype=np.float32)
+        n_len, n_org = C.c_int(), C.c_int()
+        self._check(lib().skw_log_mel(self.h, pcm.ctypes.data, pcm.size, out.ctypes.data, cap, C.byref(n_len), C.byref(n_org)))
+        return out[:hp.n_mels * n_len.value].reshape(hp.n_mels, n_len.value).copy(), n_org.value
+
+    def conv_stem(self, pcm, seek=0):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        hp = self.model.hp
+        out = np.empty((hp.n_audio_ctx, hp.n_audio_state), dtype=np.float32)
+        self._check(lib().skw_conv_stem(self.h, pcm.ctypes.data, pcm.size, seek, out.ctypes.data))
+        return out
+
+    def encode(self, pcm, seek=0, cross=True):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        hp = self.model.hp
+        enc = np.empty((hp.n_audio_ctx, hp.n_audio_state), dtype=np.float32)
+        ck = cv = None
+        if cross:
+            ck = np.empty((hp.n_text_layer, hp.n_audio_ctx, hp.n_text_state), dtype=np.float32)
+            cv = np.empty_like(ck)
+        self._check(lib().skw_encode(self.h, pcm.ctypes.data, pcm.size, seek, enc.ctypes.data,
+                                     ck.ctypes.data if cross else None, cv.ctypes.data if cross else None))
+        return enc, ck, cv
+
+    def decode_logits(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.model.hp.n_vocab, dtype=np.float32)
+        self._check(lib().skw_decode_logits(self.h, t.ctypes.data, t.size, out.ctypes.data))
+        return out
+
+    def math(self, kind, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(lib().skw_debug_math(self.h, kind, x.ctypes.data, out.ctypes.data, x.size))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().skw_ctx_free(self.h)
+            self.h = None
+
+
+def debug_enable(on=True):
+    lib().skw_debug_enable(1 if on else 0)
+
+
+def debug_get(name):
+    n = lib().skw_debug_get(name.encode(), None, 0)
+    if n < 0:
+        return None
+    out = np.empty(n, dtype=np.float32)
+    lib().skw_debug_get(name.encode(), out.ctypes.data, n)
+    return out

@@ -64,6 +64,10 @@ def lib():
         L.skwo_resampler_new.argtypes = [C.c_double, C.c_int, C.c_int]
         L.skwo_resampler_free.argtypes = [C.c_void_p]
         L.skwo_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.skwo_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        L.skwo_debug_enable.argtypes = [C.c_int]
+        L.skwo_debug_get.restype = C.c_long
+        L.skwo_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -87,6 +91,12 @@ class OracleModel:
         n = C.c_int()
         p = lib().skwo_token_str(self.h, i, C.byref(n))
         return C.string_at(p, n.value)
+
+    def math(self, kind, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        lib().skwo_math(self.h, kind, x.ctypes.data, out.ctypes.data, x.size)
+        return out
 
     def default_params(self):
         p = Params()
@@ -158,3 +168,16 @@ class OracleDecoder:
         if self.h:
             lib().skwo_dec_free(self.h)
             self.h = None
+
+
+def debug_enable(on=True):
+    lib().skwo_debug_enable(1 if on else 0)
+
+
+def debug_get(name):
+    n = lib().skwo_debug_get(name.encode(), None, 0)
+    if n < 0:
+        return None
+    out = np.empty(n, dtype=np.float32)
+    lib().skwo_debug_get(name.encode(), out.ctypes.data, n)
+    return out
