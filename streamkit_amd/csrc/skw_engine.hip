@@ -338,7 +338,43 @@ static void tap(skw_ctx* c, const char* name, const void* dev, int rows, int col
     }
 }
 
+// ------------------------------------------------------------------ per-kernel-class profiling (HIP events on the engine stream)
+enum ProfClass { PC_GEMM = 0, PC_GEMM_SMALL, PC_ATTN_ENC, PC_LAYERNORM, PC_MEL, PC_DEC_ATTN, PC_DEC_SAMPLE, PC_OTHER, PC_COUNT };
+static const char* const g_prof_names[PC_COUNT] = {"k_gemm", "k_gemm_smallm", "k_attn_encoder", "k_layernorm", "k_mel", "k_dec_attn", "k_dec_sample", "other"};
+struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
+struct ProfState { bool on = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t next = 0; double ms[PC_COUNT] = {}, flops[PC_COUNT] = {}, bytes[PC_COUNT] = {}; long count[PC_COUNT] = {}; };
+static std::map<skw_ctx*, ProfState> g_prof;
+struct ProfScope {
+    ProfState* ps; skw_ctx* c; size_t idx;
+    ProfScope(skw_ctx* c_, int cls, double flops, double bytes);
+    ~ProfScope();
+};
+
 // ------------------------------------------------------------------ GEMM helpers
+ProfScope::ProfScope(skw_ctx* c_, int cls, double flops, double bytes) : ps(nullptr), c(c_), idx(0) {
+    auto it = g_prof.find(c_); if (it == g_prof.end() || !it->second.on) return;
+    ps = &it->second;
+    auto get = [&]() { if (ps->next == ps->pool.size()) { hipEvent_t e; hipEventCreate(&e); ps->pool.push_back(e); } return ps->pool[ps->next++]; };
+    ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get(); idx = ps->recs.size(); ps->recs.push_back(r);
+    hipEventRecord(r.a, c->stream);
+}
+ProfScope::~ProfScope() { if (ps) hipEventRecord(ps->recs[idx].b, c->stream); }
+static void prof_collect(skw_ctx* c) {
+    auto it = g_prof.find(c); if (it == g_prof.end() || !it->second.on) return; ProfState& ps = it->second;
+    hipStreamSynchronize(c->stream);
+    for (auto& r : ps.recs) { float ms = 0; hipEventElapsedTime(&ms, r.a, r.b); ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
+    ps.recs.clear(); ps.next = 0;
+}
+extern "C" void skw_ctx_profile(skw_ctx* c, int on) { ProfState& ps = g_prof[c]; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0; ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
+extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_len, long* count, double* ms, double* flops, double* bytes) {
+    if (cls < 0 || cls >= PC_COUNT) return -1; ProfState& ps = g_prof[c];
+    if (name) snprintf(name, name_len, "%s", g_prof_names[cls]); *count = ps.count[cls]; *ms = ps.ms[cls]; *flops = ps.flops[cls]; *bytes = ps.bytes[cls]; return 0;
+}
+// algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
+static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical; *by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
+static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by); skw_gemm(a, c->stream); }
+static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by); skw_gemm_smallm(a, c->stream); }
+
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
     SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
 }
@@ -346,6 +382,7 @@ static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, 
 // front end for `n` clips already described in c->pcm_off / n_samples / n_len (device): mel + normalisation
 static void run_mel(skw_ctx* c, int n) {
     skw_model* m = c->m; SkwMelTables t{m->hann, m->sin_t, m->cos_t, m->filters, m->hp.n_mels, m->n_fft_bins};
+    ProfScope p_(c, PC_MEL, 0, 0);
     skw_mel_frames(c->pcm, c->pcm_off, c->n_samples, c->n_len, n, c->n_len_max, t, c->mel, c->stream);
     skw_mel_normalize(c->mel, c->n_len, n, c->n_len_max, m->hp.n_mels, c->clip_max, c->stream);
 }
@@ -354,39 +391,39 @@ static void run_conv(skw_ctx* c, int Bw) {
     skw_model* m = c->m; const int nc = m->hp.n_audio_ctx, T = 2 * nc, d = m->hp.n_audio_state;
     skw_mel_im2col(c->mel, c->clip_idx, c->seek, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
     SkwGemmArgs a = gemm_args(c->im2col, 256, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
-    skw_gemm(a, c->stream);
+    GEMM(c, a, m->conv1.n_in);
     SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d; b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;
-    skw_gemm(b, c->stream);
+    GEMM(c, b, m->conv2.n_in);
 }
 // encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
 static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, M = Bw * nc;
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer& L = m->enc[l];
-        skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, c->y16, nullptr, c->stream);
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, c->y16, nullptr, c->stream); }
         if (l == 0) tap(c, "l0.ln1", c->y16, nc, d, TAP_F16_KPERM);
-        { SkwGemmArgs a = gemm_args(c->y16, d, L.q, M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; skw_gemm(a, c->stream); }
-        { SkwGemmArgs a = gemm_args(c->y16, d, L.k, M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; skw_gemm(a, c->stream); }
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.q, M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; GEMM(c, a, d); }
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.k, M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; GEMM(c, a, d); }
         { // V^T via the swapped product: rows = features (weights as the A operand), columns = tokens
             SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt; a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
-            skw_gemm(a, c->stream);
+            GEMM(c, a, d);
         }
         if (l == 0) { tap(c, "l0.q", c->Qh, nc, d, TAP_HEADS); tap(c, "l0.k", c->Kh, nc, d, TAP_HEADS); tap(c, "l0.v", c->Vt, nc, d, TAP_VT); }
         float* dbg = nullptr;
         if (l == 0 && g_taps_on) { hipMalloc((void**)&dbg, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc + 64)); hipMemset(dbg, 0, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc)); }
         float* dbg2 = nullptr;
         if (dbg) { hipMalloc((void**)&dbg2, sizeof(float) * 64 * c->Tpad); hipMemset(dbg2, 0, sizeof(float) * 64 * c->Tpad); }
-        skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2);
+        { ProfScope p_(c, PC_ATTN_ENC, 4.0 * Bw * H * (double)nc * nc * 64, 2.0 * 4 * M * d); skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2); }
         if (dbg2) { tap(c, "l0.SP", dbg2, 64, c->Tpad, TAP_F32); hipFree(dbg2); }
         if (dbg) { tap(c, "l0.att32", dbg, nc, d, TAP_F32); tap(c, "l0.rmax", dbg + (size_t)nc * d, H, nc, TAP_F32); tap(c, "l0.rinv", dbg + (size_t)nc * d + (size_t)H * nc, H, nc, TAP_F32); hipFree(dbg); }
         if (l == 0) tap(c, "l0.att", c->y16, nc, d, TAP_F16_KPERM);
-        { SkwGemmArgs a = gemm_args(c->y16, d, L.o, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; skw_gemm(a, c->stream); }
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.o, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; GEMM(c, a, d); }
         if (l == 0) tap(c, "l0.x1", c->x, nc, d, TAP_F32);
-        skw_layernorm(c->x, M, d, L.mlp_ln.w, L.mlp_ln.b, c->y16, nullptr, c->stream);
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.mlp_ln.w, L.mlp_ln.b, c->y16, nullptr, c->stream); }
         if (l == 0) tap(c, "l0.ln2", c->y16, nc, d, TAP_F16_KPERM);
-        { SkwGemmArgs a = gemm_args(c->y16, d, L.fc1, M, c->hbuf, 4L * d, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; skw_gemm(a, c->stream); }
+        { SkwGemmArgs a = gemm_args(c->y16, d, L.fc1, M, c->hbuf, 4L * d, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM(c, a, d); }
         if (l == 0) tap(c, "l0.h", c->hbuf, nc, 4 * d, TAP_F16_KPERM);
-        { SkwGemmArgs a = gemm_args(c->hbuf, 4L * d, L.fc2, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; skw_gemm(a, c->stream); }
+        { SkwGemmArgs a = gemm_args(c->hbuf, 4L * d, L.fc2, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; GEMM(c, a, 4 * d); }
         if (l == 0) tap(c, "l0.x2", c->x, nc, d, TAP_F32);
     }
     skw_layernorm(c->x, M, d, m->ln_post.w, m->ln_post.b, c->y16, want_f32_out ? c->enc_out32 : nullptr, c->stream);
@@ -395,8 +432,8 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
             half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
-            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; skw_gemm(a, c->stream); }
-            { SkwGemmArgs a = gemm_args(c->y16, d, L.cv, M, cv, dt, EPI_F16_PLAIN); skw_gemm(a, c->stream); }
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; GEMM(c, a, d); }
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.cv, M, cv, dt, EPI_F16_PLAIN); GEMM(c, a, d); }
         }
     }
     c->last_enc_B = Bw;
@@ -414,22 +451,22 @@ static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
         half_t* sk = c->selfK + (size_t)l * c->max_batch * ntc * dt; half_t* sv = c->selfV + (size_t)l * c->max_batch * ntc * dt;
         half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
         skw_layernorm(c->dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.q, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.k, Bw, sk + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.v, Bw, sv + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); skw_gemm_smallm(a, s); }
-        skw_dec_self_attn(c->dq16, sk, sv, &c->st[0].cur_pos, Bw, H, dt, ntc, c->datt16, s);
-        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.q, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.k, Bw, sk + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.v, Bw, sv + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(c->dq16, sk, sv, &c->st[0].cur_pos, Bw, H, dt, ntc, c->datt16, s); }
+        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         skw_layernorm(c->dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.cq, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; skw_gemm_smallm(a, s); }
-        skw_dec_cross_attn(c->dq16, ck, cv, Bw, H, dt, nc, c->datt16, s);
-        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.co, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.cq, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn(c->dq16, ck, cv, Bw, H, dt, nc, c->datt16, s); }
+        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.co, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         skw_layernorm(c->dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.fc1, Bw, c->dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; skw_gemm_smallm(a, s); }
-        { SkwGemmArgs a = gemm_args(c->dh16, 4L * dt, L.fc2, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; skw_gemm_smallm(a, s); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.fc1, Bw, c->dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(c->dh16, 4L * dt, L.fc2, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
     }
     if (want_logits) {
         skw_layernorm(c->dx, Bw, dt, m->d_ln.w, m->d_ln.b, c->dy16, nullptr, s);
-        SkwGemmArgs a = gemm_args(c->dy16, dt, m->te, Bw, c->logits, hp.n_vocab, EPI_F32); skw_gemm_smallm(a, s);
+        SkwGemmArgs a = gemm_args(c->dy16, dt, m->te, Bw, c->logits, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
 }
 
@@ -523,7 +560,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             tot_steps++;
         }
         for (int i = 0; i < lp.n_max; ++i) {
-            skw_dec_sample(c->logits, c->static_mask, lp, c->st, c->toks, c->max_tok, Bw, c->n_active, c->stream);
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * Bw * NV); skw_dec_sample(c->logits, c->static_mask, lp, c->st, c->toks, c->max_tok, Bw, c->n_active, c->stream); }
             HIPCHK(hipMemcpyAsync(c->h_n_active, c->n_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             if (*c->h_n_active <= 0 || i == lp.n_max - 1) break;
@@ -581,6 +618,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         R.text = (char*)malloc(A.text.size() + 1); memcpy(R.text, A.text.data(), A.text.size()); R.text[A.text.size()] = 0;
         tot_tokens += R.n_tokens;
     }
+    prof_collect(c);
     { float a = 0, t = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&t, c->ev[0], c->ev[5]);
       c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms; c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps; c->timing.n_tokens = tot_tokens; }
     return 0;

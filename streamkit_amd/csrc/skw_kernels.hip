@@ -148,52 +148,52 @@ __global__ __launch_bounds__(256, 2) void k_gemm(SkwGemmArgs a) {
 }
 
 // ------------------------------------------------------------------ small-M GEMM (decode, M <= 64)
-// One wave per 16-column strip, MT row tiles; fragments straight from global memory (16 B per lane per 32 k).
-template <int EPI, int MT>
+// Weight-streaming form: one wave per (16-column strip, 16-row tile) with ONE accumulator, so the contraction chain
+// advances at the MFMA's dependent latency (40 cycles per 4 k) instead of being shared between row tiles, and a ring
+// of SM_DEPTH k-blocks of fragments (16 B per lane per operand per block) is kept in flight straight from global
+// memory to hide HBM latency.  The 4 waves of a block are the 4 row tiles of one strip (W lines shared through L1/L2).
+#define SM_DEPTH 8
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+union H8v { u32x4 v; half_t h[8]; };
+template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + wave;
-    const int n0 = strip * 16;
-    if (n0 >= a.N) return;
+    const int n0 = blockIdx.x * 16, mt = blockIdx.y * 4 + wave;
+    if (mt * 16 >= a.M) return;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int gn = n0 + r16;
-    const bool nok = gn < a.N;
-    const half_t* wp = a.W + (long)(nok ? gn : 0) * a.ldw + kq * 8;
-    const half_t* ap[MT]; bool aok[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { int gm = t * 16 + r16; aok[t] = gm < a.M; ap[t] = a.A + (long)(aok[t] ? gm : 0) * a.lda + kq * 8; }
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int gn = n0 + r16, gm = mt * 16 + r16;
+    // buffer descriptors with hardware range checking: rows past N / M and k-blocks past K read as zeros,
+    // and fma(0, 0, acc) == acc, so padding never perturbs a chain.  (The intrinsic also keeps the loads 128-bit wide.)
+    const unsigned wbytes = (unsigned)((long)a.N * a.ldw * 2), abytes = (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, abytes, 0x00020000);
+    const unsigned oob = 0x7fffff00u;
+    const unsigned wo = (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kq * 8) * 2) : oob;
+    const unsigned ao = (gm < a.M) ? (unsigned)(((long)gm * a.lda + kq * 8) * 2) : oob;
     const int nk = a.K >> 5;
-    H8 fw, fa[MT], fw2, fa2[MT];
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    fw.u = nok ? *(const uint4*)(wp) : z;
+    H8v fw[SM_DEPTH], fa[SM_DEPTH];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fa[t].u = aok[t] ? *(const uint4*)(ap[t]) : z;
-    for (int kb = 0; kb < nk; ++kb) {
-        if (kb + 1 < nk) {
-            fw2.u = nok ? *(const uint4*)(wp + ((kb + 1) << 5)) : z;
+    for (int j = 0; j < SM_DEPTH; ++j) {
+        fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nk) ? oob : wo + j * 64, 0, 0);
+        fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nk) ? oob : ao + j * 64, 0, 0);
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb0 = 0; kb0 < nk; kb0 += SM_DEPTH) {      // branch-free body: the ring stays SM_DEPTH blocks ahead
 #pragma unroll
-            for (int t = 0; t < MT; ++t) fa2[t].u = aok[t] ? *(const uint4*)(ap[t] + ((kb + 1) << 5)) : z;
+        for (int j = 0; j < SM_DEPTH; ++j) {
+            H8v cw = fw[j], ca = fa[j];
+            const int nb = kb0 + j + SM_DEPTH;
+            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nk) ? oob : wo + nb * 64, 0, 0);
+            fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nk) ? oob : ao + nb * 64, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = MFMA16(h2f(ca.h[e]), h2f(cw.h[e]), acc);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float bv = h2f(fw.h[e]);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = MFMA16(h2f(fa[t].h[e]), bv, acc[t]);
-        }
-        fw = fw2;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) fa[t] = fa2[t];
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int m = t * 16 + kq * 4 + r, n = n0 + r16;
-            if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[t][r]);
-        }
+    for (int r = 0; r < 4; ++r) {
+        int m = mt * 16 + kq * 4 + r, n = n0 + r16;
+        if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[r]);
+    }
 }
 
 template <int EPI> static void launch_gemm(const SkwGemmArgs& a, hipStream_t s) {
@@ -213,12 +213,8 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s) {
     }
 }
 template <int EPI> static void launch_gemm_small(const SkwGemmArgs& a, hipStream_t s) {
-    int strips = (a.N + 15) / 16, blocks = (strips + 3) / 4;
-    int mt = (a.M + 15) / 16;
-    if (mt <= 1) hipLaunchKernelGGL((k_gemm_smallm<EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL((k_gemm_smallm<EPI, 2>), dim3(blocks), dim3(256), 0, s, a);
-    else if (mt == 3) hipLaunchKernelGGL((k_gemm_smallm<EPI, 3>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_smallm<EPI, 4>), dim3(blocks), dim3(256), 0, s, a);
+    dim3 grid((a.N + 15) / 16, (a.M + 63) / 64);
+    hipLaunchKernelGGL((k_gemm_smallm<EPI>), grid, dim3(256), 0, s, a);
 }
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
     switch (a.epi) {
@@ -561,56 +557,85 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
     return r;
 }
 
-// generic single-query attention over n_kv keys with plain f16 K/V rows (row stride ldkv halves), head dim 64.
-// scores: s_j = chain_d q[d] K[j][d]; softmax (ggml_soft_max_ext, scale 1); out[c] = chain_j f16(p_j) V[j][c]
+// single-query attention over n_kv keys with plain f16 K/V rows (row stride ldkv halves), head dim 64.
+//   s_j = chain_d q[d] K[j][d];  softmax as ggml_soft_max_ext (scale 1, f64 denominator);  out[c] = chain_j f16(p_j) V[j][c]
+// One wave per (sequence, head), no block-level synchronisation: lane = key for the scores (64 independent d-chains per
+// pass over K), lane = channel for P.V (one key-ascending chain per output, p_j broadcast with v_readlane).
+// A block is 4 waves = 4 heads of one sequence.
+template <int MAXT>
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
-                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, half_t* out, long ldo) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sc = (float*)smem;                       // [n_kv_max]
-    __shared__ float shf[8]; __shared__ double shd[8]; __shared__ float qs[64];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (h >= H) return;
     const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
-    if (tid < 64) qs[tid] = h2f(q[(long)b * ldq + h * 64 + tid]);
-    __syncthreads();
     const half_t* K = kbase + (long)b * batch_stride + h * 64;
     const half_t* V = vbase + (long)b * batch_stride + h * 64;
+    float qv[64];
+    {
+        const uint4* qp = (const uint4*)(q + (long)b * ldq + h * 64);
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) { H8 t; t.u = qp[c8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[c8 * 8 + e] = h2f(t.h[e]); }
+    }
+    float sc[MAXT];
     float lmax = -INFINITY;
-    for (int j = tid; j < n_kv; j += blockDim.x) {
-        const half_t* kr = K + (long)j * ldkv;
-        float a = 0.0f;
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) { H8 kk; kk.u = *(const uint4*)(kr + c8 * 8);
+    for (int t = 0; t < MAXT; ++t) {
+        sc[t] = -INFINITY;
+        if (t * 64 < n_kv) {   // wave-uniform
+            const int key = t * 64 + lane;
+            const uint4* kr = (const uint4*)(K + (long)min(key, n_kv - 1) * ldkv);
+            uint4 kk[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qs[c8 * 8 + e], h2f(kk.h[e]), a); }
-        sc[j] = a; lmax = fmaxf(lmax, a);
-    }
-    const float mx = block_max(lmax, shf);
-    double lsum = 0.0;
-    for (int j = tid; j < n_kv; j += blockDim.x) { float e = skw_expf(sc[j] - mx); sc[j] = e; lsum += (double)e; }
-    const double tot = block_sum_f64(lsum, shd);
-    const float inv = (float)(1.0 / tot);
-    for (int j = tid; j < n_kv; j += blockDim.x) sc[j] = h2f(f2h(sc[j] * inv));
-    __syncthreads();
-    if (tid < 64) {
-        float a = 0.0f; const half_t* vp = V + tid;
-        int j = 0;
-        for (; j + 8 <= n_kv; j += 8) {
-            float v0 = h2f(vp[(long)(j + 0) * ldkv]), v1 = h2f(vp[(long)(j + 1) * ldkv]), v2 = h2f(vp[(long)(j + 2) * ldkv]), v3 = h2f(vp[(long)(j + 3) * ldkv]);
-            float v4 = h2f(vp[(long)(j + 4) * ldkv]), v5 = h2f(vp[(long)(j + 5) * ldkv]), v6 = h2f(vp[(long)(j + 6) * ldkv]), v7 = h2f(vp[(long)(j + 7) * ldkv]);
-            a = __builtin_fmaf(sc[j + 0], v0, a); a = __builtin_fmaf(sc[j + 1], v1, a); a = __builtin_fmaf(sc[j + 2], v2, a); a = __builtin_fmaf(sc[j + 3], v3, a);
-            a = __builtin_fmaf(sc[j + 4], v4, a); a = __builtin_fmaf(sc[j + 5], v5, a); a = __builtin_fmaf(sc[j + 6], v6, a); a = __builtin_fmaf(sc[j + 7], v7, a);
+            for (int c8 = 0; c8 < 8; ++c8) kk[c8] = kr[c8];
+            float a = 0.0f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) { H8 t8; t8.u = kk[c8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qv[c8 * 8 + e], h2f(t8.h[e]), a); }
+            if (key < n_kv) { sc[t] = a; lmax = fmaxf(lmax, a); }
         }
-        for (; j < n_kv; ++j) a = __builtin_fmaf(sc[j], h2f(vp[(long)j * ldkv]), a);
-        out[(long)b * ldo + skw_kperm(h * 64 + tid)] = f2h(a);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    double lsum = 0.0;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) if (t * 64 < n_kv) { float e = skw_expf(sc[t] - lmax); sc[t] = e; lsum += (double)e; }
+    lsum = wave_sum_f64(lsum);
+    const float inv = (float)(1.0 / lsum);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) if (t * 64 < n_kv) sc[t] = h2f(f2h(sc[t] * inv));
+    // P.V: lane = channel
+    float acc = 0.0f;
+    const half_t* vp = V + lane;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t * 64 < n_kv) {
+            const int nj = min(64, n_kv - t * 64);
+            const int pbits = __float_as_int(sc[t]);
+            const half_t* vt = vp + (long)t * 64 * ldkv;
+            int jj = 0;
+            for (; jj + 16 <= nj; jj += 16) {
+                half_t vv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) vv[u] = vt[(long)(jj + u) * ldkv];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, jj + u)), h2f(vv[u]), acc);
+            }
+            for (; jj < nj; ++jj) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, jj)), h2f(vt[(long)jj * ldkv]), acc);
+        }
+    }
+    out[(long)b * ldo + skw_kperm(h * 64 + lane)] = f2h(acc);
 }
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_attn, dim3(H, B), dim3(256), n_text_ctx * sizeof(float), s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, out, (long)d);
+    hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d);
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_attn, dim3(H, B), dim3(256), n_ctx * sizeof(float), s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, out, (long)d);
+    hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

@@ -74,6 +74,8 @@ def lib():
         L.skw_conv_stem.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.skw_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.skw_decode_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.skw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
+        L.skw_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.skw_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         L.skw_debug_enable.argtypes = [C.c_int]
         L.skw_debug_get.restype = C.c_long
@@ -155,6 +157,17 @@ class Context:
         t = Timing()
         lib().skw_ctx_last_timing(self.h, C.byref(t))
         return {f: getattr(t, f) for f, _ in t._fields_}
+
+    def profile(self, on=True):
+        lib().skw_ctx_profile(self.h, 1 if on else 0)
+
+    def profile_get(self):
+        out = {}
+        for cls in range(8):
+            name = C.create_string_buffer(64); cnt = C.c_long(); ms = C.c_double(); fl = C.c_double(); by = C.c_double()
+            if lib().skw_ctx_profile_get(self.h, cls, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)) == 0:
+                out[name.value.decode()] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out
 
     def stream(self):
         return lib().skw_ctx_stream(self.h)
