@@ -62,24 +62,19 @@ def main():
     params.suppress_nst = 1   # the reference node's default (lib.rs:634, suppress_non_speech_tokens = true)
 
     # inputs: clip c -> rank c mod world; resident in HBM before the timed region
-    clip_ids = [c for c in range(B * world) if c % world == rank]
+    from streamkit_amd.dist import shard_clip_ids
+    clip_ids = shard_clip_ids(B * world, rank, world)
     host = np.stack([synth.clip(c, n_samples) for c in clip_ids])
     dev = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
     ptrs = [dev[i].data_ptr() for i in range(B)]
     ns = [n_samples] * B
-    tok_buf = torch.full((B, 2 + 224), -1, dtype=torch.int32, device="cuda")
-    gathered = [torch.empty_like(tok_buf) for _ in range(world)] if world > 1 else None
+    from streamkit_amd import dist as skd
 
     def step():
         res = ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
-        if world > 1:   # the one exchange step: fixed-size token buffers to every rank (detokenised on the root)
-            rows = np.full((B, 226), -1, dtype=np.int32)
-            for i, r in enumerate(res):
-                ids = [t[0] for t in r["tokens"]][:224]
-                rows[i, 0] = len(ids); rows[i, 1] = len(r["segments"]); rows[i, 2:2 + len(ids)] = ids
-            tok_buf.copy_(torch.from_numpy(rows))
-            dist.all_gather(gathered, tok_buf)
+        if world > 1:   # the one exchange step: fixed-size int32 token buffers to every rank over RCCL
+            skd.gather_tokens(skd.pack_tokens(res), world, device=torch.device("cuda", local_rank))
         return res
 
     def barrier():

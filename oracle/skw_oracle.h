@@ -108,6 +108,9 @@ void skwo_result_free(skwo_result*);
 void skwo_debug_enable(int on);
 long skwo_debug_get(const char* name, float* out, size_t cap);
 
+/* W1-W3: segmentation state machine over per-frame speech probabilities; cuts[i] = {start_ms, end_ms, n_samples, reason (0 max_duration, 1 silence), silence_ms or -1, frame index} */
+int skwo_segment_sim(const float* prob, int n_frames, float threshold, uint64_t min_silence_ms, float max_secs, int64_t* cuts, int max_cuts);
+
 /* R1-R3: rubato FastFixedIn<f32>, PolynomialDegree::Linear, as driven by resampler.rs */
 typedef struct skwo_resampler skwo_resampler;
 skwo_resampler* skwo_resampler_new(double ratio, int chunk_frames, int channels);

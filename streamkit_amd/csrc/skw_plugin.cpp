@@ -1,0 +1,350 @@
+// skw_plugin.cpp — libwhisper.so: the StreamKit native plugin `whisper` (registered by the host as
+// plugin::native::whisper) on top of the MI355X engine.  Drop-in for the reference cdylib:
+//   /root/reference/plugins/native/whisper/src/lib.rs        (this file restates it function by function)
+//   /root/reference/sdks/plugin-sdk/native/src/lib.rs:426-856 (the six extern "C" entry points the macro generates)
+// ABI: include/streamkit_native_abi.h.
+//
+// Differences from the reference that a host can observe are all ADDITIVE params (unknown keys are ignored by the
+// reference's serde config, lib.rs:66-104): vad_mode, batch_window_ms, max_batch, flush_tail.
+#include "../../include/streamkit_native_abi.h"
+#include "../../include/skw_engine.h"
+#include "skw_segmenter.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------ error strings (conversions.rs:441-461: thread-local, borrowed)
+thread_local std::string g_last_error;
+CResult ok_result() { CResult r; r.success = true; r.error_message = nullptr; return r; }
+CResult err_result(const std::string& msg) {
+    g_last_error = msg; for (auto& ch : g_last_error) if (ch == '\0') ch = ' ';
+    CResult r; r.success = false; r.error_message = g_last_error.c_str(); return r;
+}
+CResult err_null() { CResult r; r.success = false; r.error_message = nullptr; return r; }
+
+// ------------------------------------------------------------------ configuration (lib.rs:25-157)
+struct WhisperConfig {
+    std::string model_path = "models/ggml-base.en-q5_1.bin";
+    std::string language = "en";
+    std::string vad_model_path = "models/silero_vad.onnx";
+    float vad_threshold = 0.5f;
+    uint64_t min_silence_duration_ms = 700;
+    float max_segment_duration_secs = 30.0f;
+    uint64_t n_threads = 0;
+    bool use_gpu = false; int gpu_device = 0;
+    bool suppress_blank = true, suppress_non_speech_tokens = true;
+    bool emit_vad_events = false;
+    // additive
+    std::string vad_mode = "auto";   // auto | silero | energy | always
+    int batch_window_ms = 2; int max_batch = 64; bool flush_tail = false;
+};
+
+bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
+    if (!json || !*json) return true;
+    skw::JsonValue v; std::string perr;
+    if (!skw::json_parse(json, &v, &perr)) { *err = "Invalid config: " + perr; return false; }
+    if (v.type == skw::JsonValue::Null) return true;
+    if (v.type != skw::JsonValue::Object) { *err = "Invalid config: expected a JSON object"; return false; }
+    auto str = [&](const char* k, std::string* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::String) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a string"; return false; } *dst = x->str; return true; };
+    auto num = [&](const char* k, double* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Number) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a number"; return false; } *dst = x->num; return true; };
+    auto boo = [&](const char* k, bool* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Bool) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a boolean"; return false; } *dst = x->b; return true; };
+    double d;
+    if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode)) return false;
+    d = cfg->vad_threshold; if (!num("vad_threshold", &d)) return false; cfg->vad_threshold = (float)d;
+    d = (double)cfg->min_silence_duration_ms; if (!num("min_silence_duration_ms", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: min_silence_duration_ms must be a non-negative integer"; return false; } cfg->min_silence_duration_ms = (uint64_t)d;
+    d = cfg->max_segment_duration_secs; if (!num("max_segment_duration_secs", &d)) return false; cfg->max_segment_duration_secs = (float)d;
+    d = (double)cfg->n_threads; if (!num("n_threads", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: n_threads must be a non-negative integer"; return false; } cfg->n_threads = (uint64_t)d;
+    d = cfg->gpu_device; if (!num("gpu_device", &d)) return false; if (d != std::floor(d)) { *err = "Invalid config: gpu_device must be an integer"; return false; } cfg->gpu_device = (int)d;
+    d = cfg->batch_window_ms; if (!num("batch_window_ms", &d)) return false; cfg->batch_window_ms = (int)d;
+    d = cfg->max_batch; if (!num("max_batch", &d)) return false; cfg->max_batch = std::max(1, (int)d);
+    if (!boo("use_gpu", &cfg->use_gpu) || !boo("suppress_blank", &cfg->suppress_blank) || !boo("suppress_non_speech_tokens", &cfg->suppress_non_speech_tokens) ||
+        !boo("emit_vad_events", &cfg->emit_vad_events) || !boo("flush_tail", &cfg->flush_tail)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ shared engine: model cache + batch scheduler
+// One per (model_path, use_gpu, gpu_device) — the key of the reference's WHISPER_CONTEXT_CACHE (lib.rs:175-180, 330).
+// Instances submit finished speech segments; a worker thread forms batches and runs skw_full_batch.
+struct Job {
+    std::vector<float> pcm; skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
+};
+struct SharedEngine {
+    skw_model* model = nullptr; skw_ctx* ctx = nullptr; int max_batch = 64; int window_ms = 2; int max_samples = 0;
+    std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<Job>> queue; bool stop = false; std::thread worker;
+    ~SharedEngine() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); if (worker.joinable()) worker.join();
+        if (ctx) skw_ctx_free(ctx); if (model) skw_model_free(model);
+    }
+    void run() {
+        for (;;) {
+            std::vector<std::shared_ptr<Job>> batch;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                // batch formation: give concurrent instances a short window to join
+                auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(window_ms);
+                while ((int)queue.size() < max_batch && !stop) { if (cv.wait_until(l, deadline) == std::cv_status::timeout) break; }
+                while (!queue.empty() && (int)batch.size() < max_batch) {
+                    // one skw_full_batch call shares its params: group by the params of the first job
+                    if (!batch.empty() && memcmp(&batch[0]->params, &queue.front()->params, sizeof(skw_full_params)) != 0) break;
+                    batch.push_back(queue.front()); queue.pop_front();
+                }
+            }
+            const int n = (int)batch.size();
+            std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n);
+            for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->pcm.data(); ns[i] = (int32_t)batch[i]->pcm.size(); }
+            int rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
+            for (int i = 0; i < n; ++i) {
+                if (rc == 0) batch[i]->result = res[i]; else batch[i]->error = skw_ctx_last_error(ctx);
+                batch[i]->done.set_value(rc);
+            }
+        }
+    }
+};
+std::mutex g_cache_mu;
+std::map<std::string, std::weak_ptr<SharedEngine>> g_cache;   // weak: the model is released when the last instance goes away
+
+std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, std::string* err) {
+    char keybuf[64]; snprintf(keybuf, sizeof keybuf, "|%d|%d", cfg.use_gpu ? 1 : 0, cfg.gpu_device);
+    const std::string key = cfg.model_path + keybuf;
+    std::lock_guard<std::mutex> l(g_cache_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) if (auto sp = it->second.lock()) return sp;
+    char ebuf[512] = {0};
+    auto eng = std::make_shared<SharedEngine>();
+    eng->model = skw_model_load(cfg.model_path.c_str(), cfg.gpu_device, ebuf, sizeof ebuf);
+    if (!eng->model) { *err = ebuf[0] ? ebuf : ("Failed to load Whisper model from '" + cfg.model_path + "'"); return nullptr; }
+    eng->max_batch = cfg.max_batch; eng->window_ms = cfg.batch_window_ms;
+    eng->max_samples = 16000 * 121;   // schema maximum of max_segment_duration_secs (120 s) + one VAD frame of slack
+    eng->ctx = skw_ctx_create(eng->model, eng->max_batch, eng->max_samples, ebuf, sizeof ebuf);
+    if (!eng->ctx) { *err = std::string("Failed to create Whisper state: ") + ebuf; return nullptr; }
+    eng->worker = std::thread([e = eng.get()] { e->run(); });
+    g_cache[key] = eng;
+    return eng;
+}
+
+// ------------------------------------------------------------------ the plugin instance (lib.rs:199-221)
+struct WhisperPlugin {
+    WhisperConfig config; std::shared_ptr<SharedEngine> engine; skw::Segmenter seg; std::unique_ptr<skw::Vad> vad;
+    CLogCallback log_cb = nullptr; void* log_ud = nullptr;
+    void log(CLogLevel lv, const char* fmt, ...) {
+        if (!log_cb) return; char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        log_cb(lv, "whisper_plugin_native", buf, log_ud);
+    }
+};
+
+std::unique_ptr<skw::Vad> make_vad(const WhisperConfig& cfg, WhisperPlugin* p, std::string* err) {
+    std::string mode = cfg.vad_mode;
+    if (mode == "auto") {
+        // Silero inference (vad.rs:67-120) is not part of this build; the gate that decides what reaches Whisper is
+        // replaced by an energy gate unless the host asks for something else. Logged once per instance.
+        if (p) p->log(SK_LOG_WARN, "Silero VAD model '%s' is not evaluated by this build; using vad_mode=energy (set vad_mode explicitly to silence this)", cfg.vad_model_path.c_str());
+        mode = "energy";
+    }
+    if (mode == "always") return std::unique_ptr<skw::Vad>(new skw::AlwaysSpeechVad());
+    if (mode == "energy") return std::unique_ptr<skw::Vad>(new skw::EnergyVad());
+    if (mode == "silero") { *err = "Failed to initialize VAD: Silero ONNX inference is not available in this build (use vad_mode energy or always)"; return nullptr; }
+    *err = "Failed to initialize VAD: unknown vad_mode '" + mode + "'"; return nullptr;
+}
+
+struct Emit {
+    COutputCallback out_cb; void* out_ud; CTelemetryCallback tel_cb; void* tel_ud;
+    // OutputSender::send (sdk lib.rs:200-223)
+    bool send_transcription(const std::string& json, std::string* err) const {
+        CPacket pk; pk.packet_type = SK_PACKET_TRANSCRIPTION; pk.data = json.data(); pk.len = json.size();
+        CResult r = out_cb("out", &pk, out_ud);
+        if (r.success) return true;
+        *err = r.error_message ? std::string(r.error_message) : std::string("Unknown error"); return false;
+    }
+    // OutputSender::emit_telemetry (sdk lib.rs:237-283): best effort, errors ignored by the caller (lib.rs:438 `let _ =`)
+    void telemetry(const char* event, const std::string& json) const { if (tel_cb) (void)tel_cb(event, (const uint8_t*)json.data(), json.size(), nullptr, tel_ud); }
+};
+
+// transcribe_and_emit (lib.rs:582-702)
+bool transcribe_and_emit(WhisperPlugin* self, const Emit& em, const skw::SegmentCut& cut, std::string* err) {
+    if (cut.samples.empty()) return true;
+    if (self->config.emit_vad_events && !cut.segment_id.empty()) {
+        std::string j = "{\"duration_ms\":" + std::to_string(cut.end_time_ms >= cut.start_time_ms ? cut.end_time_ms - cut.start_time_ms : 0) +
+                        ",\"end_time_ms\":" + std::to_string(cut.end_time_ms) + ",\"reason\":" + skw::json_quote(cut.reason) + ",\"segment_id\":" + skw::json_quote(cut.segment_id) +
+                        ",\"silence_duration_ms\":" + (cut.has_silence_duration ? std::to_string(cut.silence_duration_ms) : std::string("null")) +
+                        ",\"start_time_ms\":" + std::to_string(cut.start_time_ms) + "}";
+        em.telemetry("vad.speech_end", j);
+    }
+    auto job = std::make_shared<Job>();
+    job->pcm = cut.samples;
+    skw_full_default_params(&job->params);
+    int lang = skw_model_lang_id(self->config.language.c_str());
+    if (lang < 0) { *err = "Whisper inference failed: unknown language '" + self->config.language + "'"; return false; }
+    job->params.lang_id = lang; job->params.translate = 0;
+    job->params.suppress_blank = self->config.suppress_blank ? 1 : 0; job->params.suppress_nst = self->config.suppress_non_speech_tokens ? 1 : 0;
+    job->params.n_threads = (int32_t)self->config.n_threads;
+    if ((int)job->pcm.size() > self->engine->max_samples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
+    std::future<int> fut = job->done.get_future();
+    { std::lock_guard<std::mutex> l(self->engine->mu); self->engine->queue.push_back(job); }
+    self->engine->cv.notify_all();
+    int rc = fut.get();
+    if (rc != 0) { *err = "Whisper inference failed: " + job->error; return false; }
+    // segments with absolute timestamps (lib.rs:648-677)
+    struct Seg { std::string text; uint64_t t0, t1; };
+    std::vector<Seg> segs;
+    const skw_result& R = job->result;
+    for (int i = 0; i < R.n_segments; ++i) {
+        std::string text(R.text + R.segments[i].text_off, (size_t)R.segments[i].text_len);
+        if (!skw::utf8_valid(text)) { self->log(SK_LOG_WARN, "Failed to get segment text: invalid UTF-8"); continue; }
+        std::string trimmed = skw::utf8_trim(text);
+        if (trimmed.empty()) continue;
+        const uint64_t rel0 = (uint64_t)(R.segments[i].t0 * 10), rel1 = (uint64_t)(R.segments[i].t1 * 10);   // `as u64` of an i64
+        segs.push_back(Seg{trimmed, cut.start_time_ms + rel0, cut.start_time_ms + rel1});
+    }
+    if (segs.empty()) self->log(SK_LOG_WARN, "Whisper inference produced no segments");
+    else {
+        std::string full; for (size_t i = 0; i < segs.size(); ++i) { if (i) full += " "; full += segs[i].text; }
+        // serde_json::to_vec(TranscriptionData) (crates/core/src/types.rs:150-175): field order of the structs
+        std::string j = "{\"text\":" + skw::json_quote(full) + ",\"segments\":[";
+        for (size_t i = 0; i < segs.size(); ++i) {
+            if (i) j += ",";
+            j += "{\"text\":" + skw::json_quote(segs[i].text) + ",\"start_time_ms\":" + std::to_string(segs[i].t0) + ",\"end_time_ms\":" + std::to_string(segs[i].t1) + ",\"confidence\":null}";
+        }
+        j += "],\"language\":" + skw::json_quote(self->config.language) + ",\"metadata\":null}";
+        skw_result_free(&job->result);
+        if (!em.send_transcription(j, err)) return false;
+        return true;
+    }
+    skw_result_free(&job->result);
+    return true;
+}
+
+void emit_speech_start(WhisperPlugin* self, const Emit& em, const skw::SpeechStart& s) {
+    if (!self->config.emit_vad_events) return;
+    std::string j = "{\"segment_id\":" + skw::json_quote(s.segment_id) + ",\"speech_probability\":" + skw::json_f32(s.probability) +
+                    ",\"start_time_ms\":" + std::to_string(s.start_time_ms) + ",\"threshold\":" + skw::json_f32(self->config.vad_threshold) + "}";
+    em.telemetry("vad.speech_start", j);
+}
+
+// ------------------------------------------------------------------ metadata (lib.rs:224-320)
+const char* const kDescription =
+    "Real-time speech-to-text transcription using OpenAI's Whisper model. Features VAD-based segmentation for natural speech boundaries, "
+    "GPU acceleration support, and streaming output. Requires 16kHz mono audio input.";
+const char* const kSchema =
+    "{\"type\":\"object\",\"properties\":{"
+    "\"model_path\":{\"type\":\"string\",\"description\":\"Path to Whisper GGML model file (relative to repo root). IMPORTANT: Input audio must be 16kHz mono f32.\",\"default\":\"models/ggml-base.en-q5_1.bin\"},"
+    "\"language\":{\"type\":\"string\",\"description\":\"Language code (e.g., 'en', 'es', 'fr')\",\"default\":\"en\"},"
+    "\"vad_model_path\":{\"type\":\"string\",\"description\":\"Path to Silero VAD ONNX model file\",\"default\":\"models/silero_vad.onnx\"},"
+    "\"vad_threshold\":{\"type\":\"number\",\"description\":\"VAD speech probability threshold (0.0-1.0)\",\"default\":0.5,\"minimum\":0.0,\"maximum\":1.0},"
+    "\"min_silence_duration_ms\":{\"type\":\"integer\",\"description\":\"Minimum silence duration before transcription (milliseconds)\",\"default\":700,\"minimum\":100,\"maximum\":5000},"
+    "\"max_segment_duration_secs\":{\"type\":\"number\",\"description\":\"Maximum segment duration before forced transcription (seconds)\",\"default\":30.0,\"minimum\":5.0,\"maximum\":120.0},"
+    "\"n_threads\":{\"type\":\"integer\",\"description\":\"Number of threads for decoding (0 = auto: min(4, num_cores), 8-12 recommended for modern CPUs)\",\"default\":0,\"minimum\":0,\"maximum\":32},"
+    "\"use_gpu\":{\"type\":\"boolean\",\"description\":\"Enable GPU acceleration (this build always runs on the MI355X selected by gpu_device)\",\"default\":false},"
+    "\"gpu_device\":{\"type\":\"integer\",\"description\":\"GPU device ID to use (0 = first GPU, 1 = second GPU, etc.)\",\"default\":0,\"minimum\":0,\"maximum\":7},"
+    "\"suppress_blank\":{\"type\":\"boolean\",\"description\":\"Suppress blank/silent audio segments\",\"default\":true},"
+    "\"suppress_non_speech_tokens\":{\"type\":\"boolean\",\"description\":\"Suppress non-speech tokens like [BLANK_AUDIO], [MUSIC], [APPLAUSE], etc.\",\"default\":true},"
+    "\"emit_vad_events\":{\"type\":\"boolean\",\"description\":\"Emit VAD speech start/end out-of-band to the telemetry bus (does not flow through graph pins).\",\"default\":false},"
+    "\"vad_mode\":{\"type\":\"string\",\"description\":\"(additive) auto | energy | always | silero\",\"default\":\"auto\"},"
+    "\"batch_window_ms\":{\"type\":\"integer\",\"description\":\"(additive) how long the per-GPU scheduler waits for concurrent instances before launching a batch\",\"default\":2},"
+    "\"max_batch\":{\"type\":\"integer\",\"description\":\"(additive) largest number of segments transcribed in one GPU batch\",\"default\":64},"
+    "\"flush_tail\":{\"type\":\"boolean\",\"description\":\"(additive) transcribe buffered speech when the input stream ends (the reference drops it)\",\"default\":false}"
+    "}}";
+
+const CAudioFormat kInFormat = {16000, 1, SK_SAMPLE_F32};
+const CPacketTypeInfo kInTypes[1] = {{SK_PACKET_RAW_AUDIO, &kInFormat, nullptr}};
+const CInputPin kInputs[1] = {{"in", kInTypes, 1}};
+const COutputPin kOutputs[1] = {{"out", {SK_PACKET_TRANSCRIPTION, nullptr, nullptr}}};
+const char* const kCategories[3] = {"ml", "speech", "transcription"};
+const CNodeMetadata kMetadata = {"whisper", kDescription, kInputs, 1, kOutputs, 1, kSchema, kCategories, 3};
+
+// ------------------------------------------------------------------ the six entry points (sdk lib.rs:462-854)
+const CNodeMetadata* plugin_get_metadata() { return &kMetadata; }
+
+CPluginHandle plugin_create_instance(const char* params, CLogCallback log_cb, void* log_ud) {
+    auto p = std::unique_ptr<WhisperPlugin>(new WhisperPlugin()); p->log_cb = log_cb; p->log_ud = log_ud;
+    std::string err;
+    if (!parse_config(params, &p->config, &err)) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
+    p->engine = get_engine(p->config, &err);
+    if (!p->engine) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
+    p->vad = make_vad(p->config, p.get(), &err);
+    if (!p->vad) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
+    p->seg.configure(p->config.vad_threshold, p->config.min_silence_duration_ms, p->config.max_segment_duration_secs);
+    return (CPluginHandle)p.release();
+}
+
+CResult plugin_process_packet(CPluginHandle handle, const char* input_pin, const CPacket* packet, COutputCallback out_cb, void* out_ud,
+                              CTelemetryCallback tel_cb, void* tel_ud) {
+    if (!handle || !input_pin || !packet) return err_null();
+    WhisperPlugin* self = (WhisperPlugin*)handle;
+    if (!packet->data) return err_result("Invalid packet: Null packet data pointer");
+    if (packet->packet_type != SK_PACKET_RAW_AUDIO) {
+        if (packet->packet_type == SK_PACKET_TEXT || packet->packet_type == SK_PACKET_TRANSCRIPTION || packet->packet_type == SK_PACKET_CUSTOM || packet->packet_type == SK_PACKET_BINARY)
+            return err_result("Whisper plugin only accepts audio packets");
+        return err_result("Invalid packet: Unsupported packet type");
+    }
+    const CAudioFrame* fr = (const CAudioFrame*)packet->data;
+    if (!fr->samples) return err_result("Invalid packet: Null samples pointer in audio frame");
+    // validate_audio_format (lib.rs:183-197)
+    if (fr->sample_rate != 16000) return err_result("Whisper requires 16kHz audio, got " + std::to_string(fr->sample_rate) + "Hz. Please add an audio_resample node upstream.");
+    if (fr->channels != 1) return err_result("Whisper requires mono audio, got " + std::to_string(fr->channels) + " channels. Please add an audio_resample node upstream.");
+    Emit em{out_cb, out_ud, tel_cb, tel_ud};
+    std::string err; bool failed = false;
+    self->seg.push(fr->samples, fr->sample_count, *self->vad,
+                   [&](const skw::SpeechStart& s) { emit_speech_start(self, em, s); },
+                   [&](const skw::SegmentCut& cut) { if (!transcribe_and_emit(self, em, cut, &err)) { failed = true; return false; } return true; }, &err);
+    if (failed || !err.empty()) return err_result(err);
+    return ok_result();
+}
+
+CResult plugin_update_params(CPluginHandle handle, const char* params) {
+    if (!handle) return err_result("Invalid handle (null)");
+    WhisperPlugin* self = (WhisperPlugin*)handle;
+    if (!params || !*params) return ok_result();
+    WhisperConfig nc;   // serde deserialises a fresh config from the new JSON (defaults for missing keys), lib.rs:498-499
+    std::string err;
+    if (!parse_config(params, &nc, &err)) return err_result(err);
+    if (nc.model_path != self->config.model_path || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
+        auto eng = get_engine(nc, &err);
+        if (!eng) return err_result("Failed to reload Whisper model: " + err);
+        self->engine = eng;
+    }
+    if (nc.vad_model_path != self->config.vad_model_path || nc.vad_threshold != self->config.vad_threshold || nc.vad_mode != self->config.vad_mode) {
+        auto v = make_vad(nc, self, &err);
+        if (!v) return err_result("Failed to reload VAD: " + err);
+        self->vad = std::move(v);
+    }
+    if (nc.min_silence_duration_ms != self->config.min_silence_duration_ms) self->seg.set_min_silence_ms(nc.min_silence_duration_ms);
+    self->seg.set_threshold(nc.vad_threshold); self->seg.set_max_duration_secs(nc.max_segment_duration_secs);
+    self->config = nc;
+    return ok_result();
+}
+
+CResult plugin_flush(CPluginHandle handle, COutputCallback out_cb, void* out_ud, CTelemetryCallback tel_cb, void* tel_ud) {
+    if (!handle) return err_result("Invalid handle (null)");
+    WhisperPlugin* self = (WhisperPlugin*)handle;
+    if (!self->config.flush_tail) return ok_result();   // trait default (sdk lib.rs:324-326): buffered tail is dropped
+    Emit em{out_cb, out_ud, tel_cb, tel_ud}; std::string err;
+    skw::SegmentCut cut;
+    if (self->seg.take_tail(&cut) && !transcribe_and_emit(self, em, cut, &err)) return err_result(err);
+    return ok_result();
+}
+
+void plugin_destroy_instance(CPluginHandle handle) { if (handle) delete (WhisperPlugin*)handle; }
+
+const CNativePluginAPI kApi = {STREAMKIT_NATIVE_PLUGIN_API_VERSION, plugin_get_metadata, plugin_create_instance, plugin_process_packet,
+                               plugin_update_params, plugin_flush, plugin_destroy_instance};
+}  // namespace
+
+extern "C" const CNativePluginAPI* streamkit_native_plugin_api(void) { return &kApi; }

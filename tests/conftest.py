@@ -1,0 +1,89 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+HAVE_GPU = _have_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    if HAVE_GPU:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def _ensure_built():
+    tool = os.path.join(ROOT, "tools", "make_synth_model")
+    if not os.path.exists(tool):
+        subprocess.check_call(["gcc", "-O2", "-o", tool, tool + ".c", "-lm"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libskw_oracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    for lib in ("libskw_engine.so", "libwhisper.so", "libskw_minihost.so"):
+        if not os.path.exists(os.path.join(ROOT, "streamkit_amd", lib)):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "streamkit_amd", "csrc")])
+            break
+    return tool
+
+
+def synth_model(size, seed=1234):
+    tool = _ensure_built()
+    path = "/tmp/skw_test_%s_%d.bin" % (size, seed)
+    if not os.path.exists(path):
+        subprocess.check_call([tool, path + ".tmp", "--size", size, "--seed", str(seed)])
+        os.replace(path + ".tmp", path)
+    return path
+
+
+@pytest.fixture(scope="session")
+def built():
+    _ensure_built()
+    return ROOT
+
+
+@pytest.fixture(scope="session")
+def tiny_model_path():
+    return synth_model("tiny")
+
+
+@pytest.fixture(scope="session")
+def micro_model_path():
+    return synth_model("micro")
+
+
+@pytest.fixture(scope="session")
+def small_model_path():
+    return synth_model("small")
+
+
+@pytest.fixture(scope="session")
+def oracle_tiny(tiny_model_path):
+    from oracle_lib import OracleModel
+    return OracleModel(tiny_model_path)
+
+
+@pytest.fixture(scope="session")
+def oracle_micro(micro_model_path):
+    from oracle_lib import OracleModel
+    return OracleModel(micro_model_path)

@@ -1,0 +1,146 @@
+"""ctypes binding of libskw_minihost.so (C++ stand-in for the StreamKit host side of the plugin boundary)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libskw_minihost.so"))
+        L.mh_load.restype = C.c_void_p; L.mh_load.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mh_metadata_json.restype = C.c_char_p; L.mh_metadata_json.argtypes = [C.c_void_p]
+        L.mh_unload.argtypes = [C.c_void_p]
+        L.mh_create_node.restype = C.c_void_p; L.mh_create_node.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mh_process_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint16]
+        L.mh_process_text.argtypes = [C.c_void_p, C.c_char_p]
+        L.mh_process_null.argtypes = [C.c_void_p]
+        L.mh_update_params.argtypes = [C.c_void_p, C.c_char_p]
+        L.mh_flush.argtypes = [C.c_void_p]
+        L.mh_output_count.restype = C.c_size_t; L.mh_output_count.argtypes = [C.c_void_p]
+        L.mh_output_pin.restype = C.c_char_p; L.mh_output_pin.argtypes = [C.c_void_p, C.c_size_t]
+        L.mh_output_type.argtypes = [C.c_void_p, C.c_size_t]
+        L.mh_output_payload.restype = C.c_void_p; L.mh_output_payload.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mh_telemetry_count.restype = C.c_size_t; L.mh_telemetry_count.argtypes = [C.c_void_p]
+        L.mh_telemetry_type.restype = C.c_char_p; L.mh_telemetry_type.argtypes = [C.c_void_p, C.c_size_t]
+        L.mh_telemetry_json.restype = C.c_char_p; L.mh_telemetry_json.argtypes = [C.c_void_p, C.c_size_t]
+        L.mh_log_count.restype = C.c_size_t; L.mh_log_count.argtypes = [C.c_void_p]
+        L.mh_log.restype = C.c_char_p; L.mh_log.argtypes = [C.c_void_p, C.c_size_t]
+        L.mh_last_error.restype = C.c_char_p; L.mh_last_error.argtypes = [C.c_void_p]
+        L.mh_destroy_node.argtypes = [C.c_void_p]
+        L.mh_resampler_new.restype = C.c_void_p; L.mh_resampler_new.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.mh_resampler_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint16, C.c_int, C.c_uint64]
+        L.mh_resampler_finish.argtypes = [C.c_void_p]
+        L.mh_resampler_out_count.restype = C.c_size_t; L.mh_resampler_out_count.argtypes = [C.c_void_p]
+        L.mh_resampler_out.restype = C.POINTER(C.c_float)
+        L.mh_resampler_out.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mh_resampler_clear.argtypes = [C.c_void_p]
+        L.mh_resampler_error.restype = C.c_char_p; L.mh_resampler_error.argtypes = [C.c_void_p]
+        L.mh_resampler_free.argtypes = [C.c_void_p]
+        L.mh_segment_sim.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_void_p, C.c_int]
+        L.mh_json_quote.restype = C.c_char_p; L.mh_json_quote.argtypes = [C.c_char_p]
+        L.mh_json_f32.restype = C.c_char_p; L.mh_json_f32.argtypes = [C.c_float]
+        L.mh_utf8_trim.restype = C.c_char_p; L.mh_utf8_trim.argtypes = [C.c_char_p]
+        L.mh_utf8_valid.argtypes = [C.c_char_p, C.c_size_t]
+        _L = L
+    return _L
+
+
+class Plugin:
+    def __init__(self, path=None):
+        path = path or os.path.join(ROOT, "streamkit_amd", "libwhisper.so")
+        err = C.create_string_buffer(1024)
+        self.h = lib().mh_load(path.encode(), err, 1024)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+        self.metadata = json.loads(lib().mh_metadata_json(self.h).decode())
+
+    def create_node(self, params=None):
+        return Node(self, params)
+
+
+class Node:
+    def __init__(self, plugin, params=None):
+        err = C.create_string_buffer(4096)
+        pj = None if params is None else json.dumps(params).encode()
+        self.h = lib().mh_create_node(plugin.h, pj, err, 4096)
+        if not self.h:
+            raise RuntimeError(err.value.decode(errors="replace"))
+
+    def process_audio(self, samples, rate=16000, channels=1):
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        return lib().mh_process_audio(self.h, s.ctypes.data, s.size, rate, channels)
+
+    def process_text(self, text):
+        return lib().mh_process_text(self.h, text.encode())
+
+    def process_null(self):
+        return lib().mh_process_null(self.h)
+
+    def update_params(self, params):
+        return lib().mh_update_params(self.h, None if params is None else json.dumps(params).encode())
+
+    def flush(self):
+        return lib().mh_flush(self.h)
+
+    def outputs(self):
+        out = []
+        for i in range(lib().mh_output_count(self.h)):
+            n = C.c_size_t()
+            p = lib().mh_output_payload(self.h, i, C.byref(n))
+            out.append((lib().mh_output_pin(self.h, i).decode(), lib().mh_output_type(self.h, i), C.string_at(p, n.value)))
+        return out
+
+    def telemetry(self):
+        return [(lib().mh_telemetry_type(self.h, i).decode(), json.loads(lib().mh_telemetry_json(self.h, i).decode()))
+                for i in range(lib().mh_telemetry_count(self.h))]
+
+    def logs(self):
+        return [lib().mh_log(self.h, i).decode(errors="replace") for i in range(lib().mh_log_count(self.h))]
+
+    def last_error(self):
+        return lib().mh_last_error(self.h).decode(errors="replace")
+
+    def destroy(self):
+        if self.h:
+            lib().mh_destroy_node(self.h)
+            self.h = None
+
+
+class Resampler:
+    def __init__(self, target, chunk_frames=960, output_frame_size=960):
+        err = C.create_string_buffer(512)
+        self.h = lib().mh_resampler_new(target, chunk_frames, output_frame_size, err, 512)
+        if not self.h:
+            raise ValueError(err.value.decode())
+
+    def push(self, samples, rate, channels, ts=None):
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        rc = lib().mh_resampler_push(self.h, s.ctypes.data, s.size, rate, channels, 0 if ts is None else 1, 0 if ts is None else ts)
+        if rc != 0:
+            raise RuntimeError(lib().mh_resampler_error(self.h).decode())
+
+    def finish(self):
+        lib().mh_resampler_finish(self.h)
+
+    def packets(self, clear=True):
+        out = []
+        for i in range(lib().mh_resampler_out_count(self.h)):
+            n = C.c_size_t(); ts = C.c_uint64(); has = C.c_int(); dur = C.c_uint64(); seq = C.c_uint64()
+            p = lib().mh_resampler_out(self.h, i, C.byref(n), C.byref(ts), C.byref(has), C.byref(dur), C.byref(seq))
+            out.append(dict(samples=np.ctypeslib.as_array(p, shape=(n.value,)).copy(), timestamp_us=ts.value if has.value else None, duration_us=dur.value, sequence=seq.value))
+        if clear:
+            lib().mh_resampler_clear(self.h)
+        return out
+
+
+def segment_sim(prob, threshold=0.5, min_silence_ms=700, max_secs=30.0, max_cuts=256):
+    prob = np.ascontiguousarray(prob, dtype=np.float32)
+    cuts = np.zeros((max_cuts, 6), dtype=np.int64)
+    n = lib().mh_segment_sim(prob.ctypes.data, prob.size, threshold, min_silence_ms, max_secs, cuts.ctypes.data, max_cuts)
+    return cuts[:min(n, max_cuts)].tolist()

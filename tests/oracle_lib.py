@@ -64,6 +64,7 @@ def lib():
         L.skwo_resampler_new.argtypes = [C.c_double, C.c_int, C.c_int]
         L.skwo_resampler_free.argtypes = [C.c_void_p]
         L.skwo_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.skwo_segment_sim.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_void_p, C.c_int]
         L.skwo_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         L.skwo_debug_enable.argtypes = [C.c_int]
         L.skwo_debug_get.restype = C.c_long
@@ -181,3 +182,26 @@ def debug_get(name):
     out = np.empty(n, dtype=np.float32)
     lib().skwo_debug_get(name.encode(), out.ctypes.data, n)
     return out
+
+
+def segment_sim(prob, threshold=0.5, min_silence_ms=700, max_secs=30.0, max_cuts=256):
+    prob = np.ascontiguousarray(prob, dtype=np.float32)
+    cuts = np.zeros((max_cuts, 6), dtype=np.int64)
+    n = lib().skwo_segment_sim(prob.ctypes.data, prob.size, threshold, min_silence_ms, max_secs, cuts.ctypes.data, max_cuts)
+    return cuts[:min(n, max_cuts)].tolist()
+
+
+class OracleResampler:
+    """rubato FastFixedIn<f32>/Linear restatement (planar in, planar out)."""
+
+    def __init__(self, ratio, chunk_frames, channels):
+        self.h = lib().skwo_resampler_new(ratio, chunk_frames, channels)
+        self.chunk, self.ch = chunk_frames, channels
+
+    def process(self, planar):
+        planar = np.ascontiguousarray(planar, dtype=np.float32).reshape(self.ch, self.chunk)
+        cap = self.chunk * 4 + 64
+        out = np.zeros((self.ch, cap), dtype=np.float32)
+        n = lib().skwo_resampler_process(self.h, planar.ctypes.data, out.ctypes.data, cap)
+        assert n >= 0
+        return out[:, :n].copy()

@@ -1,0 +1,109 @@
+"""CPU tests: behaviour that the reference SOURCE pins by itself (SURVEY.md §8c last row) — segmentation arithmetic,
+resampler packetisation/lengths, JSON wire shapes — checked on the oracle AND on the product's host-side C++ (same inputs)."""
+import json
+
+import numpy as np
+import pytest
+
+import minihost
+import oracle_lib
+
+GOLD = json.load(open(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "segmentation_goldens.json")))
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_segmentation_goldens(built, impl):
+    sim = oracle_lib.segment_sim if impl == "oracle" else minihost.segment_sim
+    for case in GOLD["cases"]:
+        prob = np.zeros(case["n_frames"], dtype=np.float32)
+        for a, b in case["speech_runs"]:
+            prob[a:b] = 1.0
+        cuts = sim(prob, case.get("threshold", 0.5), case.get("min_silence_ms", 700), case.get("max_secs", 30.0))
+        assert [c[:5] for c in cuts] == case["cuts"], case["name"]
+
+
+def test_segmentation_forced_cut_is_939_frames(built):
+    # lib.rs:455-465 + :487: the cut fires when 32*n >= max_ms BEFORE the increment -> 939 frames = 480768 samples = 30.048 s
+    cuts = oracle_lib.segment_sim(np.ones(2000, dtype=np.float32))
+    assert cuts[0][:4] == [0, 30048, 939 * 512, 0] and cuts[0][5] == 938
+    assert cuts[1][:4] == [30048, 60096, 939 * 512, 0]
+
+
+def test_segmenter_product_equals_oracle_random(built):
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        n = int(rng.integers(50, 4000))
+        # piecewise-constant speech/silence with random run lengths
+        prob = np.zeros(n, dtype=np.float32); i = 0; state = rng.random() < 0.5
+        while i < n:
+            run = int(rng.integers(1, 400)); prob[i:i + run] = rng.random() * 0.5 + (0.5 if state else 0.0); i += run; state = not state
+        thr = float(rng.choice([0.3, 0.5, 0.7])); ms = int(rng.choice([100, 320, 700, 1000, 5000])); mx = float(rng.choice([5.0, 12.5, 30.0, 120.0]))
+        assert oracle_lib.segment_sim(prob, thr, ms, mx) == minihost.segment_sim(prob, thr, ms, mx)
+
+
+def test_resampler_reference_length_golden(built):
+    # resampler.rs:816-837: 960 interleaved stereo samples (480 frames) 48k->24k, chunk_frames 960, output_frame_size 0
+    # -> remainder path with a fresh FastFixedIn(480 frames): |len - 480| < 10, rate/channels preserved
+    r = minihost.Resampler(24000, 960, 0)
+    r.push(np.full(960, 0.5, dtype=np.float32), 48000, 2)
+    r.finish()
+    pk = r.packets()
+    assert len(pk) == 1 and abs(pk[0]["samples"].size - 480) < 10
+    assert np.allclose(pk[0]["samples"][8:], 0.5)   # linear interpolation of a constant (after the zero history) is that constant
+
+
+def test_resampler_48k_to_16k_steady_state_and_packets(built):
+    # R1 + R4: chunk 960 @48 kHz mono -> 318 frames from the first chunk, 320 afterwards; emitted as exact 960-sample packets,
+    # duration_us = frames*1e6/rate (integer), running timestamp, sequence 0,1,2...
+    x = np.sin(np.arange(48000 * 2) * 0.01).astype(np.float32)
+    r = minihost.Resampler(16000, 960, 960)
+    for i in range(0, x.size, 1920):
+        r.push(x[i:i + 1920], 48000, 1, ts=1000 if i == 0 else None)
+    r.finish()
+    pk = r.packets()
+    total = sum(p["samples"].size for p in pk)
+    assert total == 318 + 320 * 99
+    assert all(p["samples"].size == 960 for p in pk[:-1]) and pk[-1]["samples"].size == total - 960 * (len(pk) - 1)
+    assert [p["sequence"] for p in pk] == list(range(len(pk)))
+    assert pk[0]["duration_us"] == 60000 and pk[0]["timestamp_us"] == 1000 and pk[1]["timestamp_us"] == 61000
+    # sample values: product C++ node == oracle restatement == plain numpy lerp on the delayed index grid
+    orc = oracle_lib.OracleResampler(16000 / 48000, 960, 1)
+    ref = np.concatenate([orc.process(x[i:i + 960])[0] for i in range(0, x.size, 960)])
+    got = np.concatenate([p["samples"] for p in pk])
+    assert np.array_equal(got, ref)
+    idx = -4.0 + 3.0 * (1 + np.arange(ref.size)); k = np.floor(idx).astype(int); frac = (idx - k).astype(np.float32)
+    xp = np.concatenate([np.zeros(16, np.float32), x])
+    lerp = (1.0 - frac) * xp[k + 16] + frac * xp[k + 17]
+    assert np.allclose(ref, lerp, atol=1e-6)
+
+
+def test_resampler_passthrough_rechunks_wav_frames(built):
+    # config 1: 16 kHz WAV demuxed in 1920-sample frames (wav.rs:34) -> R2 re-chunks to 960-sample packets, samples untouched
+    x = np.arange(1920 * 5 + 100, dtype=np.float32)
+    r = minihost.Resampler(16000, 960, 960)
+    for i in range(0, x.size, 1920):
+        r.push(x[i:i + 1920], 16000, 1)
+    r.finish()
+    pk = r.packets()
+    assert np.array_equal(np.concatenate([p["samples"] for p in pk]), x)
+    assert [p["samples"].size for p in pk] == [960] * 10 + [100]
+
+
+def test_resampler_config_validation(built):
+    with pytest.raises(ValueError):
+        minihost.Resampler(0)
+    with pytest.raises(ValueError):
+        minihost.Resampler(16000, 960, 1000)
+    r = minihost.Resampler(16000, 960, 960)
+    r.push(np.zeros(960, np.float32), 48000, 1)
+    with pytest.raises(RuntimeError, match="Audio format changed mid-stream"):
+        r.push(np.zeros(960, np.float32), 44100, 1)
+
+
+def test_json_helpers_match_serde_shapes(built):
+    L = minihost.lib()
+    assert L.mh_json_quote('a"b\\c\n\t\x01é'.encode()).decode() == '"a\\"b\\\\c\\n\\t\\u0001é"'
+    assert L.mh_json_f32(0.5) == b"0.5" and L.mh_json_f32(1.0) == b"1.0"
+    assert float(L.mh_json_f32(np.float32(0.7))) == float(np.float32(0.7))
+    assert L.mh_utf8_trim(" \t hello world 　".encode()).decode() == "hello world"
+    assert L.mh_utf8_valid(b"ok \xe2\x99\xaa", 6) == 1 and L.mh_utf8_valid(b"\xe2\x99", 2) == 0

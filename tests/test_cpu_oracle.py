@@ -1,0 +1,163 @@
+"""CPU tests that pin the ORACLE: against independent restatements (numpy float64 mel, HF Whisper fp32), against the
+committed golden vectors, and for internal consistency.  (No reference output exists for this path: parity unpinned,
+see oracle/skw_oracle.h.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from ggml_reader import read_ggml
+from streamkit_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _ulp_diff(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def test_expf_logf_accuracy(oracle_micro):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([-rng.random(200000) * 85.9, rng.random(50000) * 80.0, -np.exp(rng.normal(0, 3, 100000))]).astype(np.float32)
+    x = x[x >= -86.0]
+    got = oracle_micro.math(0, x)
+    ref = np.exp(x.astype(np.float64)).astype(np.float32)
+    assert _ulp_diff(got, ref).max() <= 2
+    assert np.all(oracle_micro.math(0, np.array([-86.5, -1000.0, -np.inf], np.float32)) == 0.0)
+    y = np.exp(rng.normal(0, 15, 300000)).astype(np.float32)
+    y = y[(y > 1e-37) & np.isfinite(y)]
+    assert _ulp_diff(oracle_micro.math(1, y), np.log(y.astype(np.float64)).astype(np.float32)).max() <= 2
+    # monotone where it matters (softmax ordering)
+    xs = np.sort(x); e = oracle_micro.math(0, xs)
+    assert np.all(np.diff(e) >= 0)
+
+
+def test_f16_rounding_is_ieee_rne(oracle_micro):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(0, 1, 200000), rng.normal(0, 1e-5, 100000), rng.normal(0, 3e4, 50000),
+                        np.float16(np.arange(0, 65504, 7.25)).astype(np.float64) + 2.0 ** -14]).astype(np.float32)
+    h = np.arange(0x0000, 0x7bff, dtype=np.uint16).view(np.float16).astype(np.float32)
+    ties = (h[:-1].astype(np.float64) + h[1:].astype(np.float64)) / 2     # exact midpoints are representable in f32
+    x = np.concatenate([x, ties.astype(np.float32), -ties.astype(np.float32)])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    got = oracle_micro.math(3, x)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def _numpy_mel(pcm, filters):
+    """whisper.cpp's log_mel_spectrogram semantics with an exact float64 DFT (independent of the oracle's fp32 FFT)."""
+    n = pcm.size
+    padded = np.zeros(n + 480000 + 400, dtype=np.float64)
+    padded[200:200 + n] = pcm
+    padded[:200] = pcm[200:0:-1]
+    n_len = (padded.size - 400) // 160
+    n_calc = min((n + 200) // 160 + 1, n_len)
+    hann = (0.5 * (1.0 - np.cos(2.0 * np.pi * np.arange(400) / 400))).astype(np.float32).astype(np.float64)
+    idx = np.arange(n_calc)[:, None] * 160 + np.arange(400)[None, :]
+    fr = padded[idx] * hann
+    p = np.abs(np.fft.rfft(fr, axis=1)) ** 2
+    mel = np.full((filters.shape[0], n_len), -10.0)
+    mel[:, :n_calc] = np.log10(np.maximum(filters.astype(np.float64) @ p.T, 1e-10))
+    mel = np.maximum(mel, mel.max() - 8.0)
+    return ((mel + 4.0) / 4.0).astype(np.float32), 1 + (n + 200 - 400) // 160
+
+
+@pytest.mark.parametrize("n_samples", [480000, 16000 * 3 + 77, 480768])
+def test_mel_against_float64_restatement(oracle_micro, micro_model_path, n_samples):
+    _, filters, _, _ = read_ggml(micro_model_path)
+    pcm = synth.clip(5, n_samples)
+    mel, n_org = oracle_micro.log_mel(pcm)
+    ref, ref_org = _numpy_mel(pcm, filters)
+    assert mel.shape == ref.shape and n_org == ref_org
+    assert np.abs(mel - ref).max() < 1e-4          # north_star tolerance for mel frames
+
+
+def test_mel_frame_counts(oracle_micro):
+    # 30 s -> 6000 frames / n_len_org 2999; the plugin's forced cut hands over 30.048 s -> 6004 / 3004
+    for n, n_len, n_org in [(480000, 6000, 2999), (480768, 6004, 3004), (16000, 3100, 99)]:
+        mel, org = oracle_micro.log_mel(np.zeros(n, np.float32) + 0.01)
+        assert mel.shape[1] == n_len and org == n_org
+
+
+def test_short_input_returns_no_segments(oracle_micro):
+    r = oracle_micro.full(synth.clip(0, 15000))      # < 1 s -> n_len_org 94 < 100: "input is too short"
+    assert r["segments"] == [] and r["n_windows"] == 0
+
+
+def test_decoder_prompt_batching_is_exact(oracle_micro):
+    pcm = synth.clip(1, 16000 * 5)
+    mel, _ = oracle_micro.log_mel(pcm)
+    _, ck, cv = oracle_micro.encode(mel)
+    d1 = oracle_micro.decoder(ck, cv); a = d1.step([50258, 50259, 50359, 50364, 100], 0)
+    d2 = oracle_micro.decoder(ck, cv); d2.step([50258], 0); d2.step([50259, 50359], 1); d2.step([50364], 3); b = d2.step([100], 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_golden_tokens(oracle_micro):
+    gold = json.load(open(os.path.join(HERE, "golden", "oracle_micro_seed1234.json")))
+    p = oracle_micro.default_params(); p.suppress_nst = 1
+    for case in gold["cases"]:
+        r = oracle_micro.full(synth.clip(case["clip"], case["n_samples"]), p)
+        assert [t[0] for t in r["tokens"]] == case["tokens"], case
+        assert [[s["t0"], s["t1"], s["text"].decode()] for s in r["segments"]] == case["segments"]
+        assert r["n_windows"] == case["n_windows"] and r["fallback_requested"] == case["fallback_requested"]
+
+
+def test_hf_whisper_crosscheck(tiny_model_path, oracle_tiny):
+    """Independent implementation check of the ARCHITECTURE (conv stem, attention scaling, LN eps, K without bias, tied
+    logits): HF transformers' Whisper in fp32 with the same weights.  HF uses exact-erf GELU and fp32 activations where
+    ggml uses the f16 tanh-GELU table and f16-rounded matmul operands, so agreement is to ~1e-2, not bitwise."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    hp, _, _, T = read_ggml(tiny_model_path)
+    cfg = tr.WhisperConfig(vocab_size=hp["n_vocab"], num_mel_bins=hp["n_mels"], d_model=hp["n_audio_state"], encoder_layers=hp["n_audio_layer"],
+                           decoder_layers=hp["n_text_layer"], encoder_attention_heads=hp["n_audio_head"], decoder_attention_heads=hp["n_text_head"],
+                           encoder_ffn_dim=4 * hp["n_audio_state"], decoder_ffn_dim=4 * hp["n_text_state"], max_source_positions=hp["n_audio_ctx"],
+                           max_target_positions=hp["n_text_ctx"], activation_function="gelu_new" if False else "gelu", pad_token_id=50257, bos_token_id=50257,
+                           eos_token_id=50257, decoder_start_token_id=50258)
+    model = tr.WhisperModel(cfg).eval().float()
+    sd = {}
+    t = lambda n: torch.from_numpy(T[n].astype(np.float32))
+    sd["encoder.conv1.weight"] = t("encoder.conv1.weight"); sd["encoder.conv1.bias"] = t("encoder.conv1.bias").reshape(-1)
+    sd["encoder.conv2.weight"] = t("encoder.conv2.weight"); sd["encoder.conv2.bias"] = t("encoder.conv2.bias").reshape(-1)
+    sd["encoder.embed_positions.weight"] = t("encoder.positional_embedding")
+    sd["encoder.layer_norm.weight"] = t("encoder.ln_post.weight"); sd["encoder.layer_norm.bias"] = t("encoder.ln_post.bias")
+    sd["decoder.embed_tokens.weight"] = t("decoder.token_embedding.weight"); sd["decoder.embed_positions.weight"] = t("decoder.positional_embedding")
+    sd["decoder.layer_norm.weight"] = t("decoder.ln.weight"); sd["decoder.layer_norm.bias"] = t("decoder.ln.bias")
+    def blk(src, dst, cross):
+        m = {"attn_ln": "self_attn_layer_norm", "attn.query": "self_attn.q_proj", "attn.key": "self_attn.k_proj", "attn.value": "self_attn.v_proj", "attn.out": "self_attn.out_proj",
+             "mlp_ln": "final_layer_norm", "mlp.0": "fc1", "mlp.2": "fc2"}
+        if cross:
+            m.update({"cross_attn_ln": "encoder_attn_layer_norm", "cross_attn.query": "encoder_attn.q_proj", "cross_attn.key": "encoder_attn.k_proj", "cross_attn.value": "encoder_attn.v_proj", "cross_attn.out": "encoder_attn.out_proj"})
+        for a, b in m.items():
+            sd[dst + b + ".weight"] = t(src + a + ".weight")
+            if src + a + ".bias" in T:
+                sd[dst + b + ".bias"] = t(src + a + ".bias")
+    for l in range(hp["n_audio_layer"]):
+        blk("encoder.blocks.%d." % l, "encoder.layers.%d." % l, False)
+    for l in range(hp["n_text_layer"]):
+        blk("decoder.blocks.%d." % l, "decoder.layers.%d." % l, True)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("k_proj.bias") for k in missing), (missing, unexpected)   # whisper has no key bias
+    for k in missing:
+        model.state_dict()[k].zero_()
+    pcm = synth.clip(2, 480000)
+    mel, _ = oracle_tiny.log_mel(pcm)
+    enc_o, ck, cv = oracle_tiny.encode(mel)
+    with torch.no_grad():
+        feats = torch.from_numpy(mel[:, :3000]).unsqueeze(0)
+        enc_h = model.encoder(feats).last_hidden_state[0].numpy()
+        toks = torch.tensor([[50258, 50259, 50359, 50364, 1234]])
+        dec_h = model.decoder(input_ids=toks, encoder_hidden_states=torch.from_numpy(enc_h).unsqueeze(0)).last_hidden_state[0, -1]
+        logits_h = (dec_h @ model.decoder.embed_tokens.weight.T).numpy()
+    rel = np.abs(enc_h - enc_o).max() / np.abs(enc_h).max()
+    assert rel < 3e-2, rel
+    d = oracle_tiny.decoder(ck, cv)
+    logits_o = d.step([50258, 50259, 50359, 50364, 1234], 0)
+    sig = logits_h.std()
+    assert np.abs(logits_h - logits_o).max() < 0.1 * sig, (np.abs(logits_h - logits_o).max(), sig)
+    assert np.corrcoef(logits_h, logits_o)[0, 1] > 0.999

@@ -1,0 +1,142 @@
+"""GPU tests of the drop-in boundary: libwhisper.so driven through the StreamKit native-plugin C ABI by the C++ mini-host,
+replaying the reference host's call sequence (wrapper.rs) and the config-1 node chain around it."""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+import minihost
+import oracle_lib
+from oracle_lib import OracleModel
+from streamkit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def plugin():
+    return minihost.Plugin()
+
+
+def _expected_transcription(om, pcm_segment, start_ms, language="en"):
+    """What lib.rs:648-695 builds from whisper.cpp's segments, computed from the oracle's full()."""
+    po = om.default_params(); po.suppress_nst = 1
+    r = om.full(pcm_segment, po)
+    segs = []
+    for s in r["segments"]:
+        text = s["text"].decode().strip()
+        if text:
+            segs.append({"text": text, "start_time_ms": start_ms + s["t0"] * 10, "end_time_ms": start_ms + s["t1"] * 10, "confidence": None})
+    return {"text": " ".join(s["text"] for s in segs), "segments": segs, "language": language, "metadata": None} if segs else None
+
+
+def _feed(node, pcm, packet=960):
+    for i in range(0, pcm.size, packet):
+        assert node.process_audio(pcm[i:i + packet]) == 0, node.last_error()
+
+
+def test_oneshot_forced_cut_matches_oracle(plugin, tiny_model_path):
+    om = OracleModel(tiny_model_path)
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "emit_vad_events": True})
+    pcm = np.concatenate([synth.clip(0), synth.clip(1, 16000 * 3)])          # 33 s: one forced cut at 939 frames, tail dropped
+    _feed(node, pcm)
+    assert node.flush() == 0
+    outs = node.outputs()
+    assert len(outs) == 1 and outs[0][0] == "out" and outs[0][1] == 3       # one Transcription packet on pin "out"
+    got = json.loads(outs[0][2].decode())
+    assert list(got.keys()) == ["text", "segments", "language", "metadata"]  # serde field order (crates/core/src/types.rs:166-175)
+    assert got == _expected_transcription(om, pcm[:939 * 512], 0)
+    tel = node.telemetry()
+    assert [t[0] for t in tel] == ["vad.speech_start", "vad.speech_end", "vad.speech_start"]
+    assert tel[0][1] == {"segment_id": "seg-0-1", "speech_probability": 1.0, "start_time_ms": 0, "threshold": 0.5}
+    assert tel[1][1] == {"duration_ms": 30048, "end_time_ms": 30048, "reason": "max_duration", "segment_id": "seg-0-1", "silence_duration_ms": None, "start_time_ms": 0}
+    assert tel[2][1]["segment_id"] == "seg-30048-2"
+    node.destroy()
+
+
+def test_energy_vad_silence_cut_and_absolute_timestamps(plugin, tiny_model_path):
+    om = OracleModel(tiny_model_path)
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "energy", "min_silence_duration_ms": 320})
+    speech = synth.clip(2, 512 * 150)                                       # 150 frames of "speech" (rms >> 0.01)
+    pcm = np.concatenate([np.zeros(512 * 20, np.float32), speech, np.zeros(512 * 30, np.float32)])
+    _feed(node, pcm, packet=1000)                                           # packet size not aligned with the 512 framing
+    outs = node.outputs()
+    assert len(outs) == 1
+    got = json.loads(outs[0][2].decode())
+    # which frames pass the energy gate is decided by the product's VAD; the oracle then sees exactly those samples
+    frames = speech.reshape(150, 512)
+    rms = np.sqrt((frames.astype(np.float32) ** 2).sum(axis=1) / 512.0)
+    keep = (rms / (rms + 0.01)) >= 0.5
+    assert keep.all()
+    assert got == _expected_transcription(om, speech, 20 * 32)
+    assert node.outputs()[0][2] == outs[0][2]
+    node.destroy()
+
+
+def test_error_paths_match_reference_messages(plugin, tiny_model_path):
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always"})
+    assert node.process_text("hello") == -1 and node.last_error() == "Whisper plugin only accepts audio packets"          # lib.rs:492
+    assert node.process_null() == -1 and node.last_error() == "(null message)"                                            # sdk lib.rs:731-733
+    n2 = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always"})
+    assert n2.process_audio(np.zeros(960, np.float32), 48000, 1) == -1
+    assert n2.last_error() == "Whisper requires 16kHz audio, got 48000Hz. Please add an audio_resample node upstream."    # lib.rs:185-187
+    n3 = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always"})
+    assert n3.process_audio(np.zeros(960, np.float32), 16000, 2) == -1
+    assert n3.last_error() == "Whisper requires mono audio, got 2 channels. Please add an audio_resample node upstream."  # lib.rs:191-193
+    with pytest.raises(RuntimeError, match="Failed to load Whisper model"):
+        plugin.create_node({"model_path": "/nonexistent/ggml-small.bin"})
+    assert node.update_params({"model_path": tiny_model_path, "vad_mode": "always", "min_silence_duration_ms": 100}) == 0
+    assert node.update_params({"model_path": "/nonexistent.bin"}) == -1 and "Failed to reload Whisper model" in node.last_error()
+    for n in (node, n2, n3):
+        n.destroy()
+
+
+def test_flush_drops_tail_by_default_and_flush_tail_is_additive(plugin, tiny_model_path):
+    om = OracleModel(tiny_model_path)
+    pcm = synth.clip(4, 16000 * 6)
+    a = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always"})
+    _feed(a, pcm); assert a.flush() == 0 and a.outputs() == []               # reference behaviour: no flush override
+    b = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True})
+    _feed(b, pcm); assert b.flush() == 0
+    outs = b.outputs()
+    assert len(outs) == 1 and json.loads(outs[0][2].decode()) == _expected_transcription(om, pcm[:(pcm.size // 512) * 512], 0)
+    a.destroy(); b.destroy()
+
+
+def test_concurrent_instances_share_the_model_and_batch(plugin, tiny_model_path):
+    """many instances on different OS threads (wrapper.rs:398) -> the per-GPU scheduler batches them; results must equal the serial ones"""
+    clips = [np.concatenate([synth.clip(c), np.zeros(1024, np.float32)]) for c in range(6)]
+    def run(params):
+        nodes = [plugin.create_node(params) for _ in clips]
+        ths = [threading.Thread(target=_feed, args=(n, c, 1920)) for n, c in zip(nodes, clips)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        outs = [[o[2] for o in n.outputs()] for n in nodes]
+        [n.destroy() for n in nodes]
+        return outs
+    par = run({"model_path": tiny_model_path, "vad_mode": "always", "batch_window_ms": 50})
+    ser = run({"model_path": tiny_model_path, "vad_mode": "always", "batch_window_ms": 0, "max_batch": 1})
+    assert par == ser and all(len(o) == 1 for o in par)
+
+
+def test_config1_node_chain(plugin, tiny_model_path):
+    """BASELINE configs[0]: 16 kHz WAV -> 1920-sample demux frames -> audio::resampler (pass-through, 960-sample packets)
+    -> whisper -> core::json_serialize NDJSON (externally tagged packet)."""
+    om = OracleModel(tiny_model_path)
+    pcm = np.concatenate([synth.clip(8), synth.clip(9, 16000 * 2)])
+    rs = minihost.Resampler(16000, 960, 960)
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "language": "en"})
+    for i in range(0, pcm.size, 1920):
+        rs.push(pcm[i:i + 1920], 16000, 1)
+        for pk in rs.packets():
+            assert pk["samples"].size == 960
+            assert node.process_audio(pk["samples"]) == 0
+    rs.finish()
+    for pk in rs.packets():
+        assert node.process_audio(pk["samples"]) == 0
+    node.flush()
+    ndjson = b"".join(b'{"Transcription":' + o[2] + b"}\n" for o in node.outputs())
+    lines = ndjson.splitlines()
+    assert len(lines) == 1
+    assert json.loads(lines[0])["Transcription"] == _expected_transcription(om, pcm[:939 * 512], 0)
+    node.destroy()
