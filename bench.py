@@ -119,16 +119,22 @@ def main():
         ctx.profile(False)
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         name, p = dom
+        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_launch_bytes"]
+            traffic = pt[name]["total"] if name in pt else None
+        except Exception:
+            traffic = None
         kern = {k: {"launches": v["count"], "ms": round(v["ms"], 3)} for k, v in prof.items() if v["count"]}
         if name in ("k_gemm", "k_gemm_smallm", "k_attn_encoder"):
             ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern}
         else:
             ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

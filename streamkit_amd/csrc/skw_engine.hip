@@ -42,7 +42,7 @@ static void set_err(char* err, size_t n, const char* fmt, ...) {
 struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0; };
 struct DevLN { float* w = nullptr; float* b = nullptr; };
 struct EncLayer { DevLN attn_ln, mlp_ln; DevLin q, k, v, o, fc1, fc2; };
-struct DecLayer { DevLN attn_ln, cross_ln, mlp_ln; DevLin q, k, v, o, cq, ck, cv, co, fc1, fc2; };
+struct DecLayer { DevLN attn_ln, cross_ln, mlp_ln; DevLin q, k, v, o, cq, ck, cv, co, fc1, fc2; DevLin qkv; /* q|k|v rows concatenated for the fused decode projection */ };
 
 struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; };
 
@@ -224,6 +224,17 @@ extern "C" skw_model* skw_model_load(const char* path, int device, char* err, si
         ok = ok && up_ln(m, ts, p + "mlp_ln.weight", p + "mlp_ln.bias", &L.mlp_ln, err, errlen);
         ok = ok && up_lin(m, ts, p + "mlp.0.weight", (p + "mlp.0.bias").c_str(), &L.fc1, err, errlen);
         ok = ok && up_lin(m, ts, p + "mlp.2.weight", (p + "mlp.2.bias").c_str(), &L.fc2, err, errlen);
+        if (ok) {   // fused q|k|v weight [3d][k_pad] and bias [3d] (k has no bias: zeros; adding 0.0f is exact)
+            const int d = L.q.n_out, kp = L.q.k_pad; L.qkv.n_in = L.q.n_in; L.qkv.n_out = 3 * d; L.qkv.k_pad = kp;
+            half_t* w = nullptr; float* b = nullptr;
+            if (hipMalloc((void**)&w, (size_t)3 * d * kp * 2) != hipSuccess || hipMalloc((void**)&b, (size_t)3 * d * 4) != hipSuccess) { set_err(err, errlen, "device allocation failed"); ok = false; }
+            else {
+                m->allocs.push_back(w); m->allocs.push_back(b);
+                hipMemcpy(w, L.q.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)d * kp, L.k.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)2 * d * kp, L.v.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                hipMemset(b, 0, (size_t)3 * d * 4); hipMemcpy(b, L.q.b, (size_t)d * 4, hipMemcpyDeviceToDevice); hipMemcpy(b + 2 * d, L.v.b, (size_t)d * 4, hipMemcpyDeviceToDevice);
+                L.qkv.w = w; L.qkv.b = b;
+            }
+        }
     }
     if (!ok) return fail2();
     if ((m->hp.n_audio_state / m->hp.n_audio_head) != 64 || (m->hp.n_text_state / m->hp.n_text_head) != 64 || m->hp.n_audio_state % 64 || m->hp.n_audio_state > 1536) {
@@ -451,9 +462,8 @@ static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
         half_t* sk = c->selfK + (size_t)l * c->max_batch * ntc * dt; half_t* sv = c->selfV + (size_t)l * c->max_batch * ntc * dt;
         half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
         skw_layernorm(c->dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.q, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.k, Bw, sk + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.v, Bw, sv + (size_t)pos * dt, (long)ntc * dt, EPI_F16_PLAIN); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.qkv, Bw, c->dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
+          a.C2 = sk + (size_t)pos * dt; a.C3 = sv + (size_t)pos * dt; a.ldc2 = (long)ntc * dt; GEMM_S(c, a, a.K); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(c->dq16, sk, sv, &c->st[0].cur_pos, Bw, H, dt, ntc, c->datt16, s); }
         { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         skw_layernorm(c->dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, c->dy16, nullptr, s);

@@ -24,6 +24,7 @@ enum SkwEpi : int {
     EPI_HEADS_F16 = 4,  // Q/K for attention: C f16 [(b*H+h)*Tpad + i][kperm(d)], m=(b,i), n=(h,d); f16((acc+bias)*scale)
     EPI_VT_F16 = 5,     // swapped call (m = feature, n = token): C f16 [(b*H+h)*64 + c][kperm(key)] (row stride Tpad); f16(acc + bias[m])
     EPI_F16_PLAIN = 6,  // C f16 [m][n] = f16((acc + bias[n]) * scale)   (decoder K/V caches, cross K/V)
+    EPI_DEC_QKV = 8,    // fused decoder q|k|v: see epilogue (C = q plain, C2/C3 = K/V cache rows, n_ctx = d)
     EPI_GELU_F16_KPERM_ROWPAD = 7, // conv1: like 2 but row index remapped m -> (m / T) * (T + 2) + (m % T) + 1 (one zero row of padding per clip side)
 };
 
@@ -33,6 +34,7 @@ struct SkwGemmArgs {
     const half_t* W; long ldw;      // [N][K] f16, K axis kperm'ed
     int M, N, K;                    // K multiple of 32 (zero padded by the producer)
     void* C; long ldc;
+    void* C2; void* C3; long ldc2;   // EPI_DEC_QKV
     const float* bias;              // may be null
     const float* res; long ldres;   // EPI_F32 residual (may be null; may alias C)
     float scale;                    // EPI_F16*/HEADS (1.0f = none; multiply is skipped when has_scale == 0)

@@ -61,6 +61,14 @@ __device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, fl
         if (a.bias) v = v + a.bias[m];
         int b = n / a.n_ctx, key = n % a.n_ctx, h = m >> 6, c = m & 63;
         ((half_t*)a.C)[((long)(b * a.H + h) * 64 + c) * a.Tpad + skw_kperm(key)] = f2h(v);
+    } else if (EPI == EPI_DEC_QKV) {
+        // fused decoder Q|K|V projection: n in [0,d) -> q (plain, +bias, *scale); [d,2d) -> K cache (*scale); [2d,3d) -> V cache (+bias)
+        const int d = a.n_ctx;
+        if (a.bias) v = v + a.bias[n];
+        if (n < 2 * d) v = v * a.scale;
+        if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+        else if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + (n - d)] = f2h(v);
+        else ((half_t*)a.C3)[(long)m * a.ldc2 + (n - 2 * d)] = f2h(v);
     } else if (EPI == EPI_F16_PLAIN) {
         if (a.bias) v = v + a.bias[n];
         if (a.has_scale) v = v * a.scale;
@@ -152,10 +160,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm(SkwGemmArgs a) {
 // advances at the MFMA's dependent latency (40 cycles per 4 k) instead of being shared between row tiles, and a ring
 // of SM_DEPTH k-blocks of fragments (16 B per lane per operand per block) is kept in flight straight from global
 // memory to hide HBM latency.  The 4 waves of a block are the 4 row tiles of one strip (W lines shared through L1/L2).
-#define SM_DEPTH 8
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 union H8v { u32x4 v; half_t h[8]; };
-template <int EPI>
+template <int EPI, int SM_DEPTH>
 __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16, mt = blockIdx.y * 4 + wave;
@@ -214,7 +221,10 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s) {
 }
 template <int EPI> static void launch_gemm_small(const SkwGemmArgs& a, hipStream_t s) {
     dim3 grid((a.N + 15) / 16, (a.M + 63) / 64);
-    hipLaunchKernelGGL((k_gemm_smallm<EPI>), grid, dim3(256), 0, s, a);
+    const int nk = a.K >> 5;
+    // K = 768-class contractions keep the whole operand strip in flight (24 blocks = 192 VGPRs); others use an 8-deep ring
+    if (nk % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm<EPI, 24>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_smallm<EPI, 8>), grid, dim3(256), 0, s, a);
 }
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
     switch (a.epi) {
@@ -222,6 +232,7 @@ void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
         case EPI_F16_KPERM: launch_gemm_small<EPI_F16_KPERM>(a, s); break;
         case EPI_GELU_F16_KPERM: launch_gemm_small<EPI_GELU_F16_KPERM>(a, s); break;
         case EPI_F16_PLAIN: launch_gemm_small<EPI_F16_PLAIN>(a, s); break;
+        case EPI_DEC_QKV: launch_gemm_small<EPI_DEC_QKV>(a, s); break;
         default: break;
     }
 }
