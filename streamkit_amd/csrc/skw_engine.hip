@@ -384,7 +384,12 @@ extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_
 // algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
 static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical; *by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
 static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by); skw_gemm(a, c->stream); }
-static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by); skw_gemm_smallm(a, c->stream); }
+static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
+    double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by);
+    // (a VALU row-parallel variant — lane = batch row, v_fma_mix chains — was measured slower: a dependent v_fma costs 8-10 cycles
+    //  on gfx950, no better than the MFMA's 40 cycles per 4 k)
+    skw_gemm_smallm(a, c->stream);
+}
 
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
     SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
