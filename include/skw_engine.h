@@ -112,6 +112,20 @@ int skw_encode(skw_ctx*, const float* pcm_host, int n_samples, int seek, float* 
 /* K7-K10: after skw_encode, run the decoder on tokens[0..n) from position 0 and return the last token's logits [n_vocab] */
 int skw_decode_logits(skw_ctx*, const int32_t* tokens, int n_tokens, float* logits);
 
+/* ---- resampler front end: the arithmetic of the reference's audio::resampler node on the GPU ----
+ * reference: crates/nodes/src/audio/filters/resampler.rs:231-244 (FastFixedIn::new(ratio, 1.0, Linear, chunk_frames, channels)),
+ *            :384-514 (per-chunk process), :543-688 (remainder with a fresh resampler). */
+typedef struct skw_dsp skw_dsp;                 /* model-free device context (stream + scratch) */
+skw_dsp* skw_dsp_create(int device, char* err, size_t errlen);
+void skw_dsp_free(skw_dsp*);
+const char* skw_dsp_last_error(const skw_dsp*);
+typedef struct { double last_index; double ratio; int32_t chunk_frames; int32_t channels; float hist[32]; } skw_resampler_state; /* rubato's carried state: fractional index + 16-frame history */
+void skw_resampler_init(skw_resampler_state*, double ratio /* out/in */, int chunk_frames, int channels);
+/* n_chunks full chunks of interleaved f32 input -> interleaved output (host pointers); bit-exact with rubato's Linear interpolation */
+int skw_resample_linear(skw_dsp*, skw_resampler_state*, const float* in, int n_chunks, float* out, int out_cap_frames, int* out_frames);
+/* additive quality mode: polyphase Kaiser-windowed sinc (32 taps/phase), whole buffer */
+int skw_resample_polyphase(skw_dsp*, const float* in, long n_in_frames, int channels, int in_rate, int out_rate, float* out, long out_cap_frames, long* out_frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -717,3 +717,75 @@ extern "C" int skw_debug_math(skw_ctx* c, int kind, const float* in, float* out,
     hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, kind, di, dout, n, c->m->gelu_tab);
     HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost)); hipFree(di); hipFree(dout); return 0;
 }
+
+// ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
+struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
+                 size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0; };
+extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
+    int ndev = skw_device_count();
+    if (ndev <= 0) { set_err(err, errlen, "no HIP device available: the resampler kernels require an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", device, ndev); return nullptr; }
+    skw_dsp* d = new skw_dsp(); d->device = device;
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&d->d_n, sizeof(int)) != hipSuccess || hipMalloc((void**)&d->d_li, sizeof(double)) != hipSuccess) { set_err(err, errlen, "device allocation failed"); delete d; return nullptr; }
+    return d;
+}
+extern "C" void skw_dsp_free(skw_dsp* d) { if (!d) return; hipSetDevice(d->device); hipStreamSynchronize(d->stream); hipFree(d->d_in); hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); hipFree(d->d_coef); hipFree(d->d_n); hipFree(d->d_li); hipStreamDestroy(d->stream); delete d; }
+extern "C" const char* skw_dsp_last_error(const skw_dsp* d) { return d->errbuf; }
+static int dsp_reserve(skw_dsp* d, size_t n_in, size_t n_out) {
+    char* errbuf = d->errbuf;
+    if (n_in > d->cap_in) { hipFree(d->d_in); d->cap_in = n_in * 2; HIPCHK(hipMalloc((void**)&d->d_in, d->cap_in * sizeof(float))); }
+    if (n_out > d->cap_out) { hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); d->cap_out = n_out * 2; HIPCHK(hipMalloc((void**)&d->d_out, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_frac, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_pos, d->cap_out * sizeof(int))); }
+    return 0;
+}
+extern "C" void skw_resampler_init(skw_resampler_state* st, double ratio, int chunk_frames, int channels) {
+    memset(st, 0, sizeof *st); st->last_index = -4.0; st->ratio = ratio; st->chunk_frames = chunk_frames; st->channels = channels;   // -(POLYNOMIAL_LEN/2), zero history
+}
+// n_chunks full chunks of interleaved input -> interleaved output frames; state (history + fractional index) carried like rubato's
+extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const float* in, int n_chunks, float* out, int out_cap_frames, int* out_frames) {
+    char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device));
+    const int ch = st->channels, chunk = st->chunk_frames; *out_frames = 0;
+    if (ch < 1 || ch > 2 || chunk < 1 || n_chunks < 1 || (chunk < 16 && n_chunks != 1)) { snprintf(errbuf, 512, "resampler: unsupported geometry (channels %d, chunk_frames %d)", ch, chunk); return -1; }
+    const size_t n_in = (size_t)(16 + (size_t)n_chunks * chunk) * ch;
+    if (dsp_reserve(d, n_in, (size_t)out_cap_frames * ch)) return -1;
+    HIPCHK(hipMemcpyAsync(d->d_in, st->hist, sizeof(float) * 16 * ch, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->d_in + 16 * ch, in, sizeof(float) * (size_t)n_chunks * chunk * ch, hipMemcpyHostToDevice, d->stream));
+    skw_resample_linear_launch(d->d_in, ch, st->last_index, 1.0 / st->ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames, d->stream);
+    int n = 0; double li = 0;
+    HIPCHK(hipMemcpyAsync(&n, d->d_n, sizeof(int), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipMemcpyAsync(&li, d->d_li, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (n > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity %d too small for %d frames", out_cap_frames, n); return -1; }
+    HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n * ch, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    if ((size_t)n_chunks * chunk >= 16) memcpy(st->hist, in + ((size_t)n_chunks * chunk - 16) * ch, sizeof(float) * 16 * ch);   // buffer.copy_within(chunk.., 0)
+    st->last_index = li; *out_frames = n; return 0;
+}
+// quality mode: Kaiser-windowed sinc, 32 taps x decimation factor per phase, whole buffer at once (mono or interleaved stereo)
+extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_frames, int channels, int in_rate, int out_rate, float* out, long out_cap_frames, long* out_frames) {
+    char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device));
+    auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+    const long g = gcd(in_rate, out_rate); const int L = (int)(out_rate / g), M = (int)(in_rate / g);
+    if (L > 4096) { snprintf(errbuf, 512, "resampler: ratio %d/%d needs %d phases (> 4096)", out_rate, in_rate, L); return -1; }
+    const long n_out = (n_in_frames * L + M - 1) / M;
+    if (n_out > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity too small"); return -1; }
+    if (d->coef_L != L || d->coef_M != M) {
+        const int T = 32 * std::max(1, (M + L - 1) / L); std::vector<float> h((size_t)L * T);   // span 32 samples of the slower rate
+        const double fc = 0.5 * std::min(1.0, (double)L / M) * 0.90, beta = 8.6;   // cutoff (cycles per input sample), a little below Nyquist of the narrower side
+        auto bessel0 = [](double x) { double s = 1, t = 1; for (int k = 1; k < 40; ++k) { t *= (x / (2 * k)) * (x / (2 * k)); s += t; } return s; };
+        for (int ph = 0; ph < L; ++ph) {
+            double sum = 0; std::vector<double> row(T);
+            for (int t = 0; t < T; ++t) {
+                const double xpos = (double)(t - (T / 2 - 1)) - (double)ph / L;     // distance (in input samples) from the output instant
+                const double w = std::fabs(xpos) >= T / 2 ? 0.0 : bessel0(beta * std::sqrt(1.0 - (xpos / (T / 2)) * (xpos / (T / 2)))) / bessel0(beta);
+                const double arg = 2.0 * M_PI * fc * xpos; const double sinc = std::fabs(arg) < 1e-12 ? 1.0 : std::sin(arg) / arg;
+                row[t] = 2.0 * fc * sinc * w; sum += row[t];
+            }
+            for (int t = 0; t < T; ++t) h[(size_t)ph * T + t] = (float)(row[t] / sum);   // unity DC gain per phase
+        }
+        hipFree(d->d_coef); HIPCHK(hipMalloc((void**)&d->d_coef, h.size() * sizeof(float))); HIPCHK(hipMemcpy(d->d_coef, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        d->coef_L = L; d->coef_M = M;
+    }
+    if (dsp_reserve(d, (size_t)n_in_frames * channels, (size_t)n_out * channels)) return -1;
+    HIPCHK(hipMemcpyAsync(d->d_in, in, sizeof(float) * (size_t)n_in_frames * channels, hipMemcpyHostToDevice, d->stream));
+    skw_resample_polyphase_launch(d->d_in, n_in_frames, channels, d->d_coef, L, M, 32 * std::max(1, (M + L - 1) / L), d->d_out, n_out, d->stream);
+    HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n_out * channels, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    *out_frames = n_out; return 0;
+}

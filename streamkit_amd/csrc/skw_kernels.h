@@ -100,3 +100,8 @@ struct SkwLogitParams {
 // whisper_process_logits + whisper_sample_token(best) + the per-token state update of whisper_full_with_state.
 // logits: [B][n_vocab] (modified in place), static_mask: [n_vocab] bytes (1 = always suppressed: specials, langs, nst list when enabled)
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active, hipStream_t s);
+
+// ---------------- resampler (R1) ----------------
+void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
+                                float* out, int cap, hipStream_t s);
+void skw_resample_polyphase_launch(const float* in, long n_in, int channels, const float* coef, int L, int M, int T, float* out, long n_out, hipStream_t s);

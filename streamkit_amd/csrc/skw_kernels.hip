@@ -773,3 +773,55 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active);
 }
+
+// ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)
+// Restates /root/reference/crates/nodes/src/audio/filters/resampler.rs:231-244, 384-514 (rubato 0.16.2 asynchro_fast.rs):
+// per chunk: idx starts at last_index, `while idx < end_idx { idx += t_ratio; out = (1-frac)*y[floor idx] + frac*y[floor idx + 1] }`,
+// last_index = idx - chunk.  The index recurrence is a sequential f64 accumulation (its roundings decide `frac`), so one
+// lane walks it and records (sample index, frac) per output; the interpolation itself is then fully parallel.
+__global__ void k_resample_scan(double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out, int cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
+    double idx = last_index; int n = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        while (idx < end_idx) {
+            idx += t_ratio;
+            const double fl = floor(idx);
+            if (n < cap) { pos[n] = c * chunk + (int)fl; frac[n] = (float)(idx - fl); }
+            n++;
+        }
+        idx = idx - (double)chunk;
+    }
+    *n_out = n; *last_index_out = idx;
+}
+// in: [16*ch history | n_chunks*chunk*ch] interleaved (history = the 16 frames preceding the first chunk); out interleaved
+__global__ void k_resample_lerp(const float* in, int channels, const int* pos, const float* frac, const int* n_out, float* out, int cap) {
+    const int n = min(*n_out, cap);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * channels; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i / channels), c = (int)(i % channels);
+        const float fr = frac[f]; const float* y = in + ((long)(pos[f] + 16)) * channels + c;
+        out[i] = (1.0f - fr) * y[0] + fr * y[channels];
+    }
+}
+void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
+                                float* out, int cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap);
+    hipLaunchKernelGGL(k_resample_lerp, dim3(256), dim3(256), 0, s, in, channels, pos, frac, n_out, out, cap);
+}
+
+// ------------------------------------------------------------------ polyphase windowed-sinc resampler (quality mode, no reference counterpart)
+// out[n] = sum_t h[phase(n)][t] * x[base(n) + t - T/2 + 1], rational ratio L/M, T taps per phase (32 x the decimation factor); coefficients from the host.
+__global__ void k_resample_polyphase(const float* in, long n_in, int channels, const float* coef /*[L][T]*/, int L, int M, int T, float* out, long n_out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out * channels; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / channels; const int c = (int)(i % channels);
+        const long num = f * (long)M; const long base = num / L; const int ph = (int)(num % L);
+        const float* h = coef + (long)ph * T;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int t = 0; t < T; ++t) { long j = base + t - (T / 2 - 1); float x = (j >= 0 && j < n_in) ? in[j * channels + c] : 0.0f; acc = __builtin_fmaf(h[t], x, acc); }
+        out[i] = acc;
+    }
+}
+void skw_resample_polyphase_launch(const float* in, long n_in, int channels, const float* coef, int L, int M, int T, float* out, long n_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_resample_polyphase, dim3(1024), dim3(256), 0, s, in, n_in, channels, coef, L, M, T, out, n_out);
+}

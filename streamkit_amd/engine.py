@@ -44,6 +44,10 @@ class Timing(C.Structure):
                 ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32)]
 
 
+class ResamplerState(C.Structure):
+    _fields_ = [("last_index", C.c_double), ("ratio", C.c_double), ("chunk_frames", C.c_int32), ("channels", C.c_int32), ("hist", C.c_float * 32)]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -74,6 +78,14 @@ def lib():
         L.skw_conv_stem.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.skw_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.skw_decode_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.skw_dsp_create.restype = C.c_void_p
+        L.skw_dsp_create.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.skw_dsp_free.argtypes = [C.c_void_p]
+        L.skw_dsp_last_error.restype = C.c_char_p
+        L.skw_dsp_last_error.argtypes = [C.c_void_p]
+        L.skw_resampler_init.argtypes = [C.POINTER(ResamplerState), C.c_double, C.c_int, C.c_int]
+        L.skw_resample_linear.argtypes = [C.c_void_p, C.POINTER(ResamplerState), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.skw_resample_polyphase.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
         L.skw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
         L.skw_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.skw_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
@@ -229,3 +241,42 @@ def debug_get(name):
     out = np.empty(n, dtype=np.float32)
     lib().skw_debug_get(name.encode(), out.ctypes.data, n)
     return out
+
+
+class Dsp:
+    """Model-free device context for the resampler kernels (include/skw_engine.h, R1-R3)."""
+
+    def __init__(self, device=0):
+        err = C.create_string_buffer(512)
+        self.h = lib().skw_dsp_create(device, err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def linear_stream(self, ratio, chunk_frames, channels):
+        st = ResamplerState()
+        lib().skw_resampler_init(C.byref(st), ratio, chunk_frames, channels)
+        return st
+
+    def resample_linear(self, st, interleaved, n_chunks):
+        x = np.ascontiguousarray(interleaved, dtype=np.float32)
+        cap = int(n_chunks * st.chunk_frames * st.ratio) + 64
+        out = np.empty(cap * st.channels, dtype=np.float32)
+        n = C.c_int()
+        if lib().skw_resample_linear(self.h, C.byref(st), x.ctypes.data, n_chunks, out.ctypes.data, cap, C.byref(n)) != 0:
+            raise RuntimeError(lib().skw_dsp_last_error(self.h).decode())
+        return out[:n.value * st.channels].copy()
+
+    def resample_polyphase(self, interleaved, channels, in_rate, out_rate):
+        x = np.ascontiguousarray(interleaved, dtype=np.float32)
+        n_in = x.size // channels
+        cap = n_in * out_rate // in_rate + 64
+        out = np.empty(cap * channels, dtype=np.float32)
+        n = C.c_long()
+        if lib().skw_resample_polyphase(self.h, x.ctypes.data, n_in, channels, in_rate, out_rate, out.ctypes.data, cap, C.byref(n)) != 0:
+            raise RuntimeError(lib().skw_dsp_last_error(self.h).decode())
+        return out[:n.value * channels].copy()
+
+    def close(self):
+        if self.h:
+            lib().skw_dsp_free(self.h)
+            self.h = None

@@ -28,6 +28,7 @@ def test_engine_exports_every_declared_symbol(built):
 
 
 def test_plugin_exports_the_one_symbol(built):
+    assert hasattr(C.CDLL(os.path.join(ROOT, "streamkit_amd", "libresampler.so")), "streamkit_native_plugin_api")
     L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libwhisper.so"))
     assert _declared_functions("streamkit_native_abi.h") == ["streamkit_native_plugin_api"]
     assert hasattr(L, "streamkit_native_plugin_api")
