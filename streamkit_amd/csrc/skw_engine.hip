@@ -300,7 +300,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
-    WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * nc * dt, false);
+    WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false);
@@ -447,9 +447,12 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
         const int dt = hp.n_text_state; const float Kscale = (float)pow((double)((float)dt / hp.n_text_head), -0.25);
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
-            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
+            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad;
             { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; GEMM(c, a, d); }
-            { SkwGemmArgs a = gemm_args(c->y16, d, L.cv, M, cv, dt, EPI_F16_PLAIN); GEMM(c, a, d); }
+            { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
+                SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv; a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
+                GEMM(c, a, d);
+            }
         }
     }
     c->last_enc_B = Bw;
@@ -465,7 +468,7 @@ static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
         half_t* sk = c->selfK + (size_t)l * c->max_batch * ntc * dt; half_t* sv = c->selfV + (size_t)l * c->max_batch * ntc * dt;
-        half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * nc * dt;
+        half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * H * 64 * c->Tpad;
         skw_layernorm(c->dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, c->dy16, nullptr, s);
         { SkwGemmArgs a = gemm_args(c->dy16, dt, L.qkv, Bw, c->dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk + (size_t)pos * dt; a.C3 = sv + (size_t)pos * dt; a.ldc2 = (long)ntc * dt; GEMM_S(c, a, a.K); }
@@ -473,7 +476,7 @@ static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
         { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         skw_layernorm(c->dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, c->dy16, nullptr, s);
         { SkwGemmArgs a = gemm_args(c->dy16, dt, L.cq, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn(c->dq16, ck, cv, Bw, H, dt, nc, c->datt16, s); }
+        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(c->dq16, ck, cv, Bw, H, dt, nc, c->Tpad, c->datt16, s); }
         { SkwGemmArgs a = gemm_args(c->datt16, dt, L.co, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         skw_layernorm(c->dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, c->dy16, nullptr, s);
         { SkwGemmArgs a = gemm_args(c->dy16, dt, L.fc1, Bw, c->dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }
@@ -669,6 +672,8 @@ extern "C" int skw_conv_stem(skw_ctx* c, const float* pcm_host, int n_samples, i
     char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
     HIPCHK(hipMemcpyAsync(x0, c->x, sizeof(float) * c->m->hp.n_audio_ctx * c->m->hp.n_audio_state, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0;
 }
+// cross V^T [(h*64 + c)][Tpad kperm] of batch slot 0 -> natural [key][d] f32
+__global__ void k_vt2f_copy(const half_t* src, float* dst, int nc, int dt, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[(long)n * Tpad + skw_kperm(key)]; }
 __global__ void k_h2f_copy(const half_t* src, float* dst, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = (float)src[i]; }
 extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int seek, float* enc_out, float* cross_k, float* cross_v) {
     char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
@@ -678,8 +683,8 @@ extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int 
     if (cross_k && cross_v) {
         const long n = (long)nc * dt; float* tmp = nullptr; HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
         for (int l = 0; l < hp.n_text_layer; ++l) for (int kv = 0; kv < 2; ++kv) {
-            const half_t* src = (kv ? c->crossV : c->crossK) + (size_t)l * c->max_batch * nc * dt;
-            hipLaunchKernelGGL(k_h2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, tmp, n);
+            if (kv) hipLaunchKernelGGL(k_vt2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad, tmp, nc, dt, c->Tpad);
+            else hipLaunchKernelGGL(k_h2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->crossK + (size_t)l * c->max_batch * nc * dt, tmp, n);
             HIPCHK(hipMemcpyAsync((kv ? cross_v : cross_k) + (size_t)l * n, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
         }
         hipFree(tmp);
