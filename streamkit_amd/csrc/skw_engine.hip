@@ -257,6 +257,9 @@ extern "C" void skw_full_default_params(skw_full_params* p) {
 struct skw_ctx {
     skw_model* m = nullptr; int max_batch = 0, max_samples = 0, n_len_max = 0, Tpad = 0;
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
+    hipStream_t cur = nullptr;                       // stream the launch helpers enqueue on (== stream outside the decode groups)
+    static const int MAX_GROUPS = 8; hipStream_t gstream[MAX_GROUPS] = {}; hipEvent_t gev[MAX_GROUPS] = {}; int n_groups = 1;
+    struct StepGraph { int g, r0, n; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
     char errbuf[512] = {0};
     std::vector<void*> allocs;
     // front end
@@ -292,6 +295,11 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     c->Tpad = (nc + 31) & ~31;
     bool ok = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
+    c->cur = c->stream;
+    // decode groups: the step kernels are latency-bound chains that leave most CUs idle, so independent row groups run concurrently
+    { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : 1; }
+    { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : 2; if (c->n_groups < 1) c->n_groups = 1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
+    for (int g = 0; g < c->n_groups && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
 #define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
     WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
@@ -305,11 +313,11 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false);
     c->max_tok = hp.n_text_ctx / 2;
-    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, 1, true); WS(static_mask, uint8_t, hp.n_vocab, true);
+    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(static_mask, uint8_t, hp.n_vocab, true);
 #undef WS
     ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&c->h_n_active, sizeof(int)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_n_active, sizeof(int) * skw_ctx::MAX_GROUPS) == hipSuccess;
     if (!ok) { set_err(err, errlen, "workspace allocation failed (max_batch %d)", max_batch); skw_ctx_free(c); return nullptr; }
     hipDeviceSynchronize();
     return c;
@@ -317,6 +325,9 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
 extern "C" void skw_ctx_free(skw_ctx* c) {
     if (!c) return; hipSetDevice(c->m->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& sg : c->step_graphs) hipGraphExecDestroy(sg.exec);
+    c->step_graphs.clear();
+    for (int g = 0; g < skw_ctx::MAX_GROUPS; ++g) { if (c->gstream[g]) { hipStreamSynchronize(c->gstream[g]); hipStreamDestroy(c->gstream[g]); } if (c->gev[g]) hipEventDestroy(c->gev[g]); }
     for (void* p : c->allocs) hipFree(p);
     if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_n_active) hipHostFree(c->h_n_active);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -367,9 +378,9 @@ ProfScope::ProfScope(skw_ctx* c_, int cls, double flops, double bytes) : ps(null
     ps = &it->second;
     auto get = [&]() { if (ps->next == ps->pool.size()) { hipEvent_t e; hipEventCreate(&e); ps->pool.push_back(e); } return ps->pool[ps->next++]; };
     ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get(); idx = ps->recs.size(); ps->recs.push_back(r);
-    hipEventRecord(r.a, c->stream);
+    hipEventRecord(r.a, c->cur);
 }
-ProfScope::~ProfScope() { if (ps) hipEventRecord(ps->recs[idx].b, c->stream); }
+ProfScope::~ProfScope() { if (ps) hipEventRecord(ps->recs[idx].b, c->cur); }
 static void prof_collect(skw_ctx* c) {
     auto it = g_prof.find(c); if (it == g_prof.end() || !it->second.on) return; ProfState& ps = it->second;
     hipStreamSynchronize(c->stream);
@@ -383,12 +394,12 @@ extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
 static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical; *by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
-static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by); skw_gemm(a, c->stream); }
+static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by); skw_gemm(a, c->cur); }
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by);
     // (a VALU row-parallel variant — lane = batch row, v_fma_mix chains — was measured slower: a dependent v_fma costs 8-10 cycles
     //  on gfx950, no better than the MFMA's 40 cycles per 4 k)
-    skw_gemm_smallm(a, c->stream);
+    skw_gemm_smallm(a, c->cur);
 }
 
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
@@ -460,32 +471,52 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
 
 // one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
 __global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; }
-static void run_decoder_step(skw_ctx* c, int Bw, int pos, bool want_logits) {
+// rows [r0, r0 + Bw) of the window batch on stream s: sequences are independent, so groups of rows can run on their own streams
+static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logits, hipStream_t s) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int dt = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, ntc = hp.n_text_ctx;
     const float KQscale = (float)pow((double)((float)dt / H), -0.25);
-    hipStream_t s = c->stream;
-    skw_dec_embed(m->te.w, m->d_pe, &c->st[0].cur_token, &c->st[0].cur_pos, Bw, dt, c->dx, s);
+    c->cur = s;
+    float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
+    half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = c->st + r0;
+    skw_dec_embed(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
-        half_t* sk = c->selfK + (size_t)l * c->max_batch * ntc * dt; half_t* sv = c->selfV + (size_t)l * c->max_batch * ntc * dt;
-        half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * H * 64 * c->Tpad;
-        skw_layernorm(c->dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.qkv, Bw, c->dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk + (size_t)pos * dt; a.C3 = sv + (size_t)pos * dt; a.ldc2 = (long)ntc * dt; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(c->dq16, sk, sv, &c->st[0].cur_pos, Bw, H, dt, ntc, c->datt16, s); }
-        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.o, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        skw_layernorm(c->dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.cq, Bw, c->dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(c->dq16, ck, cv, Bw, H, dt, nc, c->Tpad, c->datt16, s); }
-        { SkwGemmArgs a = gemm_args(c->datt16, dt, L.co, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        skw_layernorm(c->dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, c->dy16, nullptr, s);
-        { SkwGemmArgs a = gemm_args(c->dy16, dt, L.fc1, Bw, c->dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(c->dh16, 4L * dt, L.fc2, Bw, c->dx, dt, EPI_F32); a.res = c->dx; a.ldres = dt; GEMM_S(c, a, a.K); }
+        half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
+        half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, dy16, nullptr, s); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
+          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, s); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, dy16, nullptr, s); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, s); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, dy16, nullptr, s); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
     }
     if (want_logits) {
-        skw_layernorm(c->dx, Bw, dt, m->d_ln.w, m->d_ln.b, c->dy16, nullptr, s);
-        SkwGemmArgs a = gemm_args(c->dy16, dt, m->te, Bw, c->logits, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
+        SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
+    c->cur = c->stream;
+}
+
+// One generation step of a row group as an executable graph: decoder step (positions and tokens read from the device state),
+// logit filters + sampling, and the read-back of the group's active count.  Captured once per (group, rows, filter params).
+static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogitParams& lp) {
+    for (auto& sg : c->step_graphs) if (sg.g == g && sg.r0 == r0 && sg.n == n && memcmp(&sg.lp, &lp, sizeof lp) == 0) return sg.exec;
+    const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    run_decoder_step(c, r0, n, 0, true, s);
+    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, s);
+    hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+    hipGraphDestroy(graph);
+    if (exec) { skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg); }
+    return exec;
 }
 
 static void build_static_mask(skw_ctx* c, const skw_full_params* p) {
@@ -570,21 +601,41 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = n_prompt; s.min_margin = INFINITY;
         }
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
-        *c->h_n_active = Bw;
-        HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
+        const bool profiling = g_prof.count(c) && g_prof[c].on;
+        const int G = profiling ? 1 : std::max(1, std::min(c->n_groups, Bw / 8));
+        int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
+        for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; c->h_n_active[g] = g_n[g]; }
+        HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+        for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
         for (int t = 0; t < n_prompt; ++t) {
-            hipLaunchKernelGGL(k_set_tokens, dim3(Bw), dim3(1), 0, c->stream, c->st, prompt[t], t);
-            run_decoder_step(c, Bw, t, t == n_prompt - 1);
+            for (int g = 0; g < G; ++g) {
+                hipLaunchKernelGGL(k_set_tokens, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], prompt[t], t);
+                run_decoder_step(c, g_r0[g], g_n[g], t, t == n_prompt - 1, c->gstream[g]);
+            }
             tot_steps++;
         }
+        hipGraphExec_t gexec[skw_ctx::MAX_GROUPS] = {};
+        if (c->use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
+        auto sample = [&](int g) {
+            c->cur = c->gstream[g];
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->gstream[g]); }
+            c->cur = c->stream;
+            return hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, c->gstream[g]);
+        };
+        for (int g = 0; g < G; ++g) HIPCHK(sample(g));
         for (int i = 0; i < lp.n_max; ++i) {
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * Bw * NV); skw_dec_sample(c->logits, c->static_mask, lp, c->st, c->toks, c->max_tok, Bw, c->n_active, c->stream); }
-            HIPCHK(hipMemcpyAsync(c->h_n_active, c->n_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            if (*c->h_n_active <= 0 || i == lp.n_max - 1) break;
-            run_decoder_step(c, Bw, n_prompt + i, true);
+            bool any = false;
+            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); if (c->h_n_active[g] <= 0) g_live[g] = false; else any = true; }
+            if (!any || i == lp.n_max - 1) break;
+            for (int g = 0; g < G; ++g) if (g_live[g]) {
+                if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
+                else { run_decoder_step(c, g_r0[g], g_n[g], n_prompt + i, true, c->gstream[g]); HIPCHK(sample(g)); }
+            }
             tot_steps++;
         }
+        for (int g = 0; g < G; ++g) { HIPCHK(hipEventRecord(c->gev[g], c->gstream[g])); HIPCHK(hipStreamWaitEvent(c->stream, c->gev[g], 0)); }
         HIPCHK(hipMemcpyAsync(c->h_st, c->st, sizeof(SkwSeqState) * Bw, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_toks, c->toks, sizeof(SkwTokenOut) * Bw * c->max_tok, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
@@ -696,7 +747,7 @@ extern "C" int skw_decode_logits(skw_ctx* c, const int32_t* tokens, int n_tokens
     if (n_tokens < 1 || n_tokens > c->m->hp.n_text_ctx) { snprintf(errbuf, 512, "bad n_tokens"); return -1; }
     for (int t = 0; t < n_tokens; ++t) {
         hipLaunchKernelGGL(k_set_tokens, dim3(1), dim3(1), 0, c->stream, c->st, tokens[t], t);
-        run_decoder_step(c, 1, t, t == n_tokens - 1);
+        run_decoder_step(c, 0, 1, t, t == n_tokens - 1, c->stream);
     }
     HIPCHK(hipMemcpyAsync(logits, c->logits, sizeof(float) * c->m->hp.n_vocab, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0;
 }

@@ -35,6 +35,7 @@ struct SkwGemmArgs {
     int M, N, K;                    // K multiple of 32 (zero padded by the producer)
     void* C; long ldc;
     void* C2; void* C3; long ldc2;   // EPI_DEC_QKV
+    const int* pos_ptr; int pos_stride; // EPI_DEC_QKV: row m appends its K/V at cache position pos_ptr[m * pos_stride] (device-side, so a captured step graph is step-invariant)
     const float* bias;              // may be null
     const float* res; long ldres;   // EPI_F32 residual (may be null; may alias C)
     float scale;                    // EPI_F16*/HEADS (1.0f = none; multiply is skipped when has_scale == 0)

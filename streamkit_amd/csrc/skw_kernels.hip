@@ -69,8 +69,11 @@ __device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, fl
         if (a.bias) v = v + a.bias[n];
         if (n < 2 * d) v = v * a.scale;
         if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
-        else if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + (n - d)] = f2h(v);
-        else ((half_t*)a.C3)[(long)m * a.ldc2 + (n - 2 * d)] = f2h(v);
+        else {
+            const long po = a.pos_ptr ? (long)a.pos_ptr[(long)m * a.pos_stride] * d : 0;
+            if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + po + (n - d)] = f2h(v);
+            else ((half_t*)a.C3)[(long)m * a.ldc2 + po + (n - 2 * d)] = f2h(v);
+        }
     } else if (EPI == EPI_F16_PLAIN) {
         if (a.bias) v = v + a.bias[n];
         if (a.has_scale) v = v * a.scale;
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
     for (int j = 0; j < SM_DEPTH; ++j) {
         fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nk) ? oob : wo + j * 64, 0, 0);
         fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nk) ? oob : ao + j * 64, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);    // issue in ring order (the scheduler would issue the first-needed block last)
     }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb0 = 0; kb0 < nk; kb0 += SM_DEPTH) {      // branch-free body: the ring stays SM_DEPTH blocks ahead
@@ -192,8 +196,17 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
             const int nb = kb0 + j + SM_DEPTH;
             fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nk) ? oob : wo + nb * 64, 0, 0);
             fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nk) ? oob : ao + nb * 64, 0, 0);
+            // convert the block's 16 operands first, then issue its 8 MFMAs back to back: a dependent MFMA that directly follows its
+            // producer costs 32 cycles, one separated from it by VALU work ~52 (tools/probe/probe_mfma_chain.hip: 56 -> 42 cycles/MFMA)
+            float xa[8], xw[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = MFMA16(h2f(ca.h[e]), h2f(cw.h[e]), acc);
+            for (int e = 0; e < 8; ++e) { xa[e] = h2f(ca.h[e]); xw[e] = h2f(cw.h[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = MFMA16(xa[e], xw[e], acc);
+            // keep each block's reload where it is: left alone, the scheduler sinks all loads to the end of the unrolled body
+            // (shorter live ranges) and the next pass then waits out a full memory latency (measured: 40 -> 20 us at K = 3072)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -796,27 +809,25 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // 16-byte load = 8 keys of one channel), B = p broadcast to every column, so each output channel is the same key-ascending fma chain
 // as the scalar form; a 12-deep ring keeps 24 KB of V^T per wave in flight.  HBM-bound: 55.3 MB per sequence per step over all layers.
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
-template <int MAXT>
-__global__ __launch_bounds__(384, 1) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
+template <int MAXT, int WPH>
+__global__ __launch_bounds__(192 * WPH, 1) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
                                                            const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo) {
     __shared__ float plds[3][MAXT * 64];
-    __shared__ __attribute__((aligned(16))) half_t klds[6][64 * 72];
-    __shared__ float smax[3][2];
-    __shared__ double ssum[3][2];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hs = w >> 1, half = w & 1;
+    __shared__ __attribute__((aligned(16))) half_t klds[3 * WPH][64 * 72];
+    __shared__ float smax[3][WPH];
+    __shared__ double ssum[3][WPH];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
     const int hraw = blockIdx.x * 3 + hs, b = blockIdx.y;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
     const half_t* K = kbase + (long)b * k_batch_stride + h * 64;
-    float qv[64];
+    H8v qh[8];                                  // q stays packed (32 VGPRs instead of 64); converted in the chain's shadow
     {
         const u32x4* qp = (const u32x4*)(q + (long)b * ldq + h * 64);
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) { H8v t; t.v = qp[c8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[c8 * 8 + e] = h2f(t.h[e]); }
+        for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = qp[c8];
     }
-    const int nt = (n_ctx + 63) >> 6, nth = (nt + 1) >> 1;
+    const int nt = (n_ctx + 63) >> 6, nth = (nt + WPH - 1) / WPH;
     const int t_lo = half * nth, t_hi = min(nt, t_lo + nth);
     float lmax = -INFINITY;
     half_t* kl = klds[w];
@@ -824,85 +835,108 @@ __global__ __launch_bounds__(384, 1) void k_dec_cross_attn(const half_t* q, long
     const int lrow = lane >> 3, lseg = lane & 7;
     u32x4 k0[8], k1[8], k2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { k0[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
-                                  k1[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8); }
+    for (int i = 0; i < 8; ++i) k0[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k1[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // one pass = 64 keys: refill the free ring slot with pass t+2 first, then consume `cur`.  Roles rotate by name (three passes per
+    // loop trip) so no register copies force early waits, and the scheduling barriers keep the loads where they are written.
+    auto pass = [&](int t, u32x4 (&cur)[8], u32x4 (&fill)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fill[i] = *(const u32x4*)(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < t_hi) {       // wave-uniform
+            const int key = t * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = cur[i];
+            __builtin_amdgcn_wave_barrier();   // same wave, LDS in order: a compiler-level fence is all that is needed
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) asm volatile("" : "+v"(qh[c8].v));   // opaque: stops the 64 conversions being hoisted out of the loop into 64 live registers
+            float a = 0.0f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) { H8v t8; t8.v = *(const u32x4*)(kl + lane * 72 + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf(h2f(qh[c8].h[e]), h2f(t8.h[e]), a); }
+            __builtin_amdgcn_wave_barrier();
+            if (key >= n_ctx) a = -INFINITY;
+            pl[key] = a; lmax = fmaxf(lmax, a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll 1
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int key = t * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) k2[i] = *(const u32x4*)(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = k0[i];
-        __builtin_amdgcn_wave_barrier();   // same wave, LDS in order: a compiler-level fence is all that is needed
-        float a = 0.0f;
-#pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) { H8v t8; t8.v = *(const u32x4*)(kl + lane * 72 + c8 * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qv[c8 * 8 + e], h2f(t8.h[e]), a); }
-        __builtin_amdgcn_wave_barrier();
-        if (key >= n_ctx) a = -INFINITY;
-        pl[key] = a; lmax = fmaxf(lmax, a);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { k0[i] = k1[i]; k1[i] = k2[i]; }
-    }
+    for (int t = t_lo; t < t_hi; t += 3) { pass(t, k0, k2); pass(t + 1, k1, k0); pass(t + 2, k2, k1); }
     // V^T ring: start the first loads before the softmax so they fly during it
     const int r16 = lane & 15, g = lane >> 4;
     const long bh = (long)b * H + h;
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vtbase + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
-    const unsigned vo = (unsigned)(((half * 32 + r16) * Tpad + g * 8) * 2);      // this wave's two channel tiles: 32*half + {0..15, 16..31}
+    constexpr int CT = 4 / WPH;                                                   // channel tiles per wave
+    const unsigned vo = (unsigned)(((half * CT * 16 + r16) * Tpad + g * 8) * 2);
     const int nkb = Tpad >> 5;
     constexpr int RD = 12;
-    H8v ring[RD][2];
+    H8v ring[RD][CT];
 #pragma unroll
     for (int j = 0; j < RD; ++j)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (j < nkb) ? vo + ct * 16 * Tpad * 2 + j * 64 : 0x7fffff00u, 0, 0);
+        for (int ct = 0; ct < CT; ++ct) { ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (j < nkb) ? vo + ct * 16 * Tpad * 2 + j * 64 : 0x7fffff00u, 0, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
     if (lane == 0) smax[hs][half] = lmax;
     __syncthreads();
-    lmax = fmaxf(smax[hs][0], smax[hs][1]);
+    lmax = smax[hs][0];
+#pragma unroll
+    for (int i = 1; i < WPH; ++i) lmax = fmaxf(lmax, smax[hs][i]);
     double lsum = 0.0;
     for (int t = t_lo; t < t_hi; ++t) { float e = skw_expf(pl[t * 64 + lane] - lmax); pl[t * 64 + lane] = e; lsum += (double)e; }   // exp(-inf) == 0 for masked keys
     lsum = wave_sum_f64(lsum);
     if (lane == 0) ssum[hs][half] = lsum;
     __syncthreads();
-    const float inv = (float)(1.0 / (ssum[hs][0] + ssum[hs][1]));
-    for (int t = t_lo; t < t_hi; ++t) pl[t * 64 + lane] = h2f(f2h(pl[t * 64 + lane] * inv));
-    for (int t = nt + half; t < MAXT; t += 2) pl[t * 64 + lane] = 0.0f;      // key slots past the last pass (V^T pad is zero as well)
-    __syncthreads();
-    f32x4 oacc[2];
+    double tot = ssum[hs][0];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 1; i < WPH; ++i) tot += ssum[hs][i];
+    const float inv = (float)(1.0 / tot);
+    for (int t = t_lo; t < t_hi; ++t) pl[t * 64 + lane] = h2f(f2h(pl[t * 64 + lane] * inv));
+    for (int t = nt + half; t < MAXT; t += WPH) pl[t * 64 + lane] = 0.0f;      // key slots past the last pass (V^T pad is zero as well)
+    __syncthreads();
+    f32x4 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb0 = 0; kb0 < nkb; kb0 += RD) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const int kb = kb0 + j;
-            H8v vf[2];
+            H8v vf[CT];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) vf[ct] = ring[j][ct];
+            for (int ct = 0; ct < CT; ++ct) vf[ct] = ring[j][ct];
             const int nb = kb + RD;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (nb < nkb) ? vo + ct * 16 * Tpad * 2 + nb * 64 : 0x7fffff00u, 0, 0);
+            for (int ct = 0; ct < CT; ++ct) ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (nb < nkb) ? vo + ct * 16 * Tpad * 2 + nb * 64 : 0x7fffff00u, 0, 0);
             const int kbc = min(kb, nkb - 1);     // blocks past the end multiply p by zero-filled fragments
+            float pe[8], xv[CT][8];      // operands first, then the MFMAs back to back (a dependent MFMA directly behind its producer is the cheap case)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float p = pl[kbc * 32 + 4 * e + g];
+            for (int e = 0; e < 8; ++e) { pe[e] = pl[kbc * 32 + 4 * e + g];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) oacc[ct] = MFMA16(h2f(vf[ct].h[e]), p, oacc[ct]);   // O^T[c][*] += V^T[c][key] * p[key]
-            }
+                for (int ct = 0; ct < CT; ++ct) xv[ct][e] = h2f(vf[ct].h[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) oacc[ct] = MFMA16(xv[ct][e], pe[e], oacc[ct]);   // O^T[c][*] += V^T[c][key] * p[key]
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // D = O^T replicated over columns: lane (col n = r16, rows 4*g + r) -> channel 32*half + ct*16 + 4*g + r; take column 0
     if (r16 == 0 && valid) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long)b * ldo + skw_kperm(h * 64 + half * 32 + ct * 16 + 4 * g + r)] = f2h(oacc[ct][r]);
+            for (int r = 0; r < 4; ++r) out[(long)b * ldo + skw_kperm(h * 64 + (half * CT + ct) * 16 + 4 * g + r)] = f2h(oacc[ct][r]);
     }
 }
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, hipStream_t s) {
-    hipLaunchKernelGGL((k_dec_cross_attn<24>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d);
+    static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
+    if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d);
 }
 
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s) {
