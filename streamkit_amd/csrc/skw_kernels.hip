@@ -576,10 +576,177 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_regs(const half_t* Qh, 
         }
 }
 
+// ------------------------------------------------------------------ encoder self-attention, single-pass form (K5)
+// On gfx950 the f32 MFMA and the vector ALU do not overlap on a SIMD, not even across waves (tools/probe/probe_mfma_chain.hip: 16 conversions
+// + 8 MFMAs cost 41.5 cycles/MFMA at 1, 2 or 3 waves per SIMD), so the kernel that wins is the one with the fewest MFMA + VALU cycles:
+// Q.K^T once (scores stay on chip: RT tiles in registers/AGPRs, the rest in a per-wave LDS slab), one exponential per score,
+// evaluated two at a time with packed f32 math, and every dependent MFMA chain issued back to back.  One wave = 16 queries against all
+// keys; the four waves of a workgroup are independent (no barriers).  Arithmetic per output is identical to k_attn_encoder:
+// d-ascending score chains, exact row max, skw_expf, f64 row sum, P = f16(e * inv), key-ascending P.V chains.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// skw_expf for a pair of non-positive arguments: same operations as include/skw_math.h (the x > 88.7 and n > 127 branches cannot
+// trigger for x <= 0; y * 2^n == ldexp(y, n) exactly while the result is normal, which x >= -86 guarantees)
+__device__ __forceinline__ f32x2 expf_nonpos_x2(f32x2 x) {
+    f32x2 t = x * (f32x2){1.44269504088896341f, 1.44269504088896341f};
+    f32x2 n = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
+    f32x2 r = __builtin_elementwise_fma(n, (f32x2){-0.693359375f, -0.693359375f}, x);
+    r = __builtin_elementwise_fma(n, (f32x2){2.12194440e-4f, 2.12194440e-4f}, r);
+    f32x2 p = {1.9875691500e-4f, 1.9875691500e-4f};
+    p = __builtin_elementwise_fma(p, r, (f32x2){1.3981999507e-3f, 1.3981999507e-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){8.3334519073e-3f, 8.3334519073e-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){4.1665795894e-2f, 4.1665795894e-2f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){1.6666665459e-1f, 1.6666665459e-1f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){5.0000001201e-1f, 5.0000001201e-1f});
+    f32x2 r2 = r * r;
+    f32x2 y = __builtin_elementwise_fma(p, r2, r) + (f32x2){1.0f, 1.0f};
+    f32x2 o;
+    o[0] = (x[0] >= -86.0f) ? __builtin_ldexpf(y[0], (int)n[0]) : 0.0f;
+    o[1] = (x[1] >= -86.0f) ? __builtin_ldexpf(y[1], (int)n[1]) : 0.0f;
+    return o;
+}
+template <int NT, int RT>
+__global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
+                                                            int H, int n_ctx, int Tpad, float kq_scale, int qtiles) {
+    constexpr int LT = NT - RT, NB = NT / 2, KD = 3;
+    static_assert(NT % 2 == 0 && RT % 2 == 0 && RT <= NT, "tiles come in 32-key blocks");
+    extern __shared__ __attribute__((aligned(16))) char smem_att[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x4* slds = (f32x4*)smem_att + (size_t)wave * (LT > 0 ? LT : 1) * 64 + lane;     // tile t >= RT of this lane at slds[(t - RT) * 64]
+    const int nblk = gridDim.x; int bid = blockIdx.x;
+    { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }   // XCD-aware: one (batch, head) per L2
+    const long bh = bid / qtiles; const int qt = bid % qtiles;
+    const int b = (int)(bh / H), h = (int)(bh % H);
+    const int q0 = qt * 64 + wave * 16;
+    if (q0 >= n_ctx) return;                       // waves are independent: no workgroup barriers below
+    const int r16 = lane & 15, g = lane >> 4;
+    float qf[16];                                  // Q fragment (B operand): lane (q = r16, g) holds Q[q][d = 32*blk + 4*e + g]
+    {
+        int qi = q0 + r16; if (qi >= n_ctx) qi = n_ctx - 1;
+        const half_t* qp = Qh + (bh * Tpad + qi) * 64 + g * 8;
+        H8v a, c; a.v = *(const u32x4*)qp; c.v = *(const u32x4*)(qp + 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qf[e] = h2f(a.h[e]); qf[8 + e] = h2f(c.h[e]); }
+    }
+    const int kappa = 4 * (r16 & 3) + (r16 >> 2);  // MFMA row rho of a 16-key tile holds key kappa(rho): keeps the P.V chain ascending
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
+    const unsigned ko = (unsigned)((kappa * 64 + g * 8) * 2);                 // + kb*4096 per 32-key block, +2048 second tile, +64 d-block 1
+    const unsigned vo = (unsigned)((r16 * Tpad + g * 8) * 2);                 // + ct*16*Tpad*2, + kb*64 per block
+    f32x4 sreg[RT > 0 ? RT : 1];
+    float rmax = -INFINITY;
+    H8v ring[KD][4];
+    // ---- phase A: S^T tile by tile.  Per tile: 16 conversions, then its 16-MFMA chain back to back; the previous tile is
+    //      scaled / masked / max'ed after the chain has been issued, so nothing waits on an MFMA result.
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring[j][u].v = __builtin_amdgcn_raw_buffer_load_b128(rk, ko + j * 4096 + (u >> 1) * 2048 + (u & 1) * 64, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+    auto finish_tile = [&](int t, f32x4 a) {      // t = tile index of `a`
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = a[r] * kq_scale;
+            if (t == NT - 1) v = (t * 16 + 4 * r + g < n_ctx) ? v : -INFINITY;     // only the last tile can reach past n_ctx (host checks Tpad - n_ctx < 16)
+            a[r] = v; rmax = fmaxf(rmax, v);
+        }
+        if (t < RT) sreg[t < RT ? t : 0] = a; else slds[(t - RT) * 64] = a;
+    };
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        H8v c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = ring[kb % KD][u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring[kb % KD][u].v = __builtin_amdgcn_raw_buffer_load_b128(rk, ko + (kb + KD) * 4096 + (u >> 1) * 2048 + (u & 1) * 64, 0, 0);   // past Tpad: zeros
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float xk[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xk[e] = h2f(c[kt * 2].h[e]); xk[8 + e] = h2f(c[kt * 2 + 1].h[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc = MFMA16(xk[e], qf[e], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb * 2 + kt > 0) finish_tile(kb * 2 + kt - 1, prev);
+            prev = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    finish_tile(NT - 1, prev);
+    // V^T ring starts now so the loads fly during the exponentials
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, vo + ct * 16 * Tpad * 2 + j * 64, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    // ---- phase B: e = expf(s - max) in place (pairs, packed math), f64 row sum
+    double rsum = 0.0;
+    const f32x2 mx = {rmax, rmax};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 v = (t < RT) ? sreg[t < RT ? t : 0] : slds[(t - RT) * 64];
+        f32x2 e0 = expf_nonpos_x2((f32x2){v[0], v[1]} - mx), e1 = expf_nonpos_x2((f32x2){v[2], v[3]} - mx);
+        rsum += (double)e0[0]; rsum += (double)e0[1]; rsum += (double)e1[0]; rsum += (double)e1[1];
+        v = (f32x4){e0[0], e0[1], e1[0], e1[1]};
+        if (t < RT) sreg[t < RT ? t : 0] = v; else slds[(t - RT) * 64] = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);
+    const float rinv = (float)(1.0 / rsum);
+    // ---- phase C: O = P V with P = f16(e * inv) as the A operand, keys ascending; four channel tiles = four interleaved chains
+    f32x4 oacc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        H8v vf[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) vf[ct] = ring[kb % KD][ct];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) ring[kb % KD][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (kb + KD < NB) ? vo + ct * 16 * Tpad * 2 + (kb + KD) * 64 : 0x7fffff00u, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int t = kb * 2 + kt;
+            f32x4 ev = (t < RT) ? sreg[t < RT ? t : 0] : slds[(t - RT) * 64];
+            float pr[4], xv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = h2f(f2h(ev[r] * rinv));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) xv[ct][r] = h2f(vf[ct].h[kt * 4 + r]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) oacc[ct] = MFMA16(pr[r], xv[ct][r], oacc[ct]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int qi = q0 + g * 4 + r; int c = ct * 16 + r16;
+            if (qi < n_ctx) out[((long)b * n_ctx + qi) * ld_out + skw_kperm(h * 64 + c)] = f2h(oacc[ct][r]);
+        }
+}
+
 void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2) {
     if (Tpad == 1504 && !dbg && getenv("SKW_ATTN_REGS")) {   // experimental (measured no faster: 1 wave/SIMD cannot overlap the exp phase)   // Whisper's 1500-frame context: scores stay in registers, QK^T computed once
         const int qtiles = (n_ctx + 63) / 64;
         hipLaunchKernelGGL((k_attn_encoder_regs<94, 64>), dim3(qtiles * H * B), dim3(256), (size_t)4 * 30 * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles);
+        return;
+    }
+    if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg && !getenv("SKW_ATTN_V1")) {     // Whisper's 1500-frame context
+        const int qtiles = (n_ctx + 63) / 64;
+        constexpr int RT3 = 72;
+        hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles);
         return;
     }
     dim3 grid((n_ctx + 127) / 128, H, B);

@@ -61,5 +61,19 @@ int main() {
         }
         printf("mode %d (%s), %d wave(s)/SIMD: %.1f memtime cycles per dependent MFMA\n", mode, mode == 0 ? "invariant operands" : mode == 1 ? "cvt operands, compiler order" : mode == 2 ? "cvt block then mfma block" : "cvt for next block interleaved", waves, cyc / 10 / iters);
     }
+    // whole-kernel timing (events), long chains: ns per MFMA per SIMD, all 256 CUs busy
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 4; ++mode) for (int waves = 1; waves <= 3; ++waves) {
+        const int iters = 200000; float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            if (mode == 0) hipLaunchKernelGGL(k_chain<0>, dim3(256), dim3(256 * waves), 0, 0, d, in, st, iters);
+            else if (mode == 1) hipLaunchKernelGGL(k_chain<1>, dim3(256), dim3(256 * waves), 0, 0, d, in, st, iters);
+            else if (mode == 2) hipLaunchKernelGGL(k_chain<2>, dim3(256), dim3(256 * waves), 0, 0, d, in, st, iters);
+            else hipLaunchKernelGGL(k_chain<3>, dim3(256), dim3(256 * waves), 0, 0, d, in, st, iters);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        }
+        printf("events: mode %d, %d wave(s)/SIMD: %.2f ns per MFMA per SIMD (%.1f cycles at 2.39 GHz)\n", mode, waves, 1e6 * ms / iters / waves, 2.39 * 1e6 * ms / iters / waves);
+    }
     return 0;
 }
