@@ -17,7 +17,7 @@
  *     start_timestamp() / end_timestamp()          :650-660  skw_result.segments[i].{text,t0,t1}
  *
  * skw_full_batch is the batched form of `full`: n_clips independent calls of
- * whisper_full_with_state (greedy, temperature 0) executed together on one GPU.
+ * whisper_full_with_state (greedy strategy, best_of 1, temperature fallback ladder) executed together on one GPU.
  * The kernels fail loudly (non-zero return + message) when no gfx950 device is
  * present; there is no CPU fallback in this library.
  */
@@ -51,6 +51,9 @@ typedef struct {
     float   logprob_thold;
     float   no_speech_thold;
     int32_t n_threads;        /* accepted for ABI parity with the reference param; unused on the GPU */
+    float   temperature;      /* whisper_full_params.temperature, default 0.0: the first pass of a window is greedy argmax */
+    float   temperature_inc;  /* default 0.2: a window that fails (entropy / logprob / repetition rules) is decoded again at +0.2 .. 1.0,
+                                 sampling with std::discrete_distribution semantics from a per-clip std::mt19937(0); <= 0 disables the ladder */
 } skw_full_params;
 
 typedef struct {
@@ -63,7 +66,7 @@ typedef struct { int32_t id, tid; float p, plog, pt, ptsum; } skw_token;
 
 typedef struct {
     int32_t n_segments, n_tokens, n_windows, n_decode_steps;
-    int32_t fallback_requested; /* windows whose T=0 pass whisper.cpp would have retried at T>0 (not resampled here) */
+    int32_t fallback_requested; /* decoding passes that failed whisper.cpp's acceptance rules (each but the last temperature's is retried) */
     float   min_margin;         /* smallest top1-top2 admissible-logit margin seen (diagnostic) */
     skw_segment* segments;
     skw_token* tokens;

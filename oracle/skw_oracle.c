@@ -240,6 +240,7 @@ void skwo_default_params(skwo_params* p) {
     memset(p, 0, sizeof *p);
     p->lang_id = 0; p->translate = 0; p->suppress_blank = 1; p->suppress_nst = 0; /* whisper_full_default_params */ p->no_timestamps = 0; p->single_segment = 0; p->max_tokens = 0;
     p->max_initial_ts = 1.0f; p->entropy_thold = 2.4f; p->logprob_thold = -1.0f; p->no_speech_thold = 0.6f; p->n_threads = 0;
+    p->temperature = 0.0f; p->temperature_inc = 0.2f;
 }
 
 /* --------------------------------------------------------- K1: log-mel */
@@ -623,7 +624,7 @@ static void compute_logprobs(const float* logits, int n, float* logprobs) {
     for (int i = 0; i < n; ++i) logprobs[i] = (logits[i] > -INFINITY) ? logits[i] - logsumexp : -INFINITY;
 }
 
-static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t* dc, const float* raw_logits, float* no_speech_prob) {
+static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t* dc, const float* raw_logits, float* no_speech_prob, float temperature) {
     const int n_logits = m->hp.n_vocab; float* logits = dc->logits; float* logprobs = dc->logprobs; float* probs = dc->probs;
     const int is_initial = dc->n_tokens == 0;
     memcpy(logits, raw_logits, sizeof(float) * n_logits);
@@ -631,6 +632,7 @@ static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t*
         compute_logprobs(logits, n_logits, logprobs);
         *no_speech_prob = skw_expf(logprobs[m->tok_nosp]);
     }
+    if (temperature > 0.0f) for (int i = 0; i < n_logits; ++i) logits[i] /= temperature;   /* whisper_process_logits: before any filter */
     if (p->suppress_blank && is_initial) { logits[m->tok_eot] = -INFINITY; if (m->tok_space >= 0) logits[m->tok_space] = -INFINITY; }
     logits[m->tok_not] = -INFINITY;
     if (p->no_timestamps) for (int i = m->tok_beg; i < n_logits; ++i) logits[i] = -INFINITY;
@@ -684,6 +686,53 @@ static skwo_token sample_best(const skwo_model* m, decoder_t* dc) {
     return r;
 }
 
+/* std::mt19937 as libstdc++ implements it (the generator whisper.cpp keeps per decoder, seeded with 0) */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t* g, uint32_t seed) {
+    g->mt[0] = seed; for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t* g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+/* std::generate_canonical<double, 53>(mt19937): two draws, low word first (libstdc++ bits/random.tcc) */
+static double mt_canonical(mt19937_t* g) {
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; ++k) { sum += (double)mt_next(g) * tmp; tmp *= 4294967296.0; }
+    double r = sum / tmp;
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    return r;
+}
+/* std::discrete_distribution<>(probs.begin(), probs.end())(rng): weights to double, divided by their sequential sum,
+ * sequential partial sums with the last forced to 1.0, lower_bound of one canonical draw */
+static int discrete_draw(const float* probs, int n, mt19937_t* g) {
+    double sum = 0.0; for (int i = 0; i < n; ++i) sum += (double)probs[i];
+    const double u = mt_canonical(g);
+    double cp = 0.0;
+    for (int i = 0; i < n; ++i) { cp += (double)probs[i] / sum; if (i == n - 1) cp = 1.0; if (!(cp < u)) return i; }
+    return n - 1;
+}
+int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, int32_t* out) {   /* test hook (pinned against libstdc++ in tests/) */
+    mt19937_t g; mt_seed(&g, seed); for (int k = 0; k < n_draws; ++k) out[k] = discrete_draw(probs, n, &g); return 0;
+}
+/* whisper_sample_token(best = false) */
+static skwo_token sample_dist(const skwo_model* m, decoder_t* dc, mt19937_t* rng) {
+    skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
+    { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i]; if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
+    r.id = discrete_draw(probs, n, rng); r.p = probs[r.id]; r.plog = dc->logprobs[r.id];
+    if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }
+    return r;
+}
+
 static void sequence_score(decoder_t* dc) {
     if (dc->result_len == 0) return;
     double result = 0.0; for (int i = 0; i < dc->result_len; ++i) result += dc->tokens[i].plog;
@@ -707,7 +756,9 @@ static void acc_push_seg(acc_t* a, const skwo_model* m, int64_t t0, int64_t t1, 
     s->tok_end = a->n_tok; s->text_off = a->n_text; s->text_len = tl; memcpy(a->text + a->n_text, text, tl); a->n_text += tl; a->text[a->n_text] = 0;
 }
 
-/* whisper_full_with_state, n_decoders = 1, temperatures = {0} (fallback reported, not resampled) */
+/* whisper_full_with_state, greedy strategy with best_of = 1 (lib.rs:624): one decoder, argmax at t = 0, std::discrete_distribution
+ * draws from the decoder's mt19937 on the fallback passes.  DEVIATION D2': the generator is seeded (0) per call; whisper.cpp seeds it
+ * when the state is created and lets it run on across calls. */
 int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out) {
     memset(out, 0, sizeof *out); out->min_margin = INFINITY;
 #ifdef _OPENMP
@@ -728,47 +779,54 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     if (p->no_timestamps) prompt_init[n_prompt++] = m->tok_not;
     int seek = seek_start;
     char* text = (char*)malloc(1 << 16);
+    mt19937_t rng; mt_seed(&rng, 0);
     while (1) {
         if (seek + 100 >= seek_end) break;
         skwo_encode(m, mel, n_len, seek, 0, enc_out, ck, cv);
         out->n_windows++;
-        skwo_dec* ds = skwo_dec_new(m, ck, cv);
-        /* T = 0 pass */
-        dc.n_tokens = 0; dc.result_len = 0; dc.sum_logprobs_all = 0.0; dc.sum_logprobs = -INFINITY; dc.avg_logprobs = -INFINITY; dc.entropy = 0.0; dc.score = -INFINITY;
-        dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; dc.has_ts = 0; dc.failed = 0; dc.completed = 0;
+        /* temperature ladder (whisper_full_with_state): greedy at t = temperature, then sampled passes at +temperature_inc while a pass fails */
+        float temps[16]; int n_temps = 0; temps[n_temps++] = p->temperature;
+        if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && n_temps < 16; t += p->temperature_inc) temps[n_temps++] = t;
         float no_speech_prob = 0.0f;
-        skwo_dec_step(ds, prompt_init, n_prompt, 0, 0, raw); out->n_decode_steps++;
-        process_logits(m, p, &dc, raw, &no_speech_prob);
-        const int n_max = m->hp.n_text_ctx / 2 - 4;
-        for (int i = 0; i < n_max; ++i) {
-            skwo_token tk = sample_best(m, &dc);
-            if (dc.n_tokens == dc.cap) { dc.cap *= 2; dc.tokens = (skwo_token*)realloc(dc.tokens, dc.cap * sizeof(skwo_token)); }
-            dc.tokens[dc.n_tokens++] = tk; dc.sum_logprobs_all += tk.plog;
-            {
-                if (tk.id > m->tok_beg) {
-                    const int seek_delta_new = 2 * (tk.id - m->tok_beg);
-                    if (dc.has_ts && dc.seek_delta > seek_delta_new && dc.result_len < i) { dc.failed = 1; break; }
-                    dc.seek_delta = seek_delta_new; dc.result_len = i + 1; dc.has_ts = 1;
-                }
-                if (tk.id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc.has_ts && seek + dc.seek_delta + 100 >= seek_end)) {
-                    if (dc.result_len == 0 && !p->no_timestamps) {
-                        if (seek + dc.seek_delta + 100 >= seek_end) dc.result_len = i + 1;
-                        else { dc.failed = 1; break; }
+        for (int it = 0; it < n_temps; ++it) {
+            const float t_cur = temps[it];
+            skwo_dec* ds = skwo_dec_new(m, ck, cv);
+            dc.n_tokens = 0; dc.result_len = 0; dc.sum_logprobs_all = 0.0; dc.sum_logprobs = -INFINITY; dc.avg_logprobs = -INFINITY; dc.entropy = 0.0; dc.score = -INFINITY;
+            dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; dc.has_ts = 0; dc.failed = 0; dc.completed = 0;
+            skwo_dec_step(ds, prompt_init, n_prompt, 0, 0, raw); out->n_decode_steps++;
+            process_logits(m, p, &dc, raw, &no_speech_prob, t_cur);
+            const int n_max = m->hp.n_text_ctx / 2 - 4;
+            for (int i = 0; i < n_max; ++i) {
+                skwo_token tk = (t_cur < 1e-6f) ? sample_best(m, &dc) : sample_dist(m, &dc, &rng);
+                if (dc.n_tokens == dc.cap) { dc.cap *= 2; dc.tokens = (skwo_token*)realloc(dc.tokens, dc.cap * sizeof(skwo_token)); }
+                dc.tokens[dc.n_tokens++] = tk; dc.sum_logprobs_all += tk.plog;
+                {
+                    if (tk.id > m->tok_beg) {
+                        const int seek_delta_new = 2 * (tk.id - m->tok_beg);
+                        if (dc.has_ts && dc.seek_delta > seek_delta_new && dc.result_len < i) { dc.failed = 1; break; }
+                        dc.seek_delta = seek_delta_new; dc.result_len = i + 1; dc.has_ts = 1;
                     }
-                    if (p->single_segment || p->no_timestamps) { dc.result_len = i + 1; dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
-                    dc.completed = 1; break;
+                    if (tk.id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc.has_ts && seek + dc.seek_delta + 100 >= seek_end)) {
+                        if (dc.result_len == 0 && !p->no_timestamps) {
+                            if (seek + dc.seek_delta + 100 >= seek_end) dc.result_len = i + 1;
+                            else { dc.failed = 1; break; }
+                        }
+                        if (p->single_segment || p->no_timestamps) { dc.result_len = i + 1; dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
+                        dc.completed = 1; break;
+                    }
                 }
+                if (i == n_max - 1 && (dc.result_len == 0 || dc.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dc.failed = 1; break; }
+                { int32_t t = tk.id; skwo_dec_step(ds, &t, 1, n_prompt + i, 0, raw); out->n_decode_steps++; }
+                process_logits(m, p, &dc, raw, &no_speech_prob, t_cur);
             }
-            if (i == n_max - 1 && (dc.result_len == 0 || dc.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dc.failed = 1; break; }
-            { int32_t t = tk.id; skwo_dec_step(ds, &t, 1, n_prompt + i, 0, raw); out->n_decode_steps++; }
-            process_logits(m, p, &dc, raw, &no_speech_prob);
+            skwo_dec_free(ds);
+            if (!dc.failed) {
+                dc.n_tokens = dc.result_len; sequence_score(&dc);
+                if (dc.result_len > 32 && dc.entropy < p->entropy_thold) dc.failed = 1;
+            }
+            if (dc.failed || (dc.avg_logprobs < p->logprob_thold && no_speech_prob < p->no_speech_thold)) out->fallback_requested++;   /* this pass failed */
+            else break;
         }
-        skwo_dec_free(ds);
-        if (!dc.failed) {
-            dc.n_tokens = dc.result_len; sequence_score(&dc);
-            if (dc.result_len > 32 && dc.entropy < p->entropy_thold) dc.failed = 1;
-        }
-        if (dc.failed || (dc.avg_logprobs < p->logprob_thold && no_speech_prob < p->no_speech_thold)) out->fallback_requested++;
         /* output */
         {
             int seek_delta = dc.seek_delta; const int result_len = dc.result_len; const skwo_token* tc = dc.tokens; const int ntc = dc.n_tokens; (void)result_len;

@@ -49,6 +49,8 @@ typedef struct {
     float   logprob_thold;      /* default -1.0 */
     float   no_speech_thold;    /* default 0.6 */
     int32_t n_threads;
+    float   temperature;        /* default 0.0: first pass is greedy argmax */
+    float   temperature_inc;    /* default 0.2: fallback ladder 0.2, 0.4 .. 1.0 with sampling; <= 0 disables the ladder */
 } skwo_params;
 
 typedef struct {
@@ -64,7 +66,7 @@ typedef struct {
 
 typedef struct {
     int32_t n_segments, n_tokens, n_windows, n_decode_steps;
-    int32_t fallback_requested;  /* a window failed the T=0 pass (whisper.cpp would resample at T>0) */
+    int32_t fallback_requested;  /* decoding passes that failed the acceptance rules (all but the last temperature's are retried) */
     float   min_margin;          /* smallest top1-top2 logit margin over all sampled steps */
     skwo_segment* segments;
     skwo_token* tokens;          /* all result tokens in order (timestamps included) */
@@ -100,6 +102,8 @@ int skwo_dec_step(skwo_dec*, const int32_t* tokens, int n_tokens, int n_past, in
 
 /* K11-K12 + W4: whisper_full_with_state, greedy best_of=1, T=0 pass */
 int skwo_full(const skwo_model*, const skwo_params*, const float* pcm, int n_samples, skwo_result* out);
+/* test hook: n_draws of std::discrete_distribution<>(probs, probs + n) from std::mt19937(seed), as restated in skw_oracle.c */
+int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, int32_t* out);
 void skwo_result_free(skwo_result*);
 
 /* teacher-forced logits (for margin diagnostics): runs window at `seek` with given token prefix */

@@ -251,6 +251,7 @@ extern "C" const char* skw_model_token_text(const skw_model* m, int id, int* len
 }
 extern "C" void skw_full_default_params(skw_full_params* p) {
     memset(p, 0, sizeof *p); p->lang_id = 0; p->suppress_blank = 1; p->suppress_nst = 0; p->max_initial_ts = 1.0f; p->entropy_thold = 2.4f; p->logprob_thold = -1.0f; p->no_speech_thold = 0.6f;
+    p->temperature = 0.0f; p->temperature_inc = 0.2f;
 }
 
 // ------------------------------------------------------------------ context / workspace
@@ -271,6 +272,7 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
     SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; int* n_active = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
     SkwSeqState* h_st = nullptr; SkwTokenOut* h_toks = nullptr; int* h_n_active = nullptr; // pinned
     int max_tok = 0;
@@ -313,7 +315,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false);
     c->max_tok = hp.n_text_ctx / 2;
-    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(static_mask, uint8_t, hp.n_vocab, true);
+    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, hp.n_vocab, true);
 #undef WS
     ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
@@ -510,7 +512,7 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     run_decoder_step(c, r0, n, 0, true, s);
-    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, s);
+    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, c->probs + (size_t)r0 * NV, c->rng, c->clip_idx + r0, s);
     hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, s);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
@@ -572,6 +574,11 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0;
 
     std::vector<int> seek(n_clips, 0); std::vector<SeqAcc> acc(n_clips);
+    // temperature ladder (whisper_full_with_state): per clip, the index of the temperature its current window is decoded at
+    std::vector<float> temps; temps.push_back(p->temperature);
+    if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && temps.size() < 16; t += p->temperature_inc) temps.push_back(t);
+    std::vector<int> tidx(n_clips, 0);
+    skw_rng_seed(c->rng, n_clips, 0u, c->stream);   // DEVIATION D2': seeded per call (whisper.cpp: per state, running on across calls)
     int32_t prompt[8]; int n_prompt = 0;
     prompt[n_prompt++] = m->tok_sot;
     if (NV >= 51865) { prompt[n_prompt++] = m->tok_sot + 1 + p->lang_id; prompt[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
@@ -599,6 +606,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         for (int j = 0; j < Bw; ++j) {
             SkwSeqState& s = c->h_st[j]; memset(&s, 0, sizeof s);
             s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = n_prompt; s.min_margin = INFINITY;
+            s.temperature = temps[tidx[act[j]]];
         }
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
@@ -620,7 +628,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         if (c->use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->gstream[g]); }
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->gstream[g]); }
             c->cur = c->stream;
             return hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, c->gstream[g]);
         };
@@ -645,12 +653,17 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];
-            R.n_windows++; R.n_decode_steps += n_prompt > 0 ? 1 : 0; R.n_decode_steps += std::max(0, s.n_tokens - 1);
+            if (tidx[ci] == 0) R.n_windows++;
+            R.n_decode_steps += n_prompt > 0 ? 1 : 0; R.n_decode_steps += std::max(0, s.n_tokens - 1);
             bool failed = s.failed != 0; int n_tok = s.n_tokens; const int result_len = s.result_len;
             double avg_logprobs = -INFINITY, entropy = 0.0;
             if (!failed) { n_tok = result_len; sequence_score(tk, result_len, &avg_logprobs, &entropy); if (result_len > 32 && entropy < p->entropy_thold) failed = true; }
-            if (failed || (avg_logprobs < p->logprob_thold && s.no_speech_prob < p->no_speech_thold)) R.fallback_requested++;
             if (s.min_margin < R.min_margin) R.min_margin = s.min_margin;
+            if (failed || (avg_logprobs < p->logprob_thold && s.no_speech_prob < p->no_speech_thold)) {
+                R.fallback_requested++;
+                if (tidx[ci] + 1 < (int)temps.size()) { tidx[ci]++; continue; }   // this window again, at the next temperature (the batch re-encodes it)
+            }
+            tidx[ci] = 0;
             int seek_delta = s.seek_delta;
             const bool is_no_speech = (s.no_speech_prob > p->no_speech_thold && avg_logprobs < p->logprob_thold);
             if (n_tok > 0 && !is_no_speech) {

@@ -90,8 +90,10 @@ struct SkwSeqState {
     float min_margin;
     int32_t cur_token;     // token to feed next
     int32_t cur_pos;       // its position
-    int32_t pad[2];
+    float temperature;     // 0: argmax; > 0: logits / t, then a std::discrete_distribution draw from the clip's mt19937
+    int32_t pad;
 };
+#define SKW_RNG_WORDS 625   // std::mt19937 state per clip: mt[624] + index
 struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum; };
 struct SkwLogitParams {
     int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
@@ -102,7 +104,10 @@ struct SkwLogitParams {
 };
 // whisper_process_logits + whisper_sample_token(best) + the per-token state update of whisper_full_with_state.
 // logits: [B][n_vocab] (modified in place), static_mask: [n_vocab] bytes (1 = always suppressed: specials, langs, nst list when enabled)
-void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active, hipStream_t s);
+// probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]]
+void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
+                    float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s);
+void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip
 
 // ---------------- resampler (R1) ----------------
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,

@@ -1139,8 +1139,40 @@ __device__ void block_lse(const float* lg, int lo, int hi, float* sh_f, double* 
     *out_lse = (acc > 0.0) ? skw_logf((float)acc) + m : -INFINITY;
 }
 
+// std::mt19937 / std::generate_canonical<double,53> / std::discrete_distribution as libstdc++ implements them (restated in
+// oracle/skw_oracle.c, pinned there against the real library); run by one lane: the f64 sums are sequential by definition.
+__global__ void k_rng_seed(uint32_t* rng_all, uint32_t seed) {
+    uint32_t* mt = rng_all + (long)blockIdx.x * SKW_RNG_WORDS;
+    mt[0] = seed; for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    mt[624] = 624;
+}
+void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s) { hipLaunchKernelGGL(k_rng_seed, dim3(n_clips), dim3(1), 0, s, rng, seed); }
+__device__ uint32_t mt_next(uint32_t* mt) {
+    int idx = (int)mt[624];
+    if (idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        idx = 0;
+    }
+    uint32_t y = mt[idx]; mt[624] = (uint32_t)(idx + 1);
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+__device__ int discrete_draw(const float* probs, int n, uint32_t* mt) {
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += (double)probs[i];
+    double cs = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; ++k) { cs += (double)mt_next(mt) * tmp; tmp *= 4294967296.0; }
+    double u = cs / tmp; if (u >= 1.0) u = 0.99999999999999988897769753748;   // nextafter(1.0, 0.0)
+    double cp = 0.0;
+    for (int i = 0; i < n; ++i) { cp += (double)probs[i] / sum; if (i == n - 1) cp = 1.0; if (!(cp < u)) return i; }
+    return n - 1;
+}
+
 __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
-                                                     int max_tok, int* n_active) {
+                                                     int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx) {
     __shared__ float sh_f[16]; __shared__ double sh_d[16]; __shared__ ArgBest sh_a[16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     SkwSeqState* st = &st_all[b];
@@ -1155,6 +1187,8 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
         block_lse(lg, 0, NV, sh_f, sh_d, &mx, &lse);
         if (tid == 0) st->no_speech_prob = skw_expf(lg[p.tok_nosp] - lse);
     }
+    const float temperature = st->temperature;
+    if (temperature > 0.0f) { __syncthreads(); for (int i = tid; i < NV; i += nt) lg[i] = lg[i] / temperature; __syncthreads(); }   // before any filter
     const int last_id = n_tok > 0 ? toks[n_tok - 1].id : -1;
     const int pen_id = n_tok > 1 ? toks[n_tok - 2].id : -1;
     const bool last_ts = n_tok > 0 && last_id >= p.tok_beg;
@@ -1191,10 +1225,14 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
     // best token over probs = expf(logprob), first index wins ties; timestamp statistics
     ArgBest best = {0.0f, 0}, bts = {0.0f, 0x7fffffff};
     double sum_ts = 0.0; float top1 = -INFINITY, top2 = -INFINITY;
+    const bool sampled = temperature > 0.0f;
+    float* probs = probs_all + (long)b * NV;
+    if (sampled) { for (int i = tid; i < NV; i += nt) probs[i] = 0.0f; __syncthreads(); }   // (the loop below starts at lo: another thread owns the entry)
     for (int i = lo + tid; i < NV; i += nt) {
         float v = lg[i];
         if (v > -INFINITY) {
             float pr = skw_expf(v - lse);
+            if (sampled) probs[i] = pr;
             ArgBest c = {pr, i}; if (pr > best.v || (pr == best.v && i < best.i)) best = c;
             if (i >= p.tok_beg) { sum_ts += (double)pr; if (pr > bts.v || (pr == bts.v && pr > 0.0f && i < bts.i)) { bts.v = pr; bts.i = i; } }
             if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
@@ -1207,11 +1245,14 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
     float t1 = block_max(top1, sh_f);
     float cand = (top1 == t1) ? top2 : top1;   // exact duplicates of the max report a margin of 0 via top2 only within a thread; fine for diagnostics
     float t2 = block_max(cand, sh_f);
+    if (sampled) { __threadfence_block(); __syncthreads(); }
     if (tid != 0) return;
-    SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = lg[best.i] - lse;
+    SkwTokenOut tk; tk.id = best.i; tk.p = best.v;
+    if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; }
+    tk.plog = lg[tk.id] - lse;
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
-    if (t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;
+    if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
     const int i = n_tok;
     if (i < max_tok) toks[i] = tk;
     st->n_tokens = i + 1;
@@ -1236,8 +1277,9 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
     st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
     if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
 }
-void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active);
+void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
+                    float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
 }
 
 // ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)

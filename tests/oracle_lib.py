@@ -17,7 +17,8 @@ class Params(C.Structure):
     _fields_ = [("lang_id", C.c_int32), ("translate", C.c_int32), ("suppress_blank", C.c_int32), ("suppress_nst", C.c_int32),
                 ("no_timestamps", C.c_int32), ("single_segment", C.c_int32), ("max_tokens", C.c_int32),
                 ("max_initial_ts", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float),
-                ("no_speech_thold", C.c_float), ("n_threads", C.c_int32)]
+                ("no_speech_thold", C.c_float), ("n_threads", C.c_int32),
+                ("temperature", C.c_float), ("temperature_inc", C.c_float)]
 
 
 class Segment(C.Structure):

@@ -161,3 +161,45 @@ def test_hf_whisper_crosscheck(tiny_model_path, oracle_tiny):
     sig = logits_h.std()
     assert np.abs(logits_h - logits_o).max() < 0.1 * sig, (np.abs(logits_h - logits_o).max(), sig)
     assert np.corrcoef(logits_h, logits_o)[0, 1] > 0.999
+
+
+def test_discrete_distribution_restatement_matches_libstdcxx(tmp_path):
+    """The fallback passes sample with std::discrete_distribution over std::mt19937; the oracle restates both (skw_oracle.c).
+    Pin the restatement against the real library: tests/cpp/discrete_ref.cpp compiled with g++ here."""
+    import ctypes as C
+    import subprocess
+    exe = str(tmp_path / "discrete_ref")
+    subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(HERE, "cpp", "discrete_ref.cpp")])
+    rng = np.random.default_rng(7)
+    lib = oracle_lib.lib()
+    for seed, n, kind in [(0, 51865, "peaked"), (0, 1000, "flat"), (5, 37, "sparse"), (123, 4096, "tiny")]:
+        if kind == "peaked":
+            lg = rng.normal(0, 4, n).astype(np.float32); w = np.exp(lg - lg.max()).astype(np.float32); w[rng.random(n) < 0.3] = 0.0
+        elif kind == "flat":
+            w = np.ones(n, np.float32)
+        elif kind == "sparse":
+            w = np.zeros(n, np.float32); w[[3, 17, 36]] = [0.25, 0.5, 0.25]
+        else:
+            w = (rng.random(n) * 1e-30).astype(np.float32)
+        n_draws = 700   # crosses the 624-word twist boundary (2 words per draw)
+        inp = "%d %d %d\n%s\n" % (seed, n_draws, n, " ".join(repr(float(x)) for x in w))
+        ref = [int(x) for x in subprocess.check_output([exe], input=inp.encode()).split()]
+        out = (C.c_int32 * n_draws)()
+        lib.skwo_discrete_draw(w.ctypes.data_as(C.c_void_p), n, C.c_uint32(seed), n_draws, out)
+        assert list(out) == ref, kind
+
+
+def test_temperature_ladder_in_oracle(micro_model_path):
+    """Thresholds that no pass can meet walk the whole ladder (0, 0.2 .. 1.0) and keep the last pass; with the ladder off only the greedy pass runs."""
+    om = oracle_lib.OracleModel(micro_model_path)
+    pcm = synth.clip(3, 16000 * 12)
+    base = om.full(pcm)
+    assert base["fallback_requested"] == 0
+    p = om.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0      # avg_logprobs < 1 always; no_speech_prob < 2 always
+    lad = om.full(pcm, p)
+    assert lad["fallback_requested"] == 6 * lad["n_windows"]
+    assert lad["n_decode_steps"] > base["n_decode_steps"]
+    p.temperature_inc = 0.0
+    off = om.full(pcm, p)
+    assert off["fallback_requested"] == off["n_windows"] and [t[0] for t in off["tokens"]] == [t[0] for t in base["tokens"]]
+    assert [t[0] for t in lad["tokens"]] != [t[0] for t in base["tokens"]] or lad["n_windows"] != base["n_windows"]   # sampled at t = 1.0

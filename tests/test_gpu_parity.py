@@ -173,3 +173,38 @@ def test_full_size_batch_properties(eng, small_model_path):
     for c in (0, 41):
         assert _same(res[c], om.full(pcms[c], po)), c
     ctx.close(); m.close()
+
+
+def test_temperature_fallback_ladder_matches_oracle(tiny):
+    """K11's fallback: passes that fail whisper.cpp's acceptance rules are decoded again at t = 0.2 .. 1.0, sampling with
+    std::discrete_distribution semantics from the clip's mt19937.  Thresholds no pass can meet walk the whole ladder."""
+    _, ctx, om = tiny
+    clips = [(1, 16000 * 30), (4, 16000 * 9), (2, 16000 * 30 + 768), (6, 16000 * 4)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    p = ctx.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0
+    po = om.default_params(); po.logprob_thold = 1.0; po.no_speech_thold = 2.0
+    res = ctx.full_batch(pcms, p)
+    for (c, n), pcm, rg in zip(clips, pcms, res):
+        ro = om.full(pcm, po)
+        assert ro["fallback_requested"] == 6 * ro["n_windows"] and ro["n_windows"] > 0
+        assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
+        assert [t[2] for t in rg["tokens"]] == [t[2] for t in ro["tokens"]]          # sampled-token probabilities, bit for bit
+
+
+def test_fallback_only_for_the_clips_that_need_it(tiny):
+    """A threshold between the clips' average log-probs sends some clips up the ladder while their batch mates keep the greedy pass."""
+    _, ctx, om = tiny
+    clips = [(c, 16000 * 30) for c in range(1, 7)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    base = [om.full(x) for x in pcms]
+    avg = sorted(float(np.mean([t[3] for t in r["tokens"]])) for r in base)
+    thold = 0.5 * (avg[2] + avg[3])
+    p = ctx.default_params(); p.logprob_thold = thold; p.no_speech_thold = 2.0
+    po = om.default_params(); po.logprob_thold = thold; po.no_speech_thold = 2.0
+    res = ctx.full_batch(pcms, p)
+    n_fb = 0
+    for pcm, rg in zip(pcms, res):
+        ro = om.full(pcm, po)
+        assert _same(rg, ro)
+        n_fb += ro["fallback_requested"] > 0
+    assert 0 < n_fb < len(clips)
