@@ -13,6 +13,7 @@
 #define _GNU_SOURCE
 #include "skw_oracle.h"
 #include "../include/skw_math.h"
+#include "../include/skw_ggml_quant.h"
 #include <alloca.h>
 #include <immintrin.h>
 #include <math.h>
@@ -155,7 +156,13 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
         t->name[len] = 0; t->data = xmalloc_f(t->n);
         if (tt == 0) { if (fread(t->data, 4, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } }
         else if (tt == 1) { uint16_t* h = (uint16_t*)malloc(t->n * 2); if (fread(h, 2, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } for (size_t i = 0; i < t->n; ++i) t->data[i] = skw_f16_to_f32(h[i]); free(h); }
-        else { snprintf(err, errlen, "tensor %s: unsupported ggml type %d (quantised models not supported yet)", t->name, tt); return NULL; }
+        else if (skw_ggml_block_bytes(tt) && t->ne[0] % 32 == 0) {   /* block-quantised: decoded here, values rounded to f16 (DEVIATION D4, include/skw_ggml_quant.h) */
+            const size_t bb = skw_ggml_block_bytes(tt), nb = t->n / 32; uint8_t* blk = (uint8_t*)malloc(nb * bb);
+            if (fread(blk, bb, nb, f) != nb) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; }
+            for (size_t i = 0; i < nb; ++i) { skw_ggml_dequant_block(tt, blk + i * bb, t->data + i * 32); for (int j = 0; j < 32; ++j) t->data[i * 32 + j] = skw_round_f16(t->data[i * 32 + j]); }
+            free(blk); t->type = 1;
+        }
+        else { snprintf(err, errlen, "tensor %s: unsupported ggml type %d (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)", t->name, tt); return NULL; }
         nt++;
     }
     fclose(f);

@@ -5,6 +5,7 @@
 //   :354-363 model load, :377-379 state, :624-646 params + full(), :650-660 segment readout.
 #include "../../include/skw_engine.h"
 #include "../../include/skw_math.h"
+#include "../../include/skw_ggml_quant.h"
 #include "skw_kernels.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -169,7 +170,13 @@ extern "C" skw_model* skw_model_load(const char* path, int device, char* err, si
         for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
         t.name.resize(len); if (len && fread(&t.name[0], 1, len, f) != (size_t)len) return fail("short tensor name");
         size_t esz = tt == 0 ? 4 : tt == 1 ? 2 : 0;
-        if (!esz) { std::string msg = "tensor " + t.name + ": unsupported ggml type (quantised models are not supported yet)"; return fail(msg.c_str()); }
+        if (!esz) {   // block-quantised 2-D weights: decoded to f16 here (include/skw_ggml_quant.h, DEVIATION D4)
+            const size_t bb = skw_ggml_block_bytes(tt);
+            if (!bb || t.ne[0] % 32) { std::string msg = "tensor " + t.name + ": unsupported ggml type " + std::to_string(tt) + " (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)"; return fail(msg.c_str()); }
+            std::vector<uint8_t> blocks(t.n / 32 * bb); if (fread(blocks.data(), 1, blocks.size(), f) != blocks.size()) return fail("short tensor data");
+            t.data.resize(t.n * 2); skw_ggml_dequant_to_f16(tt, blocks.data(), t.n, (uint16_t*)t.data.data()); t.type = 1;
+            ts.push_back(std::move(t)); continue;
+        }
         t.data.resize(t.n * esz); if (fread(t.data.data(), 1, t.data.size(), f) != t.data.size()) return fail("short tensor data");
         ts.push_back(std::move(t));
     }

@@ -56,6 +56,16 @@ def synth_model(size, seed=1234):
     return path
 
 
+def quantized_model(size, kind, seed=1234):
+    """The synthetic model re-encoded with block-quantised 2-D weights (tools/quantize_ggml.py), as whisper.cpp's quantize tool lays them out."""
+    src = synth_model(size, seed)
+    path = "/tmp/skw_test_%s_%d_%s.bin" % (size, seed, kind)
+    if not os.path.exists(path):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "quantize_ggml.py"), src, path + ".tmp", kind])
+        os.replace(path + ".tmp", path)
+    return path
+
+
 @pytest.fixture(scope="session")
 def built():
     _ensure_built()

@@ -203,3 +203,18 @@ def test_temperature_ladder_in_oracle(micro_model_path):
     off = om.full(pcm, p)
     assert off["fallback_requested"] == off["n_windows"] and [t[0] for t in off["tokens"]] == [t[0] for t in base["tokens"]]
     assert [t[0] for t in lad["tokens"]] != [t[0] for t in base["tokens"]] or lad["n_windows"] != base["n_windows"]   # sampled at t = 1.0
+
+
+@pytest.mark.parametrize("kind", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_quantised_ggml_is_read_as_its_dequantised_f16_twin(kind, tmp_path):
+    """The reference's default model is ggml-base.en-q5_1.bin.  The loaders decode block-quantised tensors at load time
+    (include/skw_ggml_quant.h); an independent numpy decode of the same file, written back as f16, must transcribe identically."""
+    from conftest import quantized_model
+    from ggml_reader import dequantize_file_to_f16
+    qpath = quantized_model("micro", kind)
+    twin = str(tmp_path / "twin.bin")
+    assert dequantize_file_to_f16(qpath, twin) > 10
+    pcm = synth.clip(5, 16000 * 11)
+    a = oracle_lib.OracleModel(qpath).full(pcm)
+    b = oracle_lib.OracleModel(twin).full(pcm)
+    assert a["tokens"] == b["tokens"] and a["segments"] == b["segments"] and len(a["tokens"]) > 0

@@ -208,3 +208,15 @@ def test_fallback_only_for_the_clips_that_need_it(tiny):
         assert _same(rg, ro)
         n_fb += ro["fallback_requested"] > 0
     assert 0 < n_fb < len(clips)
+
+
+@pytest.mark.parametrize("kind", ["q5_1", "q8_0", "q4_0"])
+def test_quantised_model_file_matches_oracle(eng, kind):
+    """Block-quantised GGML files (the reference's default is a q5_1 file) load through the same dequantise-to-f16 step in the
+    engine and in the oracle: tokens, segments and log-probs identical."""
+    from conftest import quantized_model
+    path = quantized_model("micro", kind)
+    m = eng.Model(path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path)
+    pcms = [synth.clip(c, n) for c, n in [(2, 16000 * 30), (8, 16000 * 7)]]
+    for pcm, rg in zip(pcms, ctx.full_batch(pcms)):
+        assert _same(rg, om.full(pcm)) and len(rg["tokens"]) > 0
