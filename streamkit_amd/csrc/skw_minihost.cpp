@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -133,6 +135,60 @@ int mh_update_params(mh_node* n, const char* json) {
 int mh_flush(mh_node* n) {
     CResult res; std::string emsg; std::thread t([&] { res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n); if (!res.success) emsg = res.error_message ? res.error_message : "Plugin flush failed"; }); t.join();
     if (!emsg.empty()) { n->last_error = emsg; return -1; } return 0;
+}
+// Oneshot batch driver (BASELINE config 2): one pipeline task (thread) per node feeds its clip in `packet`-sample RawAudio packets and
+// flushes when the input closes, all nodes concurrently, as N http requests would.  process_packet runs on the node's own thread
+// (tokio's spawn_blocking hands calls to pooled threads; what matters is one call at a time per instance).  Returns 0 when every
+// call succeeded; wall_ms = first packet in -> last flush returned.
+int mh_run_oneshot(mh_node** nodes, int n_nodes, const float* const* pcm, const size_t* n_samples, size_t packet, double* wall_ms) {
+    std::vector<std::thread> th; std::vector<int> rc(n_nodes, 0);
+    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < n_nodes; ++i) th.emplace_back([&, i] {
+        mh_node* n = nodes[i];
+        for (size_t off = 0; off < n_samples[i] && rc[i] == 0; off += packet) {
+            const size_t cnt = std::min(packet, n_samples[i] - off);
+            CAudioFrame fr; fr.sample_rate = 16000; fr.channels = 1; fr.samples = pcm[i] + off; fr.sample_count = cnt;
+            CPacket pk; pk.packet_type = SK_PACKET_RAW_AUDIO; pk.data = &fr; pk.len = sizeof(CAudioFrame);
+            n->cb_error.clear();
+            CResult res = n->plugin->api->process_packet(n->handle, "in", &pk, out_shim, n, tel_shim, n);
+            if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; n->failed = true; rc[i] = -1; }
+            else if (!n->cb_error.empty()) { n->last_error = n->cb_error; n->failed = true; rc[i] = -1; }
+        }
+        if (rc[i] == 0) { CResult res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n); if (!res.success) { n->last_error = res.error_message ? res.error_message : "Plugin flush failed"; rc[i] = -1; } }
+    });
+    for (auto& t : th) t.join();
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (wall_ms) *wall_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    for (int r : rc) if (r) return -1;
+    return 0;
+}
+// Dynamic-session driver (BASELINE config 4): every node receives its stream in `packet`-sample packets paced at real time (packet k is
+// due at t0 + k * pace_us); the duration of each process_packet call that produced output is that segment's latency (segment end ->
+// transcript: the plugin emits from inside the call that closed the segment).  lat_ms: [n_nodes][max_lat], n_lat: [n_nodes].
+int mh_run_paced(mh_node** nodes, int n_nodes, const float* const* pcm, const size_t* n_samples, size_t packet, long pace_us, double* lat_ms, int max_lat, int* n_lat, double* wall_ms) {
+    std::vector<std::thread> th; std::vector<int> rc(n_nodes, 0);
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto now_us = [&]() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (t.tv_sec - t0.tv_sec) * 1000000L + (t.tv_nsec - t0.tv_nsec) / 1000L; };
+    for (int i = 0; i < n_nodes; ++i) th.emplace_back([&, i] {
+        mh_node* n = nodes[i]; n_lat[i] = 0; long k = 0;
+        for (size_t off = 0; off < n_samples[i] && rc[i] == 0; off += packet, ++k) {
+            const long due = k * pace_us, t = now_us();
+            if (due > t) { struct timespec sl; sl.tv_sec = (due - t) / 1000000L; sl.tv_nsec = ((due - t) % 1000000L) * 1000L; nanosleep(&sl, nullptr); }
+            const size_t cnt = std::min(packet, n_samples[i] - off), before = n->outputs.size();
+            CAudioFrame fr; fr.sample_rate = 16000; fr.channels = 1; fr.samples = pcm[i] + off; fr.sample_count = cnt;
+            CPacket pk; pk.packet_type = SK_PACKET_RAW_AUDIO; pk.data = &fr; pk.len = sizeof(CAudioFrame);
+            n->cb_error.clear();
+            const long a = now_us();
+            CResult res = n->plugin->api->process_packet(n->handle, "in", &pk, out_shim, n, tel_shim, n);
+            const long b = now_us();
+            if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; n->failed = true; rc[i] = -1; }
+            if (n->outputs.size() > before && n_lat[i] < max_lat) lat_ms[(size_t)i * max_lat + n_lat[i]++] = (b - a) * 1e-3;
+        }
+    });
+    for (auto& t : th) t.join();
+    if (wall_ms) *wall_ms = now_us() * 1e-3;
+    for (int r : rc) if (r) return -1;
+    return 0;
 }
 size_t mh_output_count(mh_node* n) { return n->outputs.size(); }
 const char* mh_output_pin(mh_node* n, size_t i) { return n->outputs[i].pin.c_str(); }

@@ -162,8 +162,10 @@ public:
         }
     }
     // additive (flush_tail): hand over whatever speech is buffered when the stream ends
+    // (while a segment is open, the < 512 samples that have not filled a VAD frame yet belong to it too)
     bool take_tail(SegmentCut* out) {
         if (speech_buffer_.empty()) return false;
+        speech_buffer_.insert(speech_buffer_.end(), frame_buffer_.begin(), frame_buffer_.end()); frame_buffer_.clear();
         out->samples.swap(speech_buffer_); speech_buffer_.clear(); out->start_time_ms = segment_start_time_ms_; out->end_time_ms = absolute_time_ms_; out->reason = "flush"; out->segment_id = current_segment_id_;
         current_segment_id_.clear(); silence_frame_count_ = 0; return true;
     }

@@ -51,6 +51,19 @@ def lib():
     return _L
 
 
+def run_oneshot(nodes, pcms, packet=960):
+    """All nodes concurrently, one feeding thread each (mh_run_oneshot): clip i in `packet`-sample packets into node i, then flush.  Returns wall ms."""
+    L = lib()
+    L.mh_run_oneshot.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_double)]
+    L.mh_run_oneshot.restype = C.c_int
+    n = len(nodes)
+    hs = (C.c_void_p * n)(*[x.h for x in nodes]); ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pcms]); ns = (C.c_size_t * n)(*[p.size for p in pcms])
+    ms = C.c_double()
+    if L.mh_run_oneshot(hs, n, ptrs, ns, packet, C.byref(ms)) != 0:
+        raise RuntimeError(str([x.last_error() for x in nodes]))
+    return ms.value
+
+
 class Plugin:
     def __init__(self, path=None):
         path = path or os.path.join(ROOT, "streamkit_amd", "libwhisper.so")

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BASELINE config 2 through the drop-in boundary: N concurrent plugin instances (libwhisper.so, StreamKit native ABI v2), each fed one
+30 s clip in 960-sample RawAudio packets from host memory and flushed, the way N oneshot HTTP requests would drive the reference node.
+Informational: the bench.py headline times the engine with PCM resident in HBM; this adds packet feeding, the 512-sample
+framing, batch formation across instances, H2D copies and JSON building.   usage: python tools/bench_plugin.py [--clips 64] [--size small]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=64); ap.add_argument("--size", default="small"); ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--batch-window-ms", type=float, default=40.0); ap.add_argument("--packet", type=int, default=960)
+    a = ap.parse_args()
+    import torch  # noqa: F401  (libamdhip64 first, as bench.py does)
+    import minihost
+    from conftest import synth_model
+    from streamkit_amd import synth
+    path = synth_model(a.size)
+    plug = minihost.Plugin()
+    pcms = [synth.clip(c) for c in range(a.clips)]
+    params = {"model_path": path, "vad_mode": "always", "flush_tail": True, "max_batch": a.clips, "batch_window_ms": a.batch_window_ms}
+    best = None
+    for rep in range(a.reps + 1):
+        nodes = [plug.create_node(params) for _ in range(a.clips)]              # model load is cached per path (first create pays it; excluded, as in the reference)
+        ms = C.c_double(minihost.run_oneshot(nodes, pcms, a.packet))
+        outs = [n.outputs() for n in nodes]
+        assert all(len(o) == 1 and o[0][1] == 3 for o in outs), [len(o) for o in outs]
+        for n in nodes: n.destroy()
+        if rep > 0: best = ms.value if best is None else min(best, ms.value)     # rep 0 = warm-up
+    audio_s = sum(p.size for p in pcms) / 16000.0
+    n_seg = sum(len(json.loads(o[0][2].decode())["segments"]) for o in outs)
+    print(json.dumps({"what": "plugin-level Oneshot batch (host PCM -> Transcription JSON), %d instances" % a.clips, "value": round(audio_s / (best * 1e-3), 1), "unit": "x real-time",
+                      "wall_ms": round(best, 2), "packet_samples": a.packet, "batch_window_ms": a.batch_window_ms, "segments": n_seg, "model": a.size}))
+
+
+if __name__ == "__main__":
+    main()
