@@ -105,25 +105,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm(SkwGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: 512 16-byte chunks per operand tile, 2 per thread per operand
-    uint4 stA[2], stB[2];
+    // staging: 512 16-byte chunks per operand tile, 2 per thread per operand; buffer loads with hardware range checking (rows past
+    // M / N read as zeros, no branches), per-thread byte offsets fixed up front, the k-block offset in an SGPR
+    u32x4 stA[2], stB[2];
     const int nk = a.K >> 5;
+    const long a_rows = a.a_rows_per_batch ? (long)((a.M - 1) / a.a_rows_per_batch) * a.a_batch_stride + (long)((a.M - 1) % a.a_rows_per_batch) * a.lda : (long)(a.M - 1) * a.lda;
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)((a_rows + a.K) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)(((long)(a.N - 1) * a.ldw + a.K) * 2), 0x00020000);
+    unsigned voA[2], voB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+        int gm = m0 + row, gn = n0 + row;
+        long aoff = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
+        voA[i] = (gm < a.M) ? (unsigned)((aoff + kc * 8) * 2) : 0x7fffff00u;
+        voB[i] = (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kc * 8) * 2) : 0x7fffff00u;
+    }
     auto gload = [&](int kb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int c = tid + 256 * i, row = c >> 2, kc = c & 3;
-            int gm = m0 + row, gn = n0 + row;
-            long aoff = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
-            stA[i] = (gm < a.M) ? *(const uint4*)(a.A + aoff + (kb << 5) + kc * 8) : make_uint4(0, 0, 0, 0);
-            stB[i] = (gn < a.N) ? *(const uint4*)(a.W + (long)gn * a.ldw + (kb << 5) + kc * 8) : make_uint4(0, 0, 0, 0);
+            stA[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[i], kb * 64, 0);
+            stB[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB[i], kb * 64, 0);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int c = tid + 256 * i, row = c >> 2, kc = c & 3;
-            *(uint4*)(&lds[buf][0][row * G_LDS_ROW + kc * 8]) = stA[i];
-            *(uint4*)(&lds[buf][1][row * G_LDS_ROW + kc * 8]) = stB[i];
+            *(u32x4*)(&lds[buf][0][row * G_LDS_ROW + kc * 8]) = stA[i];
+            *(u32x4*)(&lds[buf][1][row * G_LDS_ROW + kc * 8]) = stB[i];
         }
     };
     gload(0); lstore(0); __syncthreads();
