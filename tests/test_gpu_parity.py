@@ -220,3 +220,16 @@ def test_quantised_model_file_matches_oracle(eng, kind):
     pcms = [synth.clip(c, n) for c, n in [(2, 16000 * 30), (8, 16000 * 7)]]
     for pcm, rg in zip(pcms, ctx.full_batch(pcms)):
         assert _same(rg, om.full(pcm)) and len(rg["tokens"]) > 0
+
+
+def test_multi_window_clips_advance_by_timestamps(eng, tiny_model_path):
+    """Clips longer than one 30 s window: the seek loop of whisper_full_with_state (advance by the last timestamp, or by the full
+    window after a single-timestamp ending) runs per clip while its batch mates are at other offsets or already finished."""
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 80); om = OracleModel(tiny_model_path)
+    clips = [(11, 16000 * 75), (12, 16000 * 8), (13, 16000 * 47 + 123)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    res = ctx.full_batch(pcms)
+    for (c, n), pcm, rg in zip(clips, pcms, res):
+        ro = om.full(pcm)
+        assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
+    assert res[0]["n_windows"] >= 3 and res[2]["n_windows"] >= 2 and res[1]["n_windows"] == 1
