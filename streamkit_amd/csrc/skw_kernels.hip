@@ -271,10 +271,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long)row * d;
-    float v[24];
+    float v[24], wv[24], bv[24];
     double sum = 0.0;
+    // the gain / bias loads go out together with the row (a 64-row decode launch is three dependent round trips otherwise)
 #pragma unroll
-    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; float t = (i < d) ? xr[i] : 0.0f; v[c] = t; sum += (double)t; }
+    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; const bool in = i < d; v[c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 24; ++c) sum += (double)v[c];
     sum = wave_sum_f64(sum);
     const float mean = (float)(sum / (double)d);
     double sum2 = 0.0;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int
     for (int c = 0; c < 24; ++c) {
         int i = lane + 64 * c;
         if (i < d) {
-            float t = v[c] * scale; t = t * w[i]; t = t + b[i];
+            float t = v[c] * scale; t = t * wv[c]; t = t + bv[c];
             if (out16) out16[(long)row * d + skw_kperm(i)] = f2h(t);
             if (out32) out32[(long)row * d + i] = t;
         }
