@@ -198,19 +198,35 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
         fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nk) ? oob : ao + j * 64, 0, 0);
         __builtin_amdgcn_sched_barrier(0);    // issue in ring order (the scheduler would issue the first-needed block last)
     }
+    // epilogue operands that do not depend on the chain are fetched now: a 10 us decode kernel cannot afford a dependent memory
+    // round trip (~2-3 us) after its last MFMA
+    const int en = n0 + r16; const bool en_ok = en < a.N;
+    float pre_bias = 0.0f, pre_res[4] = {0.f, 0.f, 0.f, 0.f}; long pre_po[4] = {0, 0, 0, 0};
+    if (EPI != EPI_VT_F16 && a.bias && en_ok) pre_bias = a.bias[en];
+    if (EPI == EPI_F32 && a.res && en_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_res[r] = a.res[(long)m * a.ldres + en]; }
+    }
+    if (EPI == EPI_DEC_QKV && a.pos_ptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_po[r] = (long)a.pos_ptr[(long)m * a.pos_stride] * a.n_ctx; }
+    }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb0 = 0; kb0 < nk; kb0 += SM_DEPTH) {      // branch-free body: the ring stays SM_DEPTH blocks ahead
 #pragma unroll
         for (int j = 0; j < SM_DEPTH; ++j) {
-            H8v cw = fw[j], ca = fa[j];
-            const int nb = kb0 + j + SM_DEPTH;
-            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nk) ? oob : wo + nb * 64, 0, 0);
-            fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nk) ? oob : ao + nb * 64, 0, 0);
             // convert the block's 16 operands first, then issue its 8 MFMAs back to back: a dependent MFMA that directly follows its
             // producer costs 32 cycles, one separated from it by VALU work ~52 (tools/probe/probe_mfma_chain.hip: 56 -> 42 cycles/MFMA)
             float xa[8], xw[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { xa[e] = h2f(ca.h[e]); xw[e] = h2f(cw.h[e]); }
+            for (int e = 0; e < 8; ++e) { xa[e] = h2f(fa[j].h[e]); xw[e] = h2f(fw[j].h[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot only now that it has been read: a copy of the old fragment kept live across the reload makes the
+            // register allocator rotate the whole ring with ~100 v_mov at the loop's back edge behind an s_waitcnt vmcnt(0)
+            // (a full memory latency per trip: K = 3072 ran at 31 us instead of 21)
+            const int nb = kb0 + j + SM_DEPTH;
+            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nk) ? oob : wo + nb * 64, 0, 0);
+            fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nk) ? oob : ao + nb * 64, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = MFMA16(xa[e], xw[e], acc);
@@ -222,7 +238,27 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int m = mt * 16 + kq * 4 + r, n = n0 + r16;
-        if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[r]);
+        if (!(m < a.M && n < a.N)) continue;
+        float v = acc[r];
+        if (EPI == EPI_F32) {                                   // same operations, in the same order, as epi_store<EPI>
+            if (a.bias) v = v + pre_bias;
+            if (a.res) v = v + pre_res[r];
+            ((float*)a.C)[(long)m * a.ldc + n] = v;
+        } else if (EPI == EPI_F16_PLAIN) {
+            if (a.bias) v = v + pre_bias;
+            if (a.has_scale) v = v * a.scale;
+            ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+        } else if (EPI == EPI_GELU_F16_KPERM) {
+            if (a.bias) v = v + pre_bias;
+            ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+        } else if (EPI == EPI_DEC_QKV) {
+            const int d = a.n_ctx;
+            if (a.bias) v = v + pre_bias;
+            if (n < 2 * d) v = v * a.scale;
+            if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+            else if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + pre_po[r] + (n - d)] = f2h(v);
+            else ((half_t*)a.C3)[(long)m * a.ldc2 + pre_po[r] + (n - 2 * d)] = f2h(v);
+        } else epi_store<EPI>(a, m, n, acc[r]);
     }
 }
 
