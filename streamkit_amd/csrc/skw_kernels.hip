@@ -958,6 +958,17 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
     const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
     const half_t* K = kbase + (long)b * batch_stride + h * 64;
     const half_t* V = vbase + (long)b * batch_stride + h * 64;
+    // V rows of the first NPRE keys are requested before anything else waits on memory (their addresses depend on nothing that is
+    // loaded; rows past n_kv exist in the cache and are simply not used): the short-context steps then pay one round trip, not
+    // one per 16 keys after the softmax
+    constexpr int NPRE = (MAXT * 64 < 128) ? MAXT * 64 : 128;
+    const int rows_cap = (int)(batch_stride / ldkv);
+    half_t vpre[NPRE];
+    {
+        const half_t* vp0 = V + lane;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) vpre[u] = vp0[(long)min(u, rows_cap - 1) * ldkv];
+    }
     float qv[64];
     {
         const uint4* qp = (const uint4*)(q + (long)b * ldq + h * 64);
@@ -998,7 +1009,18 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
     float acc = 0.0f;
     const half_t* vp = V + lane;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int g16 = 0; g16 < NPRE / 16; ++g16) {          // keys [0, NPRE) from the prefetched rows, ascending
+        const int pbits = __float_as_int(sc[g16 >> 2]);
+        if (g16 * 16 + 16 <= n_kv) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, (g16 & 3) * 16 + u)), h2f(vpre[g16 * 16 + u]), acc);
+        } else if (g16 * 16 < n_kv) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (g16 * 16 + u < n_kv) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, (g16 & 3) * 16 + u)), h2f(vpre[g16 * 16 + u]), acc);
+        }
+    }
+#pragma unroll
+    for (int t = NPRE / 64; t < MAXT; ++t) {
         if (t * 64 < n_kv) {
             const int nj = min(64, n_kv - t * 64);
             const int pbits = __float_as_int(sc[t]);
