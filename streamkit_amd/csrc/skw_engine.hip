@@ -322,7 +322,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false);
     c->max_tok = hp.n_text_ctx / 2;
-    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, hp.n_vocab, true);
+    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
 #undef WS
     ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
@@ -534,7 +534,8 @@ static void build_static_mask(skw_ctx* c, const skw_full_params* p) {
     mask[m->tok_not] = 1; mask[m->tok_sot] = 1; mask[m->tok_nosp] = 1; mask[m->tok_solm] = 1; mask[m->tok_translate] = 1; mask[m->tok_transcribe] = 1; mask[m->tok_prev] = 1;
     for (int i = 0; i < m->n_lang; ++i) mask[m->tok_sot + 1 + i] = 1;
     if (p->suppress_nst) { for (int id : m->nst_ids) mask[id] = 1; if (m->tok_sp_dash >= 0) mask[m->tok_sp_dash] = 1; if (m->tok_sp_quote >= 0) mask[m->tok_sp_quote] = 1; }
-    hipMemcpyAsync(c->static_mask, mask.data(), mask.size(), hipMemcpyHostToDevice, c->stream); hipStreamSynchronize(c->stream);
+    std::vector<uint8_t> packed(skw_static_mask_bytes(m->hp.n_vocab)); skw_static_mask_pack(mask.data(), m->hp.n_vocab, packed.data());
+    hipMemcpyAsync(c->static_mask, packed.data(), packed.size(), hipMemcpyHostToDevice, c->stream); hipStreamSynchronize(c->stream);
     c->static_mask_nst = p->suppress_nst ? 1 : 0;
 }
 

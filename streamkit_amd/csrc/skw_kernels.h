@@ -104,6 +104,10 @@ struct SkwLogitParams {
 };
 // whisper_process_logits + whisper_sample_token(best) + the per-token state update of whisper_full_with_state.
 // logits: [B][n_vocab] (modified in place), static_mask: [n_vocab] bytes (1 = always suppressed: specials, langs, nst list when enabled)
+// static_mask buffer = n_vocab bytes (1 = always suppressed), padded to 16, followed by the same bits transposed for the sampling
+// kernel's thread layout (two 64-bit words per thread); build it on the host with skw_static_mask_pack
+size_t skw_static_mask_bytes(int n_vocab);
+void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
 // probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]]
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s);

@@ -9,6 +9,7 @@
 //   k_attn_encoder     KQ = mul_mat(K,Q); soft_max_ext; mul_mat(V, KQ_soft_max) (K4)
 //   k_dec_*            whisper_decode_internal pieces (K7-K9), whisper_process_logits + greedy (K11)
 #include "skw_kernels.h"
+#include <cstring>
 #include "../../include/skw_math.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1242,7 +1243,7 @@ __device__ int discrete_draw(const float* probs, int n, uint32_t* mt) {
     return n - 1;
 }
 
-__global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
+__global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
                                                      int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx) {
     __shared__ float sh_f[16]; __shared__ double sh_d[16]; __shared__ ArgBest sh_a[16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -1348,9 +1349,203 @@ __global__ __launch_bounds__(1024) void k_dec_sample(float* logits_all, const ui
     st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
     if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
 }
+// Register-resident form: the row's logits (<= 104 per thread) are loaded once, every pass of whisper_process_logits then runs on
+// registers -- the streaming form above re-reads the row from L2 six times with nothing to overlap the latency (90 us per step).
+// Same operations per logit; skw_expf(-inf) == 0, so suppressed logits need no branches; exponentials go two at a time through
+// packed math; f64 partial sums are grouped differently, which the f64 accumulation makes immaterial (D1).
+#define SMP_PT 104
+#define SMP_NT 512      // 8 waves: 2 per SIMD, so the 104 resident logits fit the 256-VGPR budget
+struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; float top1, top2; };
+// element index of slot c: recomputed inside each pass from a value the optimiser cannot see through -- shared across passes, the
+// ~100 indices would stay live for the whole kernel and push the logits into scratch
+#define SMP_PASS_BEGIN { int tq = tid; asm volatile("" : "+v"(tq));
+#define SMP_PASS_END }
+#define SMP_IDX(c) (tq + SMP_NT * (c))
+__global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
+                                                       int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx) {
+    __shared__ float sh_f[2][SMP_NT / 64]; __shared__ double sh_d[SMP_NT / 64]; __shared__ SmpMain sh_m[SMP_NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    SkwSeqState* st = &st_all[b];
+    if (!st->active) return;   // uniform per block
+    float* lg = logits_all + (long)b * p.n_vocab;
+    const int NV = p.n_vocab;
+    SkwTokenOut* toks = toks_all + (long)b * max_tok;
+    const int n_tok = st->n_tokens;
+    const bool is_initial = n_tok == 0;
+    float v[SMP_PT]; unsigned long long killbits[2];
+    { const unsigned long long* kw = (const unsigned long long*)(static_mask + ((NV + 15) & ~15)); killbits[0] = kw[tid]; killbits[1] = kw[SMP_NT + tid]; }
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) {
+        if (SMP_NT * (c + 1) <= NV) v[c] = lg[tid + SMP_NT * c];                                  // whole stripe inside the row (uniform test)
+        else { const int i = tid + SMP_NT * c; v[c] = (i < NV) ? lg[i] : -INFINITY; }
+    }
+    const int last_id = n_tok > 0 ? toks[n_tok - 1].id : -1;
+    const int pen_id = n_tok > 1 ? toks[n_tok - 2].id : -1;
+    const float temperature = st->temperature;
+    const int has_ts = st->has_ts; const int ts_lo = has_ts ? p.tok_beg + st->seek_delta / 2 : 0;
+    auto bmax2 = [&](float a, float c2, float* oa, float* oc) {     // two block-wide maxima with one exchange
+        for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); c2 = fmaxf(c2, __shfl_xor(c2, o, 64)); }
+        if (lane == 0) { sh_f[0][w] = a; sh_f[1][w] = c2; }
+        __syncthreads();
+        float ra = sh_f[0][0], rc = sh_f[1][0];
+        for (int k = 1; k < SMP_NT / 64; ++k) { ra = fmaxf(ra, sh_f[0][k]); rc = fmaxf(rc, sh_f[1][k]); }
+        __syncthreads();
+        *oa = ra; *oc = rc;
+    };
+    float dummy;
+    if (is_initial) {   // no_speech_prob from the unfiltered distribution
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) m = fmaxf(m, v[c]);
+        bmax2(m, m, &m, &dummy);
+        double acc0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < SMP_PT; c += 2) {
+            f32x2 e = expf_nonpos_x2((f32x2){v[c], v[c + 1]} - (f32x2){m, m}); acc0 += (double)e[0]; acc0 += (double)e[1];
+            if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from overlapping dozens of exponentials and spilling
+        }
+        acc0 = block_sum_f64(acc0, sh_d);
+        const float lse0 = (acc0 > 0.0) ? skw_logf((float)acc0) + m : -INFINITY;
+        SMP_PASS_BEGIN
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) if (SMP_IDX(c) == p.tok_nosp) st->no_speech_prob = skw_expf(v[c] - lse0);
+        SMP_PASS_END
+    }
+    if (temperature > 0.0f) {
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) v[c] = v[c] / temperature;      // before any filter
+    }
+    const bool last_ts = n_tok > 0 && last_id >= p.tok_beg;
+    const bool pen_ts = n_tok < 2 || pen_id >= p.tok_beg;
+    SMP_PASS_BEGIN
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) {
+        const int i = SMP_IDX(c);
+        bool kill = (killbits[c >> 6] >> (c & 63)) & 1;
+        if (is_initial && p.suppress_blank && (i == p.tok_eot || i == p.tok_space)) kill = true;
+        if (p.no_timestamps && i >= p.tok_beg) kill = true;
+        if (last_ts) { if (pen_ts) { if (i >= p.tok_beg) kill = true; } else { if (i < p.tok_eot) kill = true; } }
+        if (is_initial && p.tid0_initial >= 0 && i >= p.tok_beg + p.tid0_initial + 1) kill = true;
+        if (has_ts && i >= p.tok_beg && i < ts_lo) kill = true;
+        if (kill) v[c] = -INFINITY;
+    }
+    SMP_PASS_END
+    // log-softmax statistics of the admissible logits
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) mx = fmaxf(mx, v[c]);
+    bmax2(mx, mx, &mx, &dummy);
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < SMP_PT; c += 2) {
+        f32x2 e = expf_nonpos_x2((f32x2){v[c], v[c + 1]} - (f32x2){mx, mx}); acc += (double)e[0]; acc += (double)e[1];
+        if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+    }
+    acc = block_sum_f64(acc, sh_d);
+    const float lse = (acc > 0.0) ? skw_logf((float)acc) + mx : -INFINITY;
+    // timestamp mass rule, on logprobs = logits - lse
+    float m_ts = -INFINITY, max_text = -INFINITY;
+    SMP_PASS_BEGIN
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) { const float lp = v[c] - lse; if (SMP_IDX(c) >= p.tok_beg) m_ts = fmaxf(m_ts, lp); else max_text = fmaxf(max_text, lp); }
+    SMP_PASS_END
+    bmax2(m_ts, max_text, &m_ts, &max_text);
+    double acc_ts = 0.0;
+    SMP_PASS_BEGIN
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) {
+        if (SMP_NT * (c + 1) > p.tok_beg) {     // (uniform) only the last few stripes reach the timestamp range
+            const float e = skw_expf((v[c] - lse) - m_ts);
+            if (SMP_IDX(c) >= p.tok_beg) acc_ts += (double)e;
+        }
+    }
+    SMP_PASS_END
+    acc_ts = block_sum_f64(acc_ts, sh_d);
+    const float ts_logprob = (acc_ts > 0.0) ? skw_logf((float)acc_ts) + m_ts : -INFINITY;
+    const bool force_ts = ts_logprob > max_text;
+    if (force_ts) {
+        SMP_PASS_BEGIN
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) if (SMP_IDX(c) < p.tok_beg) v[c] = -INFINITY;
+        SMP_PASS_END
+    }
+    // best token over probs = expf(logprob), first index wins ties; timestamp statistics; top-2 margin
+    const bool sampled = temperature > 0.0f;
+    float* probs = probs_all + (long)b * NV;
+    SmpMain r; r.best = {0.0f, 0}; r.best_logit = -INFINITY; r.bts = {0.0f, 0x7fffffff}; r.sum_ts = 0.0; r.top1 = -INFINITY; r.top2 = -INFINITY;
+    SMP_PASS_BEGIN
+#pragma unroll
+    for (int c = 0; c < SMP_PT; c += 2) {
+        const f32x2 e2 = expf_nonpos_x2((f32x2){v[c], v[c + 1]} - (f32x2){lse, lse});     // 0 for suppressed logits: they can win nothing below
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = SMP_IDX(c + u); const float x = v[c + u]; const float pr = e2[u];
+            if (pr > r.best.v || (pr == r.best.v && i < r.best.i)) { r.best.v = pr; r.best.i = i; r.best_logit = x; }
+            if (i >= p.tok_beg) { r.sum_ts += (double)pr; if (pr > r.bts.v || (pr == r.bts.v && pr > 0.0f && i < r.bts.i)) { r.bts.v = pr; r.bts.i = i; } }
+            if (x > r.top1) { r.top2 = r.top1; r.top1 = x; } else if (x > r.top2) r.top2 = x;
+            if (sampled && i < NV) { probs[i] = pr; lg[i] = x; }     // the draw (one lane, below) walks the row in memory
+        }
+        if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+    }
+    SMP_PASS_END
+    auto comb = [](SmpMain a, const SmpMain& c2) {
+        if (c2.best.v > a.best.v || (c2.best.v == a.best.v && c2.best.i < a.best.i)) { a.best = c2.best; a.best_logit = c2.best_logit; }
+        a.bts = better(a.bts, c2.bts); a.sum_ts += c2.sum_ts;
+        if (c2.top1 > a.top1) { a.top2 = fmaxf(a.top1, c2.top2); a.top1 = c2.top1; } else a.top2 = fmaxf(a.top2, c2.top1);
+        return a;
+    };
+    for (int o = 32; o > 0; o >>= 1) {
+        SmpMain y;
+        y.best.v = __shfl_xor(r.best.v, o, 64); y.best.i = __shfl_xor(r.best.i, o, 64); y.best_logit = __shfl_xor(r.best_logit, o, 64);
+        y.bts.v = __shfl_xor(r.bts.v, o, 64); y.bts.i = __shfl_xor(r.bts.i, o, 64); y.sum_ts = __shfl_xor(r.sum_ts, o, 64);
+        y.top1 = __shfl_xor(r.top1, o, 64); y.top2 = __shfl_xor(r.top2, o, 64);
+        r = comb(r, y);
+    }
+    if (lane == 0) sh_m[w] = r;
+    if (sampled) __threadfence_block();
+    __syncthreads();
+    if (tid != 0) return;
+    r = sh_m[0]; for (int k = 1; k < SMP_NT / 64; ++k) r = comb(r, sh_m[k]);
+    const ArgBest best = r.best, bts = r.bts; const double sum_ts = r.sum_ts; const float t1 = r.top1, t2 = r.top2;
+    SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = r.best_logit - lse;
+    if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
+    tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
+    if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
+    if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
+    const int i = n_tok;
+    if (i < max_tok) toks[i] = tk;
+    st->n_tokens = i + 1;
+    int failed = 0, completed = 0;
+    if (tk.id > p.tok_beg) {
+        const int sd_new = 2 * (tk.id - p.tok_beg);
+        if (st->has_ts && st->seek_delta > sd_new && st->result_len < i) failed = 1;
+        else { st->seek_delta = sd_new; st->result_len = i + 1; st->has_ts = 1; }
+    }
+    if (!failed && (tk.id == p.tok_eot || (p.max_tokens > 0 && i >= p.max_tokens) || (st->has_ts && st->seek + st->seek_delta + 100 >= st->seek_end))) {
+        if (st->result_len == 0 && !p.no_timestamps) {
+            if (st->seek + st->seek_delta + 100 >= st->seek_end) st->result_len = i + 1; else failed = 1;
+        }
+        if (!failed) {
+            if (p.single_segment || p.no_timestamps) { st->result_len = i + 1; st->seek_delta = 100 * 30; }
+            completed = 1;
+        }
+    }
+    if (!failed && !completed && i == p.n_max - 1 && (st->result_len == 0 || st->seek_delta < 100 * 30 / 2)) failed = 1;
+    if (!failed && !completed && i + 1 >= p.n_max) completed = 1;   // loop bound reached (whisper.cpp leaves the for loop)
+    st->failed = failed; st->completed = completed;
+    st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
+    if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
+}
+size_t skw_static_mask_bytes(int n_vocab) { return (size_t)((n_vocab + 15) & ~15) + 2 * SMP_NT * sizeof(unsigned long long); }
+void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
+    memset(out, 0, skw_static_mask_bytes(n_vocab)); memcpy(out, mask, n_vocab);
+    unsigned long long* kw = (unsigned long long*)(out + ((n_vocab + 15) & ~15));
+    for (int i = 0; i < n_vocab && i < SMP_PT * SMP_NT; ++i) if (mask[i]) { const int t = i % SMP_NT, c = i / SMP_NT; kw[(c >> 6) * SMP_NT + t] |= 1ull << (c & 63); }
+}
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
+    if (p.n_vocab <= SMP_PT * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
+    else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
 }
 
 // ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)
