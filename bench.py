@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--size", default="small")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on a one-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -40,19 +42,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    file_rank = local_rank
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     # model (random-init weights of the Whisper-small architecture in whisper.cpp's GGML container; not timed)
     tool = os.path.join(ROOT, "tools", "make_synth_model")
     if not os.path.exists(tool):
         subprocess.check_call(["gcc", "-O2", "-o", tool, tool + ".c", "-lm"])
-    path = "/tmp/skw_bench_%s_r%d.bin" % (args.size, local_rank)
+    path = "/tmp/skw_bench_%s_r%d.bin" % (args.size, file_rank)
     subprocess.check_call([tool, path, "--size", args.size, "--seed", "1234"])
     model = engine.Model(path, device=local_rank)
     B = args.clips
@@ -74,7 +82,7 @@ def main():
     def step():
         res = ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
         if world > 1:   # the one exchange step: fixed-size int32 token buffers to every rank over RCCL
-            skd.gather_tokens(skd.pack_tokens(res), world, device=torch.device("cuda", local_rank))
+            skd.gather_tokens(skd.pack_tokens(res), world, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
         return res
 
     def barrier():
@@ -91,7 +99,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     timing = ctx.timing()
