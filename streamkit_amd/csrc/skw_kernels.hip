@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
         const half_t* qp = Qh + (bh * Tpad + qi) * 64 + g * 8;
         H8v a, c; a.v = *(const u32x4*)qp; c.v = *(const u32x4*)(qp + 32);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { qf[e] = h2f(a.h[e]); qf[8 + e] = h2f(c.h[e]); }
+        // the softmax scale 64^-1/2 = 2^-3 is folded into Q: scaling by a power of two commutes with every rounding of the fma chain
+        // (no product of two f16 values comes near the f32 subnormal range), so chain(q/8, k) == chain(q, k) * 0.125f bit for bit
+        for (int e = 0; e < 8; ++e) { qf[e] = h2f(a.h[e]) * kq_scale; qf[8 + e] = h2f(c.h[e]) * kq_scale; }
     }
     const int kappa = 4 * (r16 & 3) + (r16 >> 2);  // MFMA row rho of a 16-key tile holds key kappa(rho): keeps the P.V chain ascending
     __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
     auto finish_tile = [&](int t, f32x4 a) {      // t = tile index of `a`
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = a[r] * kq_scale;
+            float v = a[r];
             if (t == NT - 1) v = (t * 16 + 4 * r + g < n_ctx) ? v : -INFINITY;     // only the last tile can reach past n_ctx (host checks Tpad - n_ctx < 16)
             a[r] = v; rmax = fmaxf(rmax, v);
         }
