@@ -654,6 +654,24 @@ __device__ __forceinline__ f32x2 expf_nonpos_x2(f32x2 x) {
     o[1] = (x[1] >= -86.0f) ? __builtin_ldexpf(y[1], (int)n[1]) : 0.0f;
     return o;
 }
+// The same without the x >= -86 -> 0 clamp, for finite arguments inside a softmax: below -86 the unclamped value is some
+// e < 2^-124 (or 0) instead of exactly 0, which neither the f64 row sum (>= 1: the row maximum contributes exp(0)) nor
+// P = f16(e / sum) can see.  Not for -inf (masked keys): the reduction would produce NaN.
+__device__ __forceinline__ f32x2 expf_nonpos_x2_softmax(f32x2 x) {
+    f32x2 t = x * (f32x2){1.44269504088896341f, 1.44269504088896341f};
+    f32x2 n = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
+    f32x2 r = __builtin_elementwise_fma(n, (f32x2){-0.693359375f, -0.693359375f}, x);
+    r = __builtin_elementwise_fma(n, (f32x2){2.12194440e-4f, 2.12194440e-4f}, r);
+    f32x2 p = {1.9875691500e-4f, 1.9875691500e-4f};
+    p = __builtin_elementwise_fma(p, r, (f32x2){1.3981999507e-3f, 1.3981999507e-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){8.3334519073e-3f, 8.3334519073e-3f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){4.1665795894e-2f, 4.1665795894e-2f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){1.6666665459e-1f, 1.6666665459e-1f});
+    p = __builtin_elementwise_fma(p, r, (f32x2){5.0000001201e-1f, 5.0000001201e-1f});
+    f32x2 r2 = r * r;
+    f32x2 y = __builtin_elementwise_fma(p, r2, r) + (f32x2){1.0f, 1.0f};
+    return (f32x2){__builtin_ldexpf(y[0], (int)n[0]), __builtin_ldexpf(y[1], (int)n[1])};
+}
 template <int NT, int RT>
 __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
                                                             int H, int n_ctx, int Tpad, float kq_scale, int qtiles) {
@@ -743,7 +761,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         f32x4 v = (t < RT) ? sreg[t < RT ? t : 0] : slds[(t - RT) * 64];
-        f32x2 e0 = expf_nonpos_x2((f32x2){v[0], v[1]} - mx), e1 = expf_nonpos_x2((f32x2){v[2], v[3]} - mx);
+        f32x2 e0, e1;
+        if (t == NT - 1) { e0 = expf_nonpos_x2((f32x2){v[0], v[1]} - mx); e1 = expf_nonpos_x2((f32x2){v[2], v[3]} - mx); }      // may hold masked (-inf) keys
+        else { e0 = expf_nonpos_x2_softmax((f32x2){v[0], v[1]} - mx); e1 = expf_nonpos_x2_softmax((f32x2){v[2], v[3]} - mx); }
         rsum += (double)e0[0]; rsum += (double)e0[1]; rsum += (double)e1[0]; rsum += (double)e1[1];
         v = (f32x4){e0[0], e0[1], e1[0], e1[1]};
         if (t < RT) sreg[t < RT ? t : 0] = v; else slds[(t - RT) * 64] = v;
