@@ -262,7 +262,9 @@ extern "C" void skw_full_default_params(skw_full_params* p) {
 }
 
 // ------------------------------------------------------------------ context / workspace
+struct ProfState;
 struct skw_ctx {
+    ProfState* prof = nullptr;                       // per-kernel-class event timing (skw_ctx_profile); per context: contexts run on different host threads
     skw_model* m = nullptr; int max_batch = 0, max_samples = 0, n_len_max = 0, Tpad = 0;
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     hipStream_t cur = nullptr;                       // stream the launch helpers enqueue on (== stream outside the decode groups)
@@ -331,8 +333,10 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     hipDeviceSynchronize();
     return c;
 }
+static void prof_free(skw_ctx* c);
 extern "C" void skw_ctx_free(skw_ctx* c) {
     if (!c) return; hipSetDevice(c->m->device);
+    prof_free(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& sg : c->step_graphs) hipGraphExecDestroy(sg.exec);
     c->step_graphs.clear();
@@ -374,7 +378,7 @@ enum ProfClass { PC_GEMM = 0, PC_GEMM_SMALL, PC_ATTN_ENC, PC_LAYERNORM, PC_MEL, 
 static const char* const g_prof_names[PC_COUNT] = {"k_gemm", "k_gemm_smallm", "k_attn_encoder", "k_layernorm", "k_mel", "k_dec_attn", "k_dec_sample", "other"};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
 struct ProfState { bool on = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t next = 0; double ms[PC_COUNT] = {}, flops[PC_COUNT] = {}, bytes[PC_COUNT] = {}; long count[PC_COUNT] = {}; };
-static std::map<skw_ctx*, ProfState> g_prof;
+static void prof_free(skw_ctx* c) { if (!c->prof) return; for (hipEvent_t e : c->prof->pool) hipEventDestroy(e); delete c->prof; c->prof = nullptr; }
 struct ProfScope {
     ProfState* ps; skw_ctx* c; size_t idx;
     ProfScope(skw_ctx* c_, int cls, double flops, double bytes);
@@ -383,22 +387,22 @@ struct ProfScope {
 
 // ------------------------------------------------------------------ GEMM helpers
 ProfScope::ProfScope(skw_ctx* c_, int cls, double flops, double bytes) : ps(nullptr), c(c_), idx(0) {
-    auto it = g_prof.find(c_); if (it == g_prof.end() || !it->second.on) return;
-    ps = &it->second;
+    if (!c_->prof || !c_->prof->on) return;
+    ps = c_->prof;
     auto get = [&]() { if (ps->next == ps->pool.size()) { hipEvent_t e; hipEventCreate(&e); ps->pool.push_back(e); } return ps->pool[ps->next++]; };
     ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get(); idx = ps->recs.size(); ps->recs.push_back(r);
     hipEventRecord(r.a, c->cur);
 }
 ProfScope::~ProfScope() { if (ps) hipEventRecord(ps->recs[idx].b, c->cur); }
 static void prof_collect(skw_ctx* c) {
-    auto it = g_prof.find(c); if (it == g_prof.end() || !it->second.on) return; ProfState& ps = it->second;
+    if (!c->prof || !c->prof->on) return; ProfState& ps = *c->prof;
     hipStreamSynchronize(c->stream);
     for (auto& r : ps.recs) { float ms = 0; hipEventElapsedTime(&ms, r.a, r.b); ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
     ps.recs.clear(); ps.next = 0;
 }
-extern "C" void skw_ctx_profile(skw_ctx* c, int on) { ProfState& ps = g_prof[c]; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0; ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
+extern "C" void skw_ctx_profile(skw_ctx* c, int on) { if (!c->prof) c->prof = new ProfState(); ProfState& ps = *c->prof; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0; ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
 extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_len, long* count, double* ms, double* flops, double* bytes) {
-    if (cls < 0 || cls >= PC_COUNT) return -1; ProfState& ps = g_prof[c];
+    if (cls < 0 || cls >= PC_COUNT || !c->prof) return -1; ProfState& ps = *c->prof;
     if (name) snprintf(name, name_len, "%s", g_prof_names[cls]); *count = ps.count[cls]; *ms = ps.ms[cls]; *flops = ps.flops[cls]; *bytes = ps.bytes[cls]; return 0;
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
@@ -618,7 +622,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         }
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
-        const bool profiling = g_prof.count(c) && g_prof[c].on;
+        const bool profiling = c->prof && c->prof->on;
         const int G = profiling ? 1 : std::max(1, std::min(c->n_groups, Bw / 8));
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
         for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; c->h_n_active[g] = g_n[g]; }
