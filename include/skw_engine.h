@@ -39,7 +39,7 @@ typedef struct {
 
 /* the whisper_full_params fields the reference sets (lib.rs:624-641) + the whisper.cpp defaults that shape greedy decoding */
 typedef struct {
-    int32_t lang_id;          /* whisper_lang_id(language); "en" = 0 */
+    int32_t lang_id;          /* whisper_lang_id(language); "en" = 0; < 0 = whisper.cpp's "auto": detected per clip from the first window (multilingual models) */
     int32_t translate;
     int32_t suppress_blank;
     int32_t suppress_nst;
@@ -72,6 +72,7 @@ typedef struct {
     skw_token* tokens;
     char* text;                 /* concatenated segment texts, NUL terminated */
     int32_t text_len;
+    int32_t lang_id;            /* the language decoded with: params.lang_id, or the detected one when that was < 0 */
 } skw_result;
 
 /* ---- lifetime ---- */

@@ -774,6 +774,24 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     int n_len = 0, n_len_org = 0; float* mel = skwo_log_mel(m, pcm, n_samples, &n_len, &n_len_org);
     const int seek_start = 0, seek_end = n_len_org;
     acc_t acc; memset(&acc, 0, sizeof acc);
+    const int NV0 = m->hp.n_vocab;
+    /* language "auto" (whisper_lang_auto_detect_with_state, offset 0): encode the first window, decode [sot], take the language
+     * token with the largest logit (first on a tie); done before the "input is too short" test, as whisper_full_with_state does */
+    int lang_id = p->lang_id;
+    if (lang_id < 0) {
+        if (NV0 < 51865) { free(mel); return -3; }
+        if (n_len_org > 0) {
+            float* eo = xmalloc_f((size_t)m->hp.n_audio_ctx * m->hp.n_audio_state);
+            float* k0 = xmalloc_f((size_t)m->hp.n_text_layer * m->hp.n_audio_ctx * m->hp.n_text_state); float* v0 = xmalloc_f((size_t)m->hp.n_text_layer * m->hp.n_audio_ctx * m->hp.n_text_state);
+            float* lg = xmalloc_f(NV0);
+            skwo_encode(m, mel, n_len, 0, 0, eo, k0, v0);
+            skwo_dec* ds0 = skwo_dec_new(m, k0, v0); int32_t sot = m->tok_sot; skwo_dec_step(ds0, &sot, 1, 0, 0, lg); skwo_dec_free(ds0);
+            const int n_lang = N_LANG + (NV0 - 51865 > 0 ? NV0 - 51865 : 0);
+            lang_id = 0; for (int i = 1; i < n_lang; ++i) if (lg[m->tok_sot + 1 + i] > lg[m->tok_sot + 1 + lang_id]) lang_id = i;
+            free(eo); free(k0); free(v0); free(lg);
+        } else lang_id = 0;
+    }
+    out->lang_id = lang_id;
     if (seek_end < seek_start + 100) { free(mel); return 0; } /* "input is too short" */
     const int d = m->hp.n_text_state, nc = m->hp.n_audio_ctx, NV = m->hp.n_vocab;
     float* enc_out = xmalloc_f((size_t)nc * m->hp.n_audio_state);
@@ -782,7 +800,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     decoder_t dc; memset(&dc, 0, sizeof dc); dc.logits = xmalloc_f(NV); dc.logprobs = xmalloc_f(NV); dc.probs = xmalloc_f(NV); dc.cap = 512; dc.tokens = (skwo_token*)malloc(dc.cap * sizeof(skwo_token)); dc.min_margin = INFINITY;
     int32_t prompt_init[8]; int n_prompt = 0;
     prompt_init[n_prompt++] = m->tok_sot;
-    if (NV >= 51865) { prompt_init[n_prompt++] = m->tok_sot + 1 + p->lang_id; prompt_init[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
+    if (NV >= 51865) { prompt_init[n_prompt++] = m->tok_sot + 1 + lang_id; prompt_init[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
     if (p->no_timestamps) prompt_init[n_prompt++] = m->tok_not;
     int seek = seek_start;
     char* text = (char*)malloc(1 << 16);

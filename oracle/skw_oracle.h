@@ -37,7 +37,7 @@ typedef struct {
 /* whisper_full_params subset that the reference sets (lib.rs:624-641) plus the
  * whisper.cpp defaults that shape greedy decoding */
 typedef struct {
-    int32_t lang_id;            /* index into whisper's language table; "en" = 0 */
+    int32_t lang_id;            /* index into whisper's language table; "en" = 0; < 0 = "auto" (whisper_lang_auto_detect_with_state) */
     int32_t translate;          /* lib.rs:626 -> false */
     int32_t suppress_blank;     /* lib.rs:633 */
     int32_t suppress_nst;       /* lib.rs:634 */
@@ -72,6 +72,7 @@ typedef struct {
     skwo_token* tokens;          /* all result tokens in order (timestamps included) */
     char* text;                  /* concatenated segment texts (no separators) */
     int32_t text_len;
+    int32_t lang_id;             /* language decoded with (detected when params.lang_id < 0) */
 } skwo_result;
 
 skwo_model* skwo_load(const char* path, char* err, int errlen);

@@ -281,6 +281,7 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
     SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; int* n_active = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
     SkwSeqState* h_st = nullptr; SkwTokenOut* h_toks = nullptr; int* h_n_active = nullptr; // pinned
@@ -314,7 +315,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
 #define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
     WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
-    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false);
+    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false); WS(row_tok, int, B, true);
     WS(im2col, half_t, (size_t)B * T * 256, false); WS(h1, half_t, (size_t)B * (T + 2) * d, true);
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
@@ -484,6 +485,14 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
 
 // one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
 __global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; }
+__global__ void k_set_tokens_rows(SkwSeqState* st, const int* tok, int pos) { st[blockIdx.x].cur_token = tok[blockIdx.x]; st[blockIdx.x].cur_pos = pos; }
+// whisper_lang_auto_detect_with_state: the language whose token has the largest logit after the [sot] step (lowest id on a tie)
+__global__ void k_lang_argmax(const float* logits, int n_vocab, int tok_sot, int n_lang, int* out) {
+    const float* lg = logits + (long)blockIdx.x * n_vocab; float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_lang; i += 64) { float v = lg[tok_sot + 1 + i]; if (v > bv) { bv = v; bi = i; } }
+    for (int o = 32; o > 0; o >>= 1) { float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+    if (threadIdx.x == 0) out[blockIdx.x] = bi;
+}
 // rows [r0, r0 + Bw) of the window batch on stream s: sequences are independent, so groups of rows can run on their own streams
 static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logits, hipStream_t s) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int dt = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, ntc = hp.n_text_ctx;
@@ -591,9 +600,27 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && temps.size() < 16; t += p->temperature_inc) temps.push_back(t);
     std::vector<int> tidx(n_clips, 0);
     skw_rng_seed(c->rng, n_clips, 0u, c->stream);   // DEVIATION D2': seeded per call (whisper.cpp: per state, running on across calls)
+    // language: fixed by the caller, or (lang_id < 0, whisper.cpp's "auto") detected per clip from the [sot] step on the first window
+    std::vector<int> lang(n_clips, p->lang_id);
+    if (p->lang_id < 0) {
+        if (NV < 51865) { snprintf(errbuf, 512, "failed to auto-detect language: the model is not multilingual"); return -3; }
+        std::vector<int> act, zero(n_clips, 0); for (int i = 0; i < n_clips; ++i) if (n_len_org[i] > 0) act.push_back(i);
+        const int Bd = (int)act.size();
+        if (Bd > 0) {
+            HIPCHK(hipMemcpyAsync(c->clip_idx, act.data(), sizeof(int) * Bd, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->seek, zero.data(), sizeof(int) * Bd, hipMemcpyHostToDevice, c->stream));
+            run_conv(c, Bd); run_encoder(c, Bd, false, true);
+            hipLaunchKernelGGL(k_set_tokens, dim3(Bd), dim3(1), 0, c->stream, c->st, m->tok_sot, 0);
+            run_decoder_step(c, 0, Bd, 0, true, c->stream);
+            hipLaunchKernelGGL(k_lang_argmax, dim3(Bd), dim3(64), 0, c->stream, c->logits, NV, m->tok_sot, m->n_lang, c->row_tok);
+            std::vector<int> det(Bd); HIPCHK(hipMemcpyAsync(det.data(), c->row_tok, sizeof(int) * Bd, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+            for (int j = 0; j < Bd; ++j) { lang[act[j]] = det[j]; results[act[j]].lang_id = det[j]; }
+        }
+        for (int i = 0; i < n_clips; ++i) if (lang[i] < 0) lang[i] = 0;
+    } else for (int i = 0; i < n_clips; ++i) results[i].lang_id = p->lang_id;
     int32_t prompt[8]; int n_prompt = 0;
     prompt[n_prompt++] = m->tok_sot;
-    if (NV >= 51865) { prompt[n_prompt++] = m->tok_sot + 1 + p->lang_id; prompt[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
+    if (NV >= 51865) { prompt[n_prompt++] = -1 /* per row: sot + 1 + lang[clip] */; prompt[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
     if (p->no_timestamps) prompt[n_prompt++] = m->tok_not;
     SkwLogitParams lp{}; lp.n_vocab = NV; lp.tok_eot = m->tok_eot; lp.tok_sot = m->tok_sot; lp.tok_translate = m->tok_translate; lp.tok_transcribe = m->tok_transcribe; lp.tok_solm = m->tok_solm;
     lp.tok_prev = m->tok_prev; lp.tok_nosp = m->tok_nosp; lp.tok_not = m->tok_not; lp.tok_beg = m->tok_beg; lp.n_lang = m->n_lang; lp.tok_space = m->tok_space; lp.tok_sp_dash = m->tok_sp_dash; lp.tok_sp_quote = m->tok_sp_quote;
@@ -610,6 +637,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         std::vector<int> sk(Bw); for (int j = 0; j < Bw; ++j) sk[j] = seek[act[j]];
         HIPCHK(hipMemcpyAsync(c->clip_idx, act.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->seek, sk.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
+        std::vector<int> ltok(Bw); for (int j = 0; j < Bw; ++j) ltok[j] = m->tok_sot + 1 + lang[act[j]];
+        HIPCHK(hipMemcpyAsync(c->row_tok, ltok.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
         run_conv(c, Bw);
         run_encoder(c, Bw, false, true);
@@ -631,7 +660,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
         for (int t = 0; t < n_prompt; ++t) {
             for (int g = 0; g < G; ++g) {
-                hipLaunchKernelGGL(k_set_tokens, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], prompt[t], t);
+                if (prompt[t] >= 0) hipLaunchKernelGGL(k_set_tokens, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], prompt[t], t);
+                else hipLaunchKernelGGL(k_set_tokens_rows, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], c->row_tok + g_r0[g], t);
                 run_decoder_step(c, g_r0[g], g_n[g], t, t == n_prompt - 1, c->gstream[g]);
             }
             tot_steps++;

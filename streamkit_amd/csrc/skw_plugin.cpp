@@ -190,8 +190,8 @@ bool transcribe_and_emit(WhisperPlugin* self, const Emit& em, const skw::Segment
     auto job = std::make_shared<Job>();
     job->pcm = cut.samples;
     skw_full_default_params(&job->params);
-    int lang = skw_model_lang_id(self->config.language.c_str());
-    if (lang < 0) { *err = "Whisper inference failed: unknown language '" + self->config.language + "'"; return false; }
+    int lang = self->config.language == "auto" ? -1 : skw_model_lang_id(self->config.language.c_str());     // "auto": whisper.cpp detects it from the first window
+    if (lang < 0 && self->config.language != "auto") { *err = "Whisper inference failed: unknown language '" + self->config.language + "'"; return false; }
     job->params.lang_id = lang; job->params.translate = 0;
     job->params.suppress_blank = self->config.suppress_blank ? 1 : 0; job->params.suppress_nst = self->config.suppress_non_speech_tokens ? 1 : 0;
     job->params.n_threads = (int32_t)self->config.n_threads;

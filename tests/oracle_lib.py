@@ -33,7 +33,7 @@ class Token(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_segments", C.c_int32), ("n_tokens", C.c_int32), ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32),
                 ("fallback_requested", C.c_int32), ("min_margin", C.c_float),
-                ("segments", C.POINTER(Segment)), ("tokens", C.POINTER(Token)), ("text", C.c_void_p), ("text_len", C.c_int32)]
+                ("segments", C.POINTER(Segment)), ("tokens", C.POINTER(Token)), ("text", C.c_void_p), ("text_len", C.c_int32), ("lang_id", C.c_int32)]
 
 
 def lib():
@@ -146,7 +146,7 @@ class OracleModel:
         segs = [dict(t0=r.segments[i].t0, t1=r.segments[i].t1, tokens=[t[0] for t in toks[r.segments[i].tok_begin:r.segments[i].tok_end]],
                      text=text[r.segments[i].text_off:r.segments[i].text_off + r.segments[i].text_len]) for i in range(r.n_segments)]
         out = dict(segments=segs, tokens=toks, n_windows=r.n_windows, n_decode_steps=r.n_decode_steps,
-                   fallback_requested=r.fallback_requested, min_margin=r.min_margin)
+                   fallback_requested=r.fallback_requested, min_margin=r.min_margin, lang_id=r.lang_id)
         lib().skwo_result_free(C.byref(r))
         return out
 

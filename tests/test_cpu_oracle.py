@@ -218,3 +218,16 @@ def test_quantised_ggml_is_read_as_its_dequantised_f16_twin(kind, tmp_path):
     a = oracle_lib.OracleModel(qpath).full(pcm)
     b = oracle_lib.OracleModel(twin).full(pcm)
     assert a["tokens"] == b["tokens"] and a["segments"] == b["segments"] and len(a["tokens"]) > 0
+
+
+def test_language_auto_detect_is_consistent_in_oracle(micro_model_path):
+    """language = "auto" (lang_id < 0): whisper_lang_auto_detect_with_state picks the language token with the largest [sot]-step logit
+    on the first window; decoding with that id explicitly must give the same transcript."""
+    om = oracle_lib.OracleModel(micro_model_path)
+    pcm = synth.clip(21, 16000 * 9)
+    p = om.default_params(); p.lang_id = -1
+    auto = om.full(pcm, p)
+    assert 0 <= auto["lang_id"] < 99
+    p.lang_id = auto["lang_id"]
+    fixed = om.full(pcm, p)
+    assert fixed["lang_id"] == auto["lang_id"] and fixed["tokens"] == auto["tokens"] and fixed["segments"] == auto["segments"]

@@ -233,3 +233,20 @@ def test_multi_window_clips_advance_by_timestamps(eng, tiny_model_path):
         ro = om.full(pcm)
         assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
     assert res[0]["n_windows"] >= 3 and res[2]["n_windows"] >= 2 and res[1]["n_windows"] == 1
+
+
+def test_language_auto_detection_matches_oracle(tiny):
+    """lang_id < 0 = whisper.cpp's language "auto": one extra [sot] step on each clip's first window picks its language; clips of one
+    batch may end up with different languages (the prompt's language token is per row)."""
+    _, ctx, om = tiny
+    clips = [(31, 16000 * 12), (32, 16000 * 30), (33, 16000 * 5), (34, 8000)]       # the last one is too short to transcribe but still detected
+    pcms = [synth.clip(c, n) for c, n in clips]
+    p = ctx.default_params(); p.lang_id = -1
+    po = om.default_params(); po.lang_id = -1
+    res = ctx.full_batch(pcms, p)
+    langs = set()
+    for pcm, rg in zip(pcms, res):
+        ro = om.full(pcm, po)
+        assert rg["lang_id"] == ro["lang_id"] and _same(rg, ro)
+        langs.add(rg["lang_id"])
+    assert res[3]["segments"] == []
