@@ -803,6 +803,11 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     if (NV >= 51865) { prompt_init[n_prompt++] = m->tok_sot + 1 + lang_id; prompt_init[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
     if (p->no_timestamps) prompt_init[n_prompt++] = m->tok_not;
     int seek = seek_start;
+    /* prompt_past: text already produced in this call conditions the next window ([prev] + its last n_text_ctx/2 tokens + the
+     * initial prompt) whenever the pass runs at t < 0.5.  whisper_full_default_params sets no_context = true, which only clears
+     * it at the start of a call; n_max_text_ctx keeps its default (16384), so the cap is n_text_ctx/2. */
+    int32_t* prompt_past = (int32_t*)malloc(sizeof(int32_t) * 1024); int n_past_tok = 0;
+    int32_t prompt[512];
     char* text = (char*)malloc(1 << 16);
     mt19937_t rng; mt_seed(&rng, 0);
     while (1) {
@@ -812,13 +817,22 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
         /* temperature ladder (whisper_full_with_state): greedy at t = temperature, then sampled passes at +temperature_inc while a pass fails */
         float temps[16]; int n_temps = 0; temps[n_temps++] = p->temperature;
         if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && n_temps < 16; t += p->temperature_inc) temps[n_temps++] = t;
-        float no_speech_prob = 0.0f;
+        float no_speech_prob = 0.0f; int last_take = 0;
         for (int it = 0; it < n_temps; ++it) {
             const float t_cur = temps[it];
+            int n_prompt_cur = 0, n_take = 0;
+            if (n_past_tok > 0 && t_cur < 0.5f) {
+                n_take = m->hp.n_text_ctx / 2 < n_past_tok ? m->hp.n_text_ctx / 2 : n_past_tok;
+                { const int room = m->hp.n_text_ctx - (m->hp.n_text_ctx / 2 - 4) - n_prompt - 1; if (n_take > room) n_take = room; }   /* only binds with no_timestamps (4-token init): keeps every position inside n_text_ctx */
+                prompt[n_prompt_cur++] = m->tok_prev;
+                for (int i = 0; i < n_take; ++i) prompt[n_prompt_cur++] = prompt_past[n_past_tok - n_take + i];
+            }
+            for (int i = 0; i < n_prompt; ++i) prompt[n_prompt_cur++] = prompt_init[i];
+            last_take = n_take;
             skwo_dec* ds = skwo_dec_new(m, ck, cv);
             dc.n_tokens = 0; dc.result_len = 0; dc.sum_logprobs_all = 0.0; dc.sum_logprobs = -INFINITY; dc.avg_logprobs = -INFINITY; dc.entropy = 0.0; dc.score = -INFINITY;
             dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; dc.has_ts = 0; dc.failed = 0; dc.completed = 0;
-            skwo_dec_step(ds, prompt_init, n_prompt, 0, 0, raw); out->n_decode_steps++;
+            skwo_dec_step(ds, prompt, n_prompt_cur, 0, 0, raw); out->n_decode_steps++;
             process_logits(m, p, &dc, raw, &no_speech_prob, t_cur);
             const int n_max = m->hp.n_text_ctx / 2 - 4;
             for (int i = 0; i < n_max; ++i) {
@@ -841,7 +855,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
                     }
                 }
                 if (i == n_max - 1 && (dc.result_len == 0 || dc.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dc.failed = 1; break; }
-                { int32_t t = tk.id; skwo_dec_step(ds, &t, 1, n_prompt + i, 0, raw); out->n_decode_steps++; }
+                { int32_t t = tk.id; skwo_dec_step(ds, &t, 1, n_prompt_cur + i, 0, raw); out->n_decode_steps++; }
                 process_logits(m, p, &dc, raw, &no_speech_prob, t_cur);
             }
             skwo_dec_free(ds);
@@ -856,6 +870,11 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
         {
             int seek_delta = dc.seek_delta; const int result_len = dc.result_len; const skwo_token* tc = dc.tokens; const int ntc = dc.n_tokens; (void)result_len;
             const int is_no_speech = (no_speech_prob > p->no_speech_thold && dc.avg_logprobs < p->logprob_thold);
+            { /* update prompt_past: what was taken from it for this window's prompt, then this window's tokens (recalled: the !is_no_speech guard) */
+                int32_t keep[512]; for (int i = 0; i < last_take; ++i) keep[i] = prompt_past[n_past_tok - last_take + i];
+                n_past_tok = 0;
+                if (!is_no_speech) { for (int i = 0; i < last_take; ++i) prompt_past[n_past_tok++] = keep[i]; for (int i = 0; i < dc.result_len; ++i) prompt_past[n_past_tok++] = tc[i].id; }
+            }
             if (ntc > 0 && !is_no_speech) {
                 int i0 = 0; int64_t t0 = seek + 2 * (tc[0].tid - m->tok_beg); int tl = 0;
                 for (int i = 0; i < ntc; ++i) {
@@ -876,7 +895,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
         }
         if (dc.min_margin < out->min_margin) out->min_margin = dc.min_margin;
     }
-    free(text); free(mel); free(enc_out); free(ck); free(cv); free(raw); free(dc.logits); free(dc.logprobs); free(dc.probs); free(dc.tokens);
+    free(prompt_past); free(text); free(mel); free(enc_out); free(ck); free(cv); free(raw); free(dc.logits); free(dc.logprobs); free(dc.probs); free(dc.tokens);
     out->n_segments = acc.n_seg; out->segments = acc.seg; out->n_tokens = acc.n_tok; out->tokens = acc.tok; out->text = acc.text; out->text_len = acc.n_text;
     return 0;
 }

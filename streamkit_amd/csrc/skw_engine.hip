@@ -281,6 +281,7 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
     SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; int* n_active = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
@@ -315,7 +316,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
 #define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
     WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
-    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false); WS(row_tok, int, B, true);
+    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false); WS(row_tok, int, B, true); WS(prompt_buf, int, (size_t)B * SKW_PROMPT_CAP, true);
     WS(im2col, half_t, (size_t)B * T * 256, false); WS(h1, half_t, (size_t)B * (T + 2) * d, true);
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
@@ -485,7 +486,6 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
 
 // one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
 __global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; }
-__global__ void k_set_tokens_rows(SkwSeqState* st, const int* tok, int pos) { st[blockIdx.x].cur_token = tok[blockIdx.x]; st[blockIdx.x].cur_pos = pos; }
 // whisper_lang_auto_detect_with_state: the language whose token has the largest logit after the [sot] step (lowest id on a tie)
 __global__ void k_lang_argmax(const float* logits, int n_vocab, int tok_sot, int n_lang, int* out) {
     const float* lg = logits + (long)blockIdx.x * n_vocab; float bv = -INFINITY; int bi = 0x7fffffff;
@@ -532,7 +532,7 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     run_decoder_step(c, r0, n, 0, true, s);
-    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, c->probs + (size_t)r0 * NV, c->rng, c->clip_idx + r0, s);
+    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, c->probs + (size_t)r0 * NV, c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
     hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, s);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
@@ -599,6 +599,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     std::vector<float> temps; temps.push_back(p->temperature);
     if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && temps.size() < 16; t += p->temperature_inc) temps.push_back(t);
     std::vector<int> tidx(n_clips, 0);
+    // prompt_past (whisper_full_with_state): text already produced in this call conditions the next window of the same clip
+    std::vector<std::vector<int>> prompt_past(n_clips); std::vector<int> last_take(n_clips, 0);
     skw_rng_seed(c->rng, n_clips, 0u, c->stream);   // DEVIATION D2': seeded per call (whisper.cpp: per state, running on across calls)
     // language: fixed by the caller, or (lang_id < 0, whisper.cpp's "auto") detected per clip from the [sot] step on the first window
     std::vector<int> lang(n_clips, p->lang_id);
@@ -637,8 +639,19 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         std::vector<int> sk(Bw); for (int j = 0; j < Bw; ++j) sk[j] = seek[act[j]];
         HIPCHK(hipMemcpyAsync(c->clip_idx, act.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->seek, sk.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
-        std::vector<int> ltok(Bw); for (int j = 0; j < Bw; ++j) ltok[j] = m->tok_sot + 1 + lang[act[j]];
-        HIPCHK(hipMemcpyAsync(c->row_tok, ltok.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
+        // per-row prompt: [prev] + the last n_text_ctx/2 tokens of the clip's prompt_past (passes at t < 0.5 only) + sot, language, task (, notimestamps)
+        std::vector<int> pbuf((size_t)Bw * SKW_PROMPT_CAP, 0), np_row(Bw, 0);
+        for (int j = 0; j < Bw; ++j) {
+            const int ci = act[j]; int* pr = pbuf.data() + (size_t)j * SKW_PROMPT_CAP; int n = 0, take = 0;
+            if (!prompt_past[ci].empty() && temps[tidx[ci]] < 0.5f) {
+                take = std::min(std::min(hp.n_text_ctx / 2, (int)prompt_past[ci].size()), hp.n_text_ctx - lp.n_max - n_prompt - 1);   // the last bound only binds with no_timestamps: every position stays inside n_text_ctx
+                pr[n++] = m->tok_prev; for (int i = 0; i < take; ++i) pr[n++] = prompt_past[ci][prompt_past[ci].size() - take + i];
+            }
+            last_take[ci] = take;
+            for (int t = 0; t < n_prompt; ++t) pr[n++] = prompt[t] >= 0 ? prompt[t] : m->tok_sot + 1 + lang[ci];
+            np_row[j] = n;
+        }
+        HIPCHK(hipMemcpyAsync(c->prompt_buf, pbuf.data(), sizeof(int) * pbuf.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
         run_conv(c, Bw);
         run_encoder(c, Bw, false, true);
@@ -646,7 +659,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         // decoder state
         for (int j = 0; j < Bw; ++j) {
             SkwSeqState& s = c->h_st[j]; memset(&s, 0, sizeof s);
-            s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = n_prompt; s.min_margin = INFINITY;
+            s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = np_row[j]; s.min_margin = INFINITY; s.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP]; s.cur_pos = 0;
             s.temperature = temps[tidx[act[j]]];
         }
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
@@ -658,32 +671,26 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
-        for (int t = 0; t < n_prompt; ++t) {
-            for (int g = 0; g < G; ++g) {
-                if (prompt[t] >= 0) hipLaunchKernelGGL(k_set_tokens, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], prompt[t], t);
-                else hipLaunchKernelGGL(k_set_tokens_rows, dim3(g_n[g]), dim3(1), 0, c->gstream[g], c->st + g_r0[g], c->row_tok + g_r0[g], t);
-                run_decoder_step(c, g_r0[g], g_n[g], t, t == n_prompt - 1, c->gstream[g]);
-            }
-            tot_steps++;
-        }
+        // every step = decoder step (token and position from the device state) + k_dec_sample, which feeds the next prompt token
+        // while a row is still inside its prompt and samples afterwards; rows have prompts of different lengths
         hipGraphExec_t gexec[skw_ctx::MAX_GROUPS] = {};
         if (c->use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->gstream[g]); }
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g]); }
             c->cur = c->stream;
             return hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, c->gstream[g]);
         };
-        for (int g = 0; g < G; ++g) HIPCHK(sample(g));
-        for (int i = 0; i < lp.n_max; ++i) {
-            bool any = false;
-            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); if (c->h_n_active[g] <= 0) g_live[g] = false; else any = true; }
-            if (!any || i == lp.n_max - 1) break;
+        const int step_cap = SKW_PROMPT_CAP + lp.n_max + 2;
+        for (int i = 0; i < step_cap; ++i) {
             for (int g = 0; g < G; ++g) if (g_live[g]) {
                 if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
-                else { run_decoder_step(c, g_r0[g], g_n[g], n_prompt + i, true, c->gstream[g]); HIPCHK(sample(g)); }
+                else { run_decoder_step(c, g_r0[g], g_n[g], i, true, c->gstream[g]); HIPCHK(sample(g)); }
             }
             tot_steps++;
+            bool any = false;
+            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); if (c->h_n_active[g] <= 0) g_live[g] = false; else any = true; }
+            if (!any) break;
         }
         for (int g = 0; g < G; ++g) { HIPCHK(hipEventRecord(c->gev[g], c->gstream[g])); HIPCHK(hipStreamWaitEvent(c->stream, c->gev[g], 0)); }
         HIPCHK(hipMemcpyAsync(c->h_st, c->st, sizeof(SkwSeqState) * Bw, hipMemcpyDeviceToHost, c->stream));
@@ -696,7 +703,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];
             if (tidx[ci] == 0) R.n_windows++;
-            R.n_decode_steps += n_prompt > 0 ? 1 : 0; R.n_decode_steps += std::max(0, s.n_tokens - 1);
+            R.n_decode_steps += 1 + std::max(0, s.n_tokens - 1);     // the prompt is one decode call in whisper.cpp, then one per sampled token but the last
             bool failed = s.failed != 0; int n_tok = s.n_tokens; const int result_len = s.result_len;
             double avg_logprobs = -INFINITY, entropy = 0.0;
             if (!failed) { n_tok = result_len; sequence_score(tk, result_len, &avg_logprobs, &entropy); if (result_len > 32 && entropy < p->entropy_thold) failed = true; }
@@ -708,6 +715,11 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             tidx[ci] = 0;
             int seek_delta = s.seek_delta;
             const bool is_no_speech = (s.no_speech_prob > p->no_speech_thold && avg_logprobs < p->logprob_thold);
+            {   // update prompt_past: what this window's prompt took from it, then this window's tokens
+                std::vector<int>& pp = prompt_past[ci]; std::vector<int> keep(pp.end() - last_take[ci], pp.end());
+                pp.clear();
+                if (!is_no_speech) { pp = keep; for (int i = 0; i < result_len; ++i) pp.push_back(tk[i].id); }
+            }
             if (n_tok > 0 && !is_no_speech) {
                 int i0 = 0; int64_t t0 = seek[ci] + 2 * (tk[0].tid - m->tok_beg); std::string text;
                 auto push = [&](int64_t a, int64_t b, int from, int to) {

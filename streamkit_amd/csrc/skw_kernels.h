@@ -93,6 +93,7 @@ struct SkwSeqState {
     float temperature;     // 0: argmax; > 0: logits / t, then a std::discrete_distribution draw from the clip's mt19937
     int32_t pad;
 };
+#define SKW_PROMPT_CAP 240   // [prev] + n_text_ctx/2 past tokens + sot, language, task, notimestamps
 #define SKW_RNG_WORDS 625   // std::mt19937 state per clip: mt[624] + index
 struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum; };
 struct SkwLogitParams {
@@ -110,7 +111,7 @@ size_t skw_static_mask_bytes(int n_vocab);
 void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
 // probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]]
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
-                    float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s);
+                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s);
 void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip
 
 // ---------------- resampler (R1) ----------------

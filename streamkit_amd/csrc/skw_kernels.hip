@@ -1266,11 +1266,15 @@ __device__ int discrete_draw(const float* probs, int n, uint32_t* mt) {
 }
 
 __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
-                                                     int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx) {
+                                                     int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf) {
     __shared__ float sh_f[16]; __shared__ double sh_d[16]; __shared__ ArgBest sh_a[16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     SkwSeqState* st = &st_all[b];
     if (!st->active) return;   // uniform per block
+    if (st->cur_pos < st->n_prompt - 1) {     // still feeding the prompt ([prev] + past text + sot/lang/task): next prompt token, no sampling (uniform per block)
+        if (threadIdx.x == 0) { const int np = st->cur_pos + 1; st->cur_token = prompt_buf[(long)b * SKW_PROMPT_CAP + np]; st->cur_pos = np; }
+        return;
+    }
     float* lg = logits_all + (long)b * p.n_vocab;
     const int NV = p.n_vocab;
     SkwTokenOut* toks = toks_all + (long)b * max_tok;
@@ -1384,11 +1388,15 @@ struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; flo
 #define SMP_PASS_END }
 #define SMP_IDX(c) (tq + SMP_NT * (c))
 __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
-                                                       int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx) {
+                                                       int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf) {
     __shared__ float sh_f[2][SMP_NT / 64]; __shared__ double sh_d[SMP_NT / 64]; __shared__ SmpMain sh_m[SMP_NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     SkwSeqState* st = &st_all[b];
     if (!st->active) return;   // uniform per block
+    if (st->cur_pos < st->n_prompt - 1) {     // still feeding the prompt ([prev] + past text + sot/lang/task): next prompt token, no sampling (uniform per block)
+        if (threadIdx.x == 0) { const int np = st->cur_pos + 1; st->cur_token = prompt_buf[(long)b * SKW_PROMPT_CAP + np]; st->cur_pos = np; }
+        return;
+    }
     float* lg = logits_all + (long)b * p.n_vocab;
     const int NV = p.n_vocab;
     SkwTokenOut* toks = toks_all + (long)b * max_tok;
@@ -1565,9 +1573,9 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
     for (int i = 0; i < n_vocab && i < SMP_PT * SMP_NT; ++i) if (mask[i]) { const int t = i % SMP_NT, c = i / SMP_NT; kw[(c >> 6) * SMP_NT + t] |= 1ull << (c & 63); }
 }
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
-                    float* probs, uint32_t* rng, const int* clip_idx, hipStream_t s) {
-    if (p.n_vocab <= SMP_PT * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
-    else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx);
+                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s) {
+    if (p.n_vocab <= SMP_PT * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
+    else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
 }
 
 // ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)
