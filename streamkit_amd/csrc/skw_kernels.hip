@@ -484,148 +484,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder(const half_t* Qh, const
                 if (dbg && qi < n_ctx && b == 0) { dbg[(long)qi * (H * 64) + h * 64 + c] = oacc[qt][ct][r]; if (ct == 0 && r == 0 && g == 0 && q0 + qt * 16 + r16 < n_ctx) { dbg[(long)n_ctx * H * 64 + (long)h * n_ctx + q0 + qt * 16 + r16] = rmax[qt]; dbg[(long)n_ctx * H * 64 + (long)(H + h) * n_ctx + q0 + qt * 16 + r16] = rinv[qt]; } }
             }
 }
-// ------------------------------------------------------------------ encoder attention v2: S resident in registers
-// One wave owns 16 queries and keeps the whole score row block S^T (NT key tiles x 4 registers = 376 accumulator
-// registers at T = 1504) in the unified VGPR/AGPR file (1 wave per SIMD), so QK^T is computed once:
-//   phase 1  S^T tiles by MFMA (two independent 16-MFMA chains per 32-key block), scale, mask, running max
-//   phase 2  e = expf(s - max) in place, f64 row sums (VALU only)
-//   phase 3  p = f16(e * inv) straight from the registers as the A operand of the P.V MFMAs (ascending key order)
-// A block is 4 waves = 64 queries of one (batch, head); K / V^T tiles are staged through LDS for the 4 waves.
-template <int NT, int RT>   // NT key tiles of 16; the first RT live in registers, the remaining NT-RT in this wave's LDS slab
-__global__ __launch_bounds__(256, 1) void k_attn_encoder_regs(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                              int H, int n_ctx, int Tpad, float kq_scale, int qtiles) {
-    constexpr int LT = NT - RT;
-    extern __shared__ __attribute__((aligned(16))) char smem_att[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f32x4* slds = (f32x4*)smem_att + (size_t)wave * LT * 64 + lane;     // tile t of this lane at slds[t * 64]
-    // XCD-aware remap: blocks b and b+8 share an XCD; give each XCD a contiguous run so the q-tiles of one (batch, head) hit one L2
-    const int nblk = gridDim.x; int bid = blockIdx.x;
-    { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }
-    const long bh = bid / qtiles; const int qt = bid % qtiles;
-    const int b = (int)(bh / H), h = (int)(bh % H);
-    const int q0 = qt * 64 + wave * 16;
-    if (q0 >= n_ctx) return;                       // no block-level synchronisation in this kernel: waves are independent
-    const int r16 = lane & 15, g = lane >> 4;
-    H8 qh0, qh1;                                   // Q fragment (B operand), kept packed: lane (q = r16, g) holds Q[q][d = 32*blk + 4*e + g]
-    {
-        int qi = q0 + r16; if (qi >= n_ctx) qi = n_ctx - 1;
-        const half_t* qp = Qh + (bh * Tpad + qi) * 64 + g * 8;
-        qh0.u = *(const uint4*)qp; qh1.u = *(const uint4*)(qp + 32);
-    }
-    const int kappa = 4 * (r16 & 3) + (r16 >> 2);  // MFMA row rho of a 16-key tile holds key kappa(rho): keeps the P.V chain ascending
-    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
-    const unsigned ko = (unsigned)((kappa * 64 + g * 8) * 2);                 // + kb*4096 per 32-key block, +2048 second tile, +64 d-block 1
-    const unsigned vo = (unsigned)((r16 * Tpad + g * 8) * 2);                 // + ct*16*Tpad*2, + kb*64 per block
-    f32x4 sreg[RT];
-    float rmax = -INFINITY;
-    // one 32-key block of S^T: two 16-key tiles (independent 16-MFMA chains), scaled and masked
-    auto qk_block = [&](int kb, const H8v& k00, const H8v& k01, const H8v& k10, const H8v& k11, f32x4& a0, f32x4& a1) {
-        a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { float qv = h2f(qh0.h[e]); a0 = MFMA16(h2f(k00.h[e]), qv, a0); a1 = MFMA16(h2f(k10.h[e]), qv, a1); }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { float qv = h2f(qh1.h[e]); a0 = MFMA16(h2f(k01.h[e]), qv, a0); a1 = MFMA16(h2f(k11.h[e]), qv, a1); }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key0 = kb * 32 + 4 * r + g;
-            float v0 = a0[r] * kq_scale, v1 = a1[r] * kq_scale;
-            v0 = (key0 < n_ctx) ? v0 : -INFINITY; v1 = (key0 + 16 < n_ctx) ? v1 : -INFINITY;
-            a0[r] = v0; a1[r] = v1; rmax = fmaxf(rmax, fmaxf(v0, v1));
-        }
-    };
-    auto kload = [&](int kb, H8v* f) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u].v = __builtin_amdgcn_raw_buffer_load_b128(rk, ko + kb * 4096 + (u >> 1) * 2048 + (u & 1) * 64, 0, 0);   // past Tpad: zeros
-    };
-    // ---- phase 1
-    {
-        H8v kf[2][4]; kload(0, kf[0]); kload(1, kf[1]);
-#pragma unroll
-        for (int kb = 0; kb < RT / 2; ++kb) {
-            H8v c0 = kf[kb & 1][0], c1 = kf[kb & 1][1], c2 = kf[kb & 1][2], c3 = kf[kb & 1][3];
-            kload(kb + 2, kf[kb & 1]);
-            qk_block(kb, c0, c1, c2, c3, sreg[2 * kb], sreg[2 * kb + 1]);
-            __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting later blocks' loads (register pressure)
-        }
-        H8v ka[4], kb4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { ka[u] = kf[(RT / 2) & 1][u]; kb4[u] = kf[(RT / 2 + 1) & 1][u]; }
-        for (int kb = RT / 2; kb < NT / 2; ++kb) {
-            H8v c0 = ka[0], c1 = ka[1], c2 = ka[2], c3 = ka[3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ka[u] = kb4[u];
-            kload(kb + 2, kb4);
-            f32x4 a0, a1; qk_block(kb, c0, c1, c2, c3, a0, a1);
-            slds[(2 * kb - RT) * 64] = a0; slds[(2 * kb + 1 - RT) * 64] = a1;
-        }
-    }
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 16, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    // ---- phase 2: e = expf(s - max) in place, f64 row sum
-    double rsum = 0.0;
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { float e = skw_expf(sreg[t][r] - rmax); sreg[t][r] = e; rsum += (double)e; if (r == 3) __builtin_amdgcn_sched_barrier(0); }
-    for (int t = 0; t < LT; ++t) {
-        f32x4 v = slds[t * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { float e = skw_expf(v[r] - rmax); v[r] = e; rsum += (double)e; }
-        slds[t * 64] = v;
-    }
-    rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);
-    const float rinv = (float)(1.0 / rsum);
-    // ---- phase 3: O = P V with P = f16(e * inv) as the A operand, keys ascending
-    f32x4 oacc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto vload = [&](int kb, H8v* f) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) f[ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, vo + ct * 16 * Tpad * 2 + kb * 64, 0, 0);
-    };
-    auto pv_block = [&](const f32x4& e0, const f32x4& e1, const H8v* vf) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = (kt ? e1[r] : e0[r]) * rinv;
-                p = h2f(f2h(p));
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) oacc[ct] = MFMA16(p, h2f(vf[ct].h[kt * 4 + r]), oacc[ct]);
-            }
-    };
-    {
-        H8v vfr[2][4]; vload(0, vfr[0]); vload(1, vfr[1]);
-#pragma unroll
-        for (int kb = 0; kb < RT / 2; ++kb) {
-            H8v vf[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) vf[ct] = vfr[kb & 1][ct];
-            vload(kb + 2, vfr[kb & 1]);            // past the end of a row the loads run into the next row / past the buffer: values never used
-            pv_block(sreg[2 * kb], sreg[2 * kb + 1], vf);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        H8v va[4], vb[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { va[ct] = vfr[(RT / 2) & 1][ct]; vb[ct] = vfr[(RT / 2 + 1) & 1][ct]; }
-        for (int kb = RT / 2; kb < NT / 2; ++kb) {
-            H8v vf[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) { vf[ct] = va[ct]; va[ct] = vb[ct]; }
-            vload(kb + 2, vb);
-            f32x4 e0 = slds[(2 * kb - RT) * 64], e1 = slds[(2 * kb + 1 - RT) * 64];
-            pv_block(e0, e1, vf);
-        }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int qi = q0 + g * 4 + r; int c = ct * 16 + r16;
-            if (qi < n_ctx) out[((long)b * n_ctx + qi) * ld_out + skw_kperm(h * 64 + c)] = f2h(oacc[ct][r]);
-        }
-}
-
 // ------------------------------------------------------------------ encoder self-attention, single-pass form (K5)
 // On gfx950 the f32 MFMA and the vector ALU do not overlap on a SIMD, not even across waves (tools/probe/probe_mfma_chain.hip: 16 conversions
 // + 8 MFMAs cost 41.5 cycles/MFMA at 1, 2 or 3 waves per SIMD), so the kernel that wins is the one with the fewest MFMA + VALU cycles:
@@ -810,11 +668,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
 }
 
 void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2) {
-    if (Tpad == 1504 && !dbg && getenv("SKW_ATTN_REGS")) {   // experimental (measured no faster: 1 wave/SIMD cannot overlap the exp phase)   // Whisper's 1500-frame context: scores stay in registers, QK^T computed once
-        const int qtiles = (n_ctx + 63) / 64;
-        hipLaunchKernelGGL((k_attn_encoder_regs<94, 64>), dim3(qtiles * H * B), dim3(256), (size_t)4 * 30 * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles);
-        return;
-    }
     if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg && !getenv("SKW_ATTN_V1")) {     // Whisper's 1500-frame context
         const int qtiles = (n_ctx + 63) / 64;
         constexpr int RT3 = 72;
