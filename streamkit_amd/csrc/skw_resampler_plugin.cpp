@@ -11,6 +11,7 @@
 #include "../../include/streamkit_native_abi.h"
 #include "../../include/skw_engine.h"
 #include "skw_segmenter.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -28,6 +29,9 @@ struct Resampler {
     bool init = false, needs = false; uint32_t rate = 0; uint16_t channels = 0;
     skw_dsp* dsp = nullptr; skw_resampler_state st{};
     std::vector<float> sample_buffer, output_buffer, scratch;
+    // mode "polyphase" (additive): streaming form of skw_resample_polyphase.  pp_in holds input frames from absolute frame pp_base
+    // (a multiple of M, so local and absolute phases coincide); outputs [0, pp_next) have been produced.
+    bool polyphase = false; int L = 1, M = 1, T = 32; std::vector<float> pp_in; long pp_base = 0, pp_total = 0, pp_next = 0;
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
     ~Resampler() { if (dsp) skw_dsp_free(dsp); }
 };
@@ -50,11 +54,32 @@ bool run_chunks(Resampler* r, skw_resampler_state* st, const float* in, int n_ch
     out->resize((size_t)n * r->channels); return true;
 }
 
+// streaming polyphase: produce every output whose filter support is already here (all of them at end of stream), keep what later outputs need
+bool polyphase_step(Resampler* r, bool final_call, std::vector<float>* out, std::string* err) {
+    out->clear();
+    const long ch = r->channels, n_loc = (long)(r->pp_in.size() / ch);
+    // output m sits at input position floor(m*M/L) and reads frames [pos - (T/2 - 1), pos + T/2]
+    long m_hi = final_call ? (r->pp_total * r->L + r->M - 1) / r->M : 0;
+    if (!final_call) { const long last_pos = r->pp_total - 1 - r->T / 2; m_hi = last_pos < 0 ? 0 : ((last_pos + 1) * r->L + r->M - 1) / r->M; }   // every m with floor(m*M/L) <= last_pos
+    if (m_hi <= r->pp_next || n_loc == 0) return true;
+    const long base_out = r->pp_base / r->M * r->L;                       // first output index of the local buffer (pp_base is a multiple of M)
+    const long n_out_loc = (n_loc * r->L + r->M - 1) / r->M; std::vector<float> all((size_t)n_out_loc * ch); long got = 0;
+    if (skw_resample_polyphase(r->dsp, r->pp_in.data(), n_loc, (int)ch, (int)r->rate, (int)r->target, all.data(), n_out_loc, &got) != 0) { *err = std::string("Resampling failed: ") + skw_dsp_last_error(r->dsp); return false; }
+    const long lo = r->pp_next - base_out, hi = std::min(m_hi - base_out, got);
+    if (hi > lo) out->assign(all.begin() + lo * ch, all.begin() + hi * ch);
+    r->pp_next = base_out + std::max(lo, hi);
+    // drop input no future output reads: keep from the support start of output pp_next, rounded down to a multiple of M
+    long keep_from = (r->pp_next * r->M) / r->L - (r->T / 2 - 1); if (keep_from < 0) keep_from = 0; keep_from = keep_from / r->M * r->M;
+    if (keep_from > r->pp_base) { r->pp_in.erase(r->pp_in.begin(), r->pp_in.begin() + (keep_from - r->pp_base) * ch); r->pp_base = keep_from; }
+    return true;
+}
+
 const char* const kSchema =
     "{\"type\":\"object\",\"required\":[\"target_sample_rate\"],\"properties\":{"
     "\"target_sample_rate\":{\"type\":\"integer\",\"minimum\":1,\"description\":\"Target output sample rate in Hz\"},"
     "\"chunk_frames\":{\"type\":\"integer\",\"minimum\":1,\"default\":960,\"description\":\"Fixed chunk size for resampler\"},"
     "\"output_frame_size\":{\"type\":\"integer\",\"default\":960,\"description\":\"Output frame size (0 disables re-chunking); must be 0 or a valid Opus frame size\"},"
+    "\"mode\":{\"type\":\"string\",\"default\":\"linear\",\"description\":\"(additive) linear = the built-in node's rubato interpolation, bit for bit; polyphase = Kaiser-windowed sinc, 32 taps per phase of the slower rate\"},"
     "\"gpu_device\":{\"type\":\"integer\",\"default\":0,\"minimum\":0,\"maximum\":7,\"description\":\"(additive) GPU that runs the kernels\"}}}";
 const CAudioFormat kAnyF32 = {0, 0, SK_SAMPLE_F32};
 const CPacketTypeInfo kIn[1] = {{SK_PACKET_RAW_AUDIO, &kAnyF32, nullptr}};
@@ -79,6 +104,7 @@ CPluginHandle create_instance(const char* params, CLogCallback log_cb, void* log
     if (cf < 1) return fail("chunk_frames must be greater than 0");
     if (of != 0) { const double okv[] = {120, 240, 480, 960, 1920, 2880}; bool okf = false; for (double x : okv) okf = okf || x == of; if (!okf) return fail("output_frame_size must be 0 (disabled) or a valid Opus frame size: [120, 240, 480, 960, 1920, 2880]"); }
     r->target = (uint32_t)t; r->chunk_frames = (size_t)cf; r->out_frame = (size_t)of; r->gpu_device = (int)num("gpu_device", 0);
+    { const skw::JsonValue* x = v.get("mode"); if (x) { if (x->type != skw::JsonValue::String || (x->str != "linear" && x->str != "polyphase")) return fail("mode must be \"linear\" or \"polyphase\""); r->polyphase = x->str == "polyphase"; } }
     return (CPluginHandle)r.release();
 }
 
@@ -98,6 +124,7 @@ CResult process_packet(CPluginHandle h, const char* pin, const CPacket* pk, COut
             char eb[512] = {0}; r->dsp = skw_dsp_create(r->gpu_device, eb, sizeof eb);
             if (!r->dsp) return err_result(std::string("Failed to create resampler: ") + eb);
             skw_resampler_init(&r->st, (double)r->target / (double)r->rate, (int)r->chunk_frames, r->channels);
+            { long a = r->rate, b = r->target; while (b) { long t2 = a % b; a = b; b = t2; } r->L = (int)(r->target / a); r->M = (int)(r->rate / a); r->T = 32 * std::max(1, (r->M + r->L - 1) / r->L); }
         }
     }
     if (fr->sample_rate != r->rate || fr->channels != r->channels) {
@@ -107,6 +134,14 @@ CResult process_packet(CPluginHandle h, const char* pin, const CPacket* pk, COut
         if (r->out_frame == 0) { if (!emit(r, cb, ud, fr->samples, fr->sample_count, &err)) return err_result(err); return ok_result(); }
         r->output_buffer.insert(r->output_buffer.end(), fr->samples, fr->samples + fr->sample_count);
         if (!drain(r, cb, ud, &err)) return err_result(err); return ok_result();
+    }
+    if (r->polyphase) {
+        r->pp_in.insert(r->pp_in.end(), fr->samples, fr->samples + fr->sample_count); r->pp_total += (long)(fr->sample_count / r->channels);
+        if (!polyphase_step(r, false, &r->scratch, &err)) return err_result(err);
+        if (r->scratch.empty()) return ok_result();
+        if (r->out_frame > 0) { r->output_buffer.insert(r->output_buffer.end(), r->scratch.begin(), r->scratch.end()); if (!drain(r, cb, ud, &err)) return err_result(err); }
+        else if (!emit(r, cb, ud, r->scratch.data(), r->scratch.size(), &err)) return err_result(err);
+        return ok_result();
     }
     r->sample_buffer.insert(r->sample_buffer.end(), fr->samples, fr->samples + fr->sample_count);
     const size_t cs = r->chunk_frames * r->channels; const int n_chunks = (int)(r->sample_buffer.size() / cs);
@@ -127,7 +162,14 @@ CResult update_params(CPluginHandle h, const char*) { if (!h) return err_result(
 CResult flush(CPluginHandle h, COutputCallback cb, void* ud, CTelemetryCallback, void*) {
     if (!h) return err_result("Invalid handle (null)");
     Resampler* r = (Resampler*)h; std::string err;
-    if (r->needs && !r->sample_buffer.empty()) {
+    if (r->needs && r->polyphase) {
+        if (!polyphase_step(r, true, &r->scratch, &err)) return err_result(err);
+        if (!r->scratch.empty()) {
+            if (r->out_frame > 0) { r->output_buffer.insert(r->output_buffer.end(), r->scratch.begin(), r->scratch.end()); if (!drain(r, cb, ud, &err)) return err_result(err); }
+            else if (!emit(r, cb, ud, r->scratch.data(), r->scratch.size(), &err)) return err_result(err);
+        }
+    }
+    if (r->needs && !r->polyphase && !r->sample_buffer.empty()) {
         const size_t rem = r->sample_buffer.size() / r->channels;
         if (rem >= 1) {   // fresh resampler sized to the remainder: zero history, last_index = -4 (resampler.rs:564-570)
             skw_resampler_state t; skw_resampler_init(&t, (double)r->target / (double)r->rate, (int)rem, r->channels);

@@ -90,3 +90,22 @@ def test_resampler_plugin_equals_host_node(dsp):
     with pytest.raises(RuntimeError):
         p.create_node({"target_sample_rate": 16000, "output_frame_size": 1000})
     n2.destroy()
+
+
+@pytest.mark.parametrize("in_rate,ch,packet", [(48000, 1, 960), (44100, 1, 1111), (48000, 2, 500), (8000, 1, 160)])
+def test_resampler_plugin_polyphase_streaming_equals_whole_buffer(dsp, in_rate, ch, packet):
+    """mode = polyphase (additive): the plugin filters a stream packet by packet, carrying only the input its later outputs need;
+    the concatenated output must be bit-identical to filtering the whole signal at once."""
+    p = minihost.Plugin(minihost.os.path.join(minihost.ROOT, "streamkit_amd", "libresampler.so"))
+    n_frames = in_rate * 2 + 321
+    x = _signal(n_frames * ch, ch, seed=9)
+    node = p.create_node({"target_sample_rate": 16000, "output_frame_size": 0, "mode": "polyphase"})
+    for i in range(0, x.size, packet * ch):
+        assert node.process_audio(x[i:i + packet * ch], in_rate, ch) == 0, node.last_error()
+    assert node.flush() == 0
+    got = np.concatenate([np.frombuffer(o[2], dtype=np.float32) for o in node.outputs()])
+    exp = dsp.resample_polyphase(x, ch, in_rate, 16000)
+    assert got.size == exp.size and np.array_equal(got.view(np.uint32), np.asarray(exp, np.float32).view(np.uint32))
+    node.destroy()
+    with pytest.raises(RuntimeError):
+        p.create_node({"target_sample_rate": 16000, "mode": "cubic"})
