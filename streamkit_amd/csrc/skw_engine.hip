@@ -746,6 +746,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());          // a launch that failed (bad configuration, lost device) must not look like a transcript
     for (int i = 0; i < n_clips; ++i) {
         skw_result& R = results[i]; SeqAcc& A = acc[i];
         R.n_segments = (int)A.seg.size(); R.n_tokens = (int)A.tok.size(); R.text_len = (int)A.text.size();
