@@ -250,3 +250,19 @@ def test_language_auto_detection_matches_oracle(tiny):
         assert rg["lang_id"] == ro["lang_id"] and _same(rg, ro)
         langs.add(rg["lang_id"])
     assert res[3]["segments"] == []
+
+
+def test_small_model_ragged_multi_window_matches_oracle(eng, small_model_path):
+    """Whisper-small dimensions (the benchmark's model) on clips that are not the benchmark's: short, one window, two windows
+    (the second conditioned on the first through prompt_past), and too short to transcribe — tokens, timestamps, log-probs vs the oracle."""
+    m = eng.Model(small_model_path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 50); om = OracleModel(small_model_path)
+    clips = [(71, 16000 * 7 + 311), (72, 16000 * 30), (73, 16000 * 44), (74, 6000)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    p = ctx.default_params(); p.suppress_nst = 1
+    po = om.default_params(); po.suppress_nst = 1
+    res = ctx.full_batch(pcms, p)
+    for (c, n), pcm, rg in zip(clips, pcms, res):
+        ro = om.full(pcm, po)
+        assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
+    assert res[2]["n_windows"] >= 2 and res[3]["segments"] == []
+    ctx.close(); m.close()
