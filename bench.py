@@ -55,6 +55,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        # communicator set-up is lazy: force it now, outside the timed region, whatever --warmup is
+        _w = torch.zeros(1, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(_w)
 
     # model (random-init weights of the Whisper-small architecture in whisper.cpp's GGML container; not timed)
     tool = os.path.join(ROOT, "tools", "make_synth_model")
