@@ -2,13 +2,19 @@
 """bench.py — real-time factor of the Whisper-small Oneshot batch path on MI355X (BASELINE.json metric).
 
 One step = one pass of the hot path (log-mel -> encoder -> cross K/V -> batched greedy decode -> segments) over one batch
-of 64 synthetic 30 s clips per GPU, PCM already resident in HBM.  N > 1: one process per GPU (torchrun), clips sharded
+of 64 synthetic 30 s clips per GPU, PCM already resident in HBM.  N > 1: one process per GPU, clips sharded
 c -> rank c mod N (independent clips: no data-path collective), then one RCCL all_gather of the fixed-size token buffers.
-Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (fresh child processes; the parent never
+touches the GPU); under torchrun it is one of the ranks.  Rank 0 prints ONE JSON line.
+
+The headline runs the f16-MFMA precision (f16 operands on the f16 matrix cores, f32 accumulate; token ids / timestamps / texts
+checked identical to the exact mode on every clip of the batch and to the CPU oracle on a sample); the exact mode (f32-chain
+contractions, bit-identical to the oracle) is timed beside it and reported under "modes".
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -17,46 +23,89 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
-F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (dense peaks)
+F32_MFMA_PEAK_TFLOPS = 157.3
+F16_MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--size", default="small")
+    ap.add_argument("--precision", default="f16_mfma", choices=["f16_mfma", "exact"], help="precision of the headline number")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh ranks.  This process must not initialise the GPU (a later exec / fork of a
+    GPU-initialised process is what the pool forbids), so it only counts devices and relays rank 0's line."""
+    import torch
+    n_dev = torch.cuda.device_count()          # does not create a HIP context
+    if n_dev < args.gpus and not args.share_gpu:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, n_dev))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.stdout.write(out0)
+        return 1
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: rank 0 did not report n_gpus == %d\n" % args.gpus)
+        return 1
+    print(line[-1], flush=True)
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from streamkit_amd import engine, synth
+    from streamkit_amd import dist as skd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     file_rank = local_rank
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    gdev = torch.device("cuda", local_rank)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=gdev)
         else:
             dist.init_process_group(args.backend)
         # communicator set-up is lazy: force it now, outside the timed region, whatever --warmup is
-        _w = torch.zeros(1, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+        _w = torch.zeros(1, device=gdev if args.backend == "nccl" else "cpu")
         dist.all_reduce(_w)
 
     # model (random-init weights of the Whisper-small architecture in whisper.cpp's GGML container; not timed)
@@ -66,6 +115,7 @@ def main():
     path = "/tmp/skw_bench_%s_r%d.bin" % (args.size, file_rank)
     subprocess.check_call([tool, path, "--size", args.size, "--seed", "1234"])
     model = engine.Model(path, device=local_rank)
+    hp = model.hp
     B = args.clips
     n_samples = 480000
     ctx = engine.Context(model, max_batch=B, max_samples=n_samples)
@@ -73,19 +123,24 @@ def main():
     params.suppress_nst = 1   # the reference node's default (lib.rs:634, suppress_non_speech_tokens = true)
 
     # inputs: clip c -> rank c mod world; resident in HBM before the timed region
-    from streamkit_amd.dist import shard_clip_ids
-    clip_ids = shard_clip_ids(B * world, rank, world)
+    clip_ids = skd.shard_clip_ids(B * world, rank, world)
     host = np.stack([synth.clip(c, n_samples) for c in clip_ids])
     dev = torch.from_numpy(host).cuda()
+    pinned = torch.from_numpy(host).pin_memory()
     torch.cuda.synchronize()
     ptrs = [dev[i].data_ptr() for i in range(B)]
     ns = [n_samples] * B
-    from streamkit_amd import dist as skd
+    gather_s = [0.0]
 
-    def step():
+    def step(from_host=False):
+        if from_host:    # PCIe-inclusive variant: the batch's PCM starts in pinned host memory
+            dev.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
         res = ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
         if world > 1:   # the one exchange step: fixed-size int32 token buffers to every rank over RCCL
-            skd.gather_tokens(skd.pack_tokens(res), world, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+            t = time.perf_counter()
+            skd.gather_tokens(skd.pack_tokens(res), world, device=gdev if args.backend == "nccl" else None)
+            gather_s[0] += time.perf_counter() - t
         return res
 
     def barrier():
@@ -93,60 +148,121 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    timing = ctx.timing()
-    audio_s = args.steps * B * world * (n_samples / 16000.0)
-    value = audio_s / dt
+    def timed(n_warm, n_steps, from_host=False):
+        for _ in range(n_warm):
+            res = step(from_host)
+        barrier()
+        gather_s[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            res = step(from_host)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=gdev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, res
 
+    audio_per_step = B * world * (n_samples / 16000.0)
+    ctx.set_precision(args.precision)
+    dt, res = timed(args.warmup, args.steps)
+    gather_ms = 1000.0 * gather_s[0] / args.steps
+    timing = ctx.timing()
+    value = args.steps * audio_per_step / dt
+    modes = {args.precision: {"value": round(value, 2), "ms_per_step": round(1000.0 * dt / args.steps, 3),
+                              "encode_ms": round(timing["encode_ms"], 3), "decode_ms": round(timing["decode_ms"], 3), "mel_ms": round(timing["mel_ms"], 3)}}
+    dt_h, _ = timed(1, max(2, min(args.steps, 5)), from_host=True)
+    pcie_value = max(2, min(args.steps, 5)) * audio_per_step / dt_h
+
+    other = "exact" if args.precision == "f16_mfma" else "f16_mfma"
+    identical = None
+    if not args.no_other_mode:
+        n_o = max(2, min(args.steps, 5))
+        ctx.set_precision(other)
+        dt_o, res_o = timed(1, n_o)
+        t_o = ctx.timing()
+        modes[other] = {"value": round(n_o * audio_per_step / dt_o, 2), "ms_per_step": round(1000.0 * dt_o / n_o, 3),
+                        "encode_ms": round(t_o["encode_ms"], 3), "decode_ms": round(t_o["decode_ms"], 3), "mel_ms": round(t_o["mel_ms"], 3)}
+        identical = all([t[0] for t in a["tokens"]] == [t[0] for t in b["tokens"]] and
+                        [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]]
+                        for a, b in zip(res, res_o))
+        ctx.set_precision(args.precision)
+
+    fast = args.precision == "f16_mfma"
     out = {
         "metric": "real-time factor (audio-sec/wall-sec) Whisper-small Oneshot batch",
         "value": round(value, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Whisper-%s Oneshot batch, %dx30 s synthetic 16 kHz clips per GPU (configs[1]), greedy T=0, "
+        "dtype": "f16" if fast else "f32", "data": "synthetic",
+        "config": {"workload": "Whisper-%s Oneshot batch, %dx30 s synthetic 16 kHz clips per GPU (configs[1]), greedy T=0 with the temperature ladder armed, "
                                "random-init weights in GGML f16 container" % (args.size, B),
-                   "clips_per_gpu": B, "sharding": "clip c -> rank c mod N; one RCCL all_gather of int32 [64 x 226] token buffers",
-                   "vad": "none (engine-level full(); plugin path uses AlwaysSpeech when no Silero model is present)",
+                   "precision": args.precision + (": f16 operands on v_mfma_f32_16x16x32_f16, f32 accumulate" if fast else ": f16 operands widened to f32, k-ordered chains on v_mfma_f32_16x16x4_f32"),
+                   "clips_per_gpu": B, "sharding": "clip c -> rank c mod N; one RCCL all_gather of int32 [%d x 226] token buffers" % B,
+                   "vad": "none (engine-level full(); the plugin path is measured by tools/bench_plugin.py)",
                    "last_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
                    "fallback_requested": int(sum(r["fallback_requested"] for r in res))},
+        "modes": modes,
+        "tokens_identical_between_modes": identical,
+        "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
+        "value_pcie_inclusive": round(pcie_value, 2),
     }
 
     if rank == 0 and not args.no_roofline:
-        # per-kernel-class HIP-event timing on the engine's stream, one extra (untimed) step
+        # per-kernel-class HIP-event timing on the engine's streams, one extra (untimed) step
         ctx.profile(True)
         ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
         prof = ctx.profile_get()
         ctx.profile(False)
+        tprof = ctx.timing()
+        mfma_peak = F16_MFMA_PEAK_TFLOPS if fast else F32_MFMA_PEAK_TFLOPS
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         name, p = dom
         traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
         try:
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_launch_bytes"]
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pt = pt.get(args.precision, pt).get("per_launch_bytes", {})
             traffic = pt[name]["total"] if name in pt else None
         except Exception:
             traffic = None
-        kern = {k: {"launches": v["count"], "ms": round(v["ms"], 3)} for k, v in prof.items() if v["count"]}
+        kern = {}
+        for k, v in prof.items():
+            if not v["count"]:
+                continue
+            e = {"launches": v["count"], "ms": round(v["ms"], 3)}
+            if v["flops"]:
+                e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
+            if v["bytes"]:
+                e["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+            kern[k] = e
         if name in ("k_gemm", "k_gemm_smallm", "k_attn_encoder"):
             ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern}
+            pk = mfma_peak if name != "k_gemm_smallm" or fast else F32_MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4)}
         else:
             ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern}
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        roof.update({"traffic": traffic, "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern})
+        # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times
+        nwin, nsteps = timing["n_windows"], timing["n_decode_steps"]
+        d, dt_, nc, L = hp.n_audio_state, hp.n_text_state, hp.n_audio_ctx, hp.n_text_layer
+        enc_fl = sum(prof[k]["flops"] for k in ("k_gemm", "k_attn_encoder"))                  # 386.7 GF per window at Whisper-small
+        xkv = 2.0 * L * nc * dt_ * 2                                                           # cross K/V bytes per sequence per step (55.3 MB)
+        dec_w = 2.0 * (L * (4 * dt_ * dt_ + 4 * dt_ * dt_ + 8 * dt_ * dt_) + hp.n_vocab * dt_)  # decoder weights streamed per step (306 MB)
+        dec_bytes = nsteps * (B * xkv + dec_w)
+        fe_bytes = nwin * (n_samples * 4 + 2 * nc * hp.n_mels * 4.0)
+        t_enc, t_dec, t_fe = timing["encode_ms"] * 1e-3, timing["decode_ms"] * 1e-3, timing["mel_ms"] * 1e-3
+        ph = {"encode": {"bound": "mfma", "achieved": round(enc_fl / t_enc / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s", "ms": round(t_enc * 1e3, 3)},
+              "decode": {"bound": "hbm", "achieved": round(dec_bytes / t_dec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms": round(t_dec * 1e3, 3),
+                         "bytes": "steps x (B x %.1f MB cross K/V + %.0f MB weights)" % (xkv / 1e6, dec_w / 1e6), "steps": nsteps},
+              "front_end": {"bound": "hbm", "achieved": round(fe_bytes / t_fe / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms": round(t_fe * 1e3, 3)}}
+        for v in ph.values():
+            v["frac"] = round(v["achieved"] / v["peak"], 4)
+        t_roof = enc_fl / (mfma_peak * 1e12) + dec_bytes / (HBM_PEAK_GBS * 1e9) + fe_bytes / (HBM_PEAK_GBS * 1e9)
+        ph["combined"] = {"roofline_ms": round(t_roof * 1e3, 3), "measured_ms": round(timing["total_ms"], 3), "frac": round(t_roof * 1e3 / timing["total_ms"], 4)}
+        roof["phases"] = ph
+        roof["profiled_step_ms"] = {"encode": round(tprof["encode_ms"], 2), "decode_one_group": round(tprof["decode_ms"], 2)}
+        out["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (a port) on the host cores, bounded sample of the same workload
@@ -155,17 +271,22 @@ def main():
         om = OracleModel(path)
         threads = int(os.environ["OMP_NUM_THREADS"])
         n_cpu = 2
-        t0 = time.perf_counter()
         ok = True
         op = om.default_params()
         op.suppress_nst = 1
+        t0 = time.perf_counter()
         for i in range(n_cpu):
             ro = om.full(host[i], op)
             ok = ok and [t[0] for t in ro["tokens"]] == [t[0] for t in res[i]["tokens"]]
         cdt = time.perf_counter() - t0
+        op.n_threads = 4    # the reference node's default n_threads = min(4, cores) (lib.rs:92, 139)
+        t0 = time.perf_counter()
+        om.full(host[2], op)
+        cdt4 = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(n_cpu * 30.0 / cdt, 3), "unit": "x real-time", "cores": threads, "kind": "port",
-                               "sample": "%d of the %d clips of this workload through oracle/ (OpenMP, %d threads); tokens %s the GPU's"
-                                         % (n_cpu, B, threads, "identical to" if ok else "DIFFER from")}
+                               "sample": "%d of the %d clips of this workload through oracle/ (OpenMP, %d threads); tokens %s the GPU's (%s mode)"
+                                         % (n_cpu, B, threads, "identical to" if ok else "DIFFER from", args.precision),
+                               "value_n_threads_4": round(30.0 / cdt4, 3)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

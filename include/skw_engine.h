@@ -87,6 +87,18 @@ skw_ctx* skw_ctx_create(skw_model*, int max_batch, int max_samples_per_clip, cha
 void skw_ctx_free(skw_ctx*);
 const char* skw_ctx_last_error(const skw_ctx*);
 
+/* Which form of the dense contractions (K2, K4-K6 and, in decode, K8-K10) a context runs.  Additive: the reference has no such knob.
+ *   SKW_PRECISION_EXACT     f16 values widened to f32 and chained in k order on the f32-input MFMA: every tensor is bit-identical
+ *                           to oracle/ (the checker mode; 1/16 of the f16 matrix rate);
+ *   SKW_PRECISION_F16_MFMA  the same f16 operands fed to v_mfma_f32_16x16x32_f16 (f32 accumulate, hardware summation order):
+ *                           token ids / timestamps / texts are required to equal the exact mode's, intermediate tensors agree
+ *                           to the tolerances tests/test_gpu_f16.py states; log-mel, LayerNorm, GELU and the logit rules are
+ *                           the exact kernels in both modes. */
+#define SKW_PRECISION_EXACT 0
+#define SKW_PRECISION_F16_MFMA 1
+int skw_ctx_set_precision(skw_ctx*, int precision);   /* 0 on success; takes effect from the next call on this context */
+int skw_ctx_get_precision(const skw_ctx*);
+
 void skw_full_default_params(skw_full_params*);
 
 /* ---- the hot path ---- */

@@ -28,6 +28,7 @@
 #define WHISPER_N_FFT 400
 #define WHISPER_HOP_LENGTH 160
 #define WHISPER_CHUNK_SIZE 30
+#define DELTA_MIN 10   /* whisper_full_with_state: `const int delta_min = 10` mel frames = 100 ms (whisper.cpp #2065; the pre-1.6 rule was 100 = 1 s) */
 #define N_LANG 99
 
 /* ------------------------------------------------------------------ model */
@@ -792,7 +793,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
         } else lang_id = 0;
     }
     out->lang_id = lang_id;
-    if (seek_end < seek_start + 100) { free(mel); return 0; } /* "input is too short" */
+    if (seek_end < seek_start + DELTA_MIN) { free(mel); return 0; } /* "input is too short" (< 100 ms) */
     const int d = m->hp.n_text_state, nc = m->hp.n_audio_ctx, NV = m->hp.n_vocab;
     float* enc_out = xmalloc_f((size_t)nc * m->hp.n_audio_state);
     float* ck = xmalloc_f((size_t)m->hp.n_text_layer * nc * d); float* cv = xmalloc_f((size_t)m->hp.n_text_layer * nc * d);
@@ -811,7 +812,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     char* text = (char*)malloc(1 << 16);
     mt19937_t rng; mt_seed(&rng, 0);
     while (1) {
-        if (seek + 100 >= seek_end) break;
+        if (seek + DELTA_MIN >= seek_end) break;   /* "if only 100ms left, then stop" */
         skwo_encode(m, mel, n_len, seek, 0, enc_out, ck, cv);
         out->n_windows++;
         /* temperature ladder (whisper_full_with_state): greedy at t = temperature, then sampled passes at +temperature_inc while a pass fails */
@@ -845,9 +846,9 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
                         if (dc.has_ts && dc.seek_delta > seek_delta_new && dc.result_len < i) { dc.failed = 1; break; }
                         dc.seek_delta = seek_delta_new; dc.result_len = i + 1; dc.has_ts = 1;
                     }
-                    if (tk.id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc.has_ts && seek + dc.seek_delta + 100 >= seek_end)) {
+                    if (tk.id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc.has_ts && seek + dc.seek_delta + DELTA_MIN >= seek_end)) {
                         if (dc.result_len == 0 && !p->no_timestamps) {
-                            if (seek + dc.seek_delta + 100 >= seek_end) dc.result_len = i + 1;
+                            if (seek + dc.seek_delta + DELTA_MIN >= seek_end) dc.result_len = i + 1;
                             else { dc.failed = 1; break; }
                         }
                         if (p->single_segment || p->no_timestamps) { dc.result_len = i + 1; dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
@@ -870,10 +871,12 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
         {
             int seek_delta = dc.seek_delta; const int result_len = dc.result_len; const skwo_token* tc = dc.tokens; const int ntc = dc.n_tokens; (void)result_len;
             const int is_no_speech = (no_speech_prob > p->no_speech_thold && dc.avg_logprobs < p->logprob_thold);
-            { /* update prompt_past: what was taken from it for this window's prompt, then this window's tokens (recalled: the !is_no_speech guard) */
+            { /* update prompt_past (recalled): clear; re-insert what this window's prompt took from it (prompt.begin()+1 .. end()-prompt_init.size())
+               * unconditionally; append this window's tokens only `&& !is_no_speech` */
                 int32_t keep[512]; for (int i = 0; i < last_take; ++i) keep[i] = prompt_past[n_past_tok - last_take + i];
                 n_past_tok = 0;
-                if (!is_no_speech) { for (int i = 0; i < last_take; ++i) prompt_past[n_past_tok++] = keep[i]; for (int i = 0; i < dc.result_len; ++i) prompt_past[n_past_tok++] = tc[i].id; }
+                for (int i = 0; i < last_take; ++i) prompt_past[n_past_tok++] = keep[i];
+                if (!is_no_speech) for (int i = 0; i < dc.result_len; ++i) prompt_past[n_past_tok++] = tc[i].id;
             }
             if (ntc > 0 && !is_no_speech) {
                 int i0 = 0; int64_t t0 = seek + 2 * (tc[0].tid - m->tok_beg); int tl = 0;

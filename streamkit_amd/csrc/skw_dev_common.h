@@ -1,0 +1,77 @@
+// skw_dev_common.h — device helpers shared by the exact (skw_kernels.hip) and the f16-MFMA (skw_kernels_f16.hip) kernels:
+// conversions with pinned rounding, ggml's GELU table lookup, and the GEMM epilogues (identical in both precisions: only the
+// contraction differs).
+#pragma once
+#include "skw_kernels.h"
+#include "../../include/skw_math.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+// f32 -> f16 of an ALREADY ROUNDED f32 value.  The empty asm makes the operand opaque: without it hipcc folds
+// `(half)(a * b)` / `(half)(a + b)` into v_fma_mixlo_f16, which rounds the exact product once (to f16) instead of
+// twice (f32, then f16) and so differs from ggml's f32 -> f16 conversion of an f32 result on ties-after-rounding.
+__device__ __forceinline__ half_t f2h(float f) { asm("" : "+v"(f)); return (half_t)f; }   // v_cvt_f16_f32, RNE
+__device__ __forceinline__ float gelu_dev(float x, const uint16_t* tab) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f) return x;
+    half_t h = f2h(x); uint16_t bits = __builtin_bit_cast(uint16_t, h);
+    uint16_t o = tab[bits];
+    return h2f(__builtin_bit_cast(half_t, o));
+}
+
+union H8 { uint4 u; half_t h[8]; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+union H8v { u32x4 v; half_t h[8]; };
+
+// ------------------------------------------------------------------ epilogues
+template <int EPI>
+__device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, float v) {
+    if (EPI == EPI_F32) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.res) v = v + a.res[(long)m * a.ldres + n];
+        ((float*)a.C)[(long)m * a.ldc + n] = v;
+    } else if (EPI == EPI_F16_KPERM) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(v);
+    } else if (EPI == EPI_GELU_F16_KPERM) {
+        if (a.bias) v = v + a.bias[n];
+        ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+    } else if (EPI == EPI_GELU_F16_KPERM_ROWPAD) {
+        if (a.bias) v = v + a.bias[n];
+        long row = (long)(m / a.n_ctx) * (a.n_ctx + 2) + (m % a.n_ctx) + 1;
+        ((half_t*)a.C)[row * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+    } else if (EPI == EPI_CONV2) {
+        if (a.bias) v = v + a.bias[n];
+        float g = gelu_dev(v, a.gelu_tab);
+        ((float*)a.C)[(long)m * a.ldc + n] = a.pe[(long)(m % a.n_ctx) * a.N + n] + g;
+    } else if (EPI == EPI_HEADS_F16) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        int b = m / a.n_ctx, i = m % a.n_ctx, h = n >> 6, d = n & 63;
+        ((half_t*)a.C)[((long)(b * a.H + h) * a.Tpad + i) * 64 + skw_kperm(d)] = f2h(v);
+    } else if (EPI == EPI_VT_F16) {
+        if (a.bias) v = v + a.bias[m];
+        int b = n / a.n_ctx, key = n % a.n_ctx, h = m >> 6, c = m & 63;
+        ((half_t*)a.C)[((long)(b * a.H + h) * 64 + c) * a.Tpad + skw_kperm(key)] = f2h(v);
+    } else if (EPI == EPI_DEC_QKV) {
+        // fused decoder Q|K|V projection: n in [0,d) -> q (plain, +bias, *scale); [d,2d) -> K cache (*scale); [2d,3d) -> V cache (+bias)
+        const int d = a.n_ctx;
+        if (a.bias) v = v + a.bias[n];
+        if (n < 2 * d) v = v * a.scale;
+        if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+        else {
+            const long po = a.pos_ptr ? (long)a.pos_ptr[(long)m * a.pos_stride] * d : 0;
+            if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + po + (n - d)] = f2h(v);
+            else ((half_t*)a.C3)[(long)m * a.ldc2 + po + (n - 2 * d)] = f2h(v);
+        }
+    } else if (EPI == EPI_F16_PLAIN) {
+        if (a.bias) v = v + a.bias[n];
+        if (a.has_scale) v = v * a.scale;
+        ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+    }
+}
+

@@ -54,7 +54,7 @@ struct skw_model {
     int tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
     int tok_space = -1, tok_sp_dash = -1, tok_sp_quote = -1; std::vector<int> nst_ids; int n_lang = 99;
     // device
-    float *filters = nullptr, *hann = nullptr, *sin_t = nullptr, *cos_t = nullptr; int n_fft_bins = 201;
+    float *filters = nullptr, *hann = nullptr, *sin_t = nullptr, *cos_t = nullptr; int n_fft_bins = 201; int *mel_grp_lo = nullptr, *mel_grp_hi = nullptr;
     uint16_t* gelu_tab = nullptr;
     float* e_pe = nullptr; DevLin conv1, conv2; DevLN ln_post; std::vector<EncLayer> enc;
     float* d_pe = nullptr; DevLin te; DevLN d_ln; std::vector<DecLayer> dec;
@@ -184,6 +184,11 @@ extern "C" skw_model* skw_model_load(const char* path, int device, char* err, si
     auto fail2 = [&]() -> skw_model* { skw_model_free(m); return nullptr; };
     // tables
     m->filters = dev_upload(m, filt.data(), filt.size());
+    {   // per mel filter: the range of 4-bin groups with a non-zero tap (the filterbank comes from the model file; Slaney filters are narrow)
+        std::vector<int> lo(nm, 0), hi(nm, 0);
+        for (int j = 0; j < nm; ++j) { int a = nf, b = -1; for (int k = 0; k < nf; ++k) if (filt[(size_t)j * nf + k] != 0.0f) { a = std::min(a, k); b = std::max(b, k); } if (b >= 0) { lo[j] = a / 4; hi[j] = b / 4 + 1; } }
+        m->mel_grp_lo = dev_upload(m, lo.data(), lo.size()); m->mel_grp_hi = dev_upload(m, hi.data(), hi.size());
+    }
     {
         std::vector<float> sn(WHISPER_N_FFT), cs(WHISPER_N_FFT), hn(WHISPER_N_FFT);
         for (int i = 0; i < WHISPER_N_FFT; ++i) { double theta = (2 * M_PI * i) / WHISPER_N_FFT; sn[i] = sinf(theta); cs[i] = cosf(theta); hn[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / (WHISPER_N_FFT))); }
@@ -264,6 +269,7 @@ extern "C" void skw_full_default_params(skw_full_params* p) {
 // ------------------------------------------------------------------ context / workspace
 struct ProfState;
 struct skw_ctx {
+    int precision = SKW_PRECISION_EXACT;             // SKW_PRECISION_*: which form of the contractions runs (skw_ctx_set_precision)
     ProfState* prof = nullptr;                       // per-kernel-class event timing (skw_ctx_profile); per context: contexts run on different host threads
     skw_model* m = nullptr; int max_batch = 0, max_samples = 0, n_len_max = 0, Tpad = 0;
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
@@ -294,6 +300,11 @@ template <typename T> static T* ws_alloc(skw_ctx* c, size_t n, bool zero = false
     T* d = nullptr; if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr; if (zero) (void)hipMemset(d, 0, n * sizeof(T)); c->allocs.push_back(d); return d;
 }
 extern "C" const char* skw_ctx_last_error(const skw_ctx* c) { return c->errbuf; }
+extern "C" int skw_ctx_set_precision(skw_ctx* c, int precision) {
+    if (precision != SKW_PRECISION_EXACT && precision != SKW_PRECISION_F16_MFMA) { snprintf(c->errbuf, 512, "unknown precision %d", precision); return -1; }
+    c->precision = precision; return 0;
+}
+extern "C" int skw_ctx_get_precision(const skw_ctx* c) { return c->precision; }
 extern "C" void* skw_ctx_stream(const skw_ctx* c) { return (void*)c->stream; }
 extern "C" void skw_ctx_last_timing(const skw_ctx* c, skw_timing* out) { *out = c->timing; }
 
@@ -409,7 +420,11 @@ extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
 static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical; *by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
-static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) { double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by); skw_gemm(a, c->cur); }
+static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
+    double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by);
+    if (c->precision == SKW_PRECISION_F16_MFMA && (a.K & 63) == 0) skw_gemm16(a, c->cur);   // K step of the f16 kernel is 64; every Whisper geometry satisfies it
+    else skw_gemm(a, c->cur);
+}
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by);
     // (a VALU row-parallel variant — lane = batch row, v_fma_mix chains — was measured slower: a dependent v_fma costs 8-10 cycles
@@ -423,7 +438,7 @@ static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, 
 
 // front end for `n` clips already described in c->pcm_off / n_samples / n_len (device): mel + normalisation
 static void run_mel(skw_ctx* c, int n) {
-    skw_model* m = c->m; SkwMelTables t{m->hann, m->sin_t, m->cos_t, m->filters, m->hp.n_mels, m->n_fft_bins};
+    skw_model* m = c->m; SkwMelTables t{m->hann, m->sin_t, m->cos_t, m->filters, m->hp.n_mels, m->n_fft_bins, m->mel_grp_lo, m->mel_grp_hi};
     ProfScope p_(c, PC_MEL, 0, 0);
     skw_mel_frames(c->pcm, c->pcm_off, c->n_samples, c->n_len, n, c->n_len_max, t, c->mel, c->stream);
     skw_mel_normalize(c->mel, c->n_len, n, c->n_len_max, m->hp.n_mels, c->clip_max, c->stream);
@@ -455,7 +470,9 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
         if (l == 0 && g_taps_on) { hipMalloc((void**)&dbg, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc + 64)); hipMemset(dbg, 0, sizeof(float) * ((size_t)nc * d + 2 * (size_t)H * nc)); }
         float* dbg2 = nullptr;
         if (dbg) { hipMalloc((void**)&dbg2, sizeof(float) * 64 * c->Tpad); hipMemset(dbg2, 0, sizeof(float) * 64 * c->Tpad); }
-        { ProfScope p_(c, PC_ATTN_ENC, 4.0 * Bw * H * (double)nc * nc * 64, 2.0 * 4 * M * d); skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2); }
+        { ProfScope p_(c, PC_ATTN_ENC, 4.0 * Bw * H * (double)nc * nc * 64, 2.0 * 4 * M * d);
+          if (c->precision == SKW_PRECISION_F16_MFMA && !dbg) skw_attn_encoder16(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream);
+          else skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2); }
         if (dbg2) { tap(c, "l0.SP", dbg2, 64, c->Tpad, TAP_F32); hipFree(dbg2); }
         if (dbg) { tap(c, "l0.att32", dbg, nc, d, TAP_F32); tap(c, "l0.rmax", dbg + (size_t)nc * d, H, nc, TAP_F32); tap(c, "l0.rinv", dbg + (size_t)nc * d + (size_t)H * nc, H, nc, TAP_F32); hipFree(dbg); }
         if (l == 0) tap(c, "l0.att", c->y16, nc, d, TAP_F16_KPERM);
@@ -632,8 +649,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     lp.n_max = hp.n_text_ctx / 2 - 4;
 
     while (true) {
-        // clips that still have audio to decode ("if only 1 second left, then stop"; "input is too short")
-        std::vector<int> act; for (int i = 0; i < n_clips; ++i) if (n_len_org[i] >= 100 && seek[i] + 100 < n_len_org[i]) act.push_back(i);
+        // clips that still have audio to decode ("if only 100ms left, then stop"; "input is too short": delta_min = 10 frames, whisper.cpp #2065)
+        std::vector<int> act; for (int i = 0; i < n_clips; ++i) if (n_len_org[i] >= SKW_DELTA_MIN && seek[i] + SKW_DELTA_MIN < n_len_org[i]) act.push_back(i);
         if (act.empty()) break;
         const int Bw = (int)act.size();
         std::vector<int> sk(Bw); for (int j = 0; j < Bw; ++j) sk[j] = seek[act[j]];
@@ -715,10 +732,10 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             tidx[ci] = 0;
             int seek_delta = s.seek_delta;
             const bool is_no_speech = (s.no_speech_prob > p->no_speech_thold && avg_logprobs < p->logprob_thold);
-            {   // update prompt_past: what this window's prompt took from it, then this window's tokens
+            {   // update prompt_past: what this window's prompt took from it is always kept; this window's tokens only when it is speech
                 std::vector<int>& pp = prompt_past[ci]; std::vector<int> keep(pp.end() - last_take[ci], pp.end());
-                pp.clear();
-                if (!is_no_speech) { pp = keep; for (int i = 0; i < result_len; ++i) pp.push_back(tk[i].id); }
+                pp = keep;
+                if (!is_no_speech) for (int i = 0; i < result_len; ++i) pp.push_back(tk[i].id);
             }
             if (n_tok > 0 && !is_no_speech) {
                 int i0 = 0; int64_t t0 = seek[ci] + 2 * (tk[0].tid - m->tok_beg); std::string text;

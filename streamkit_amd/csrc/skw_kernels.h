@@ -48,6 +48,9 @@ struct SkwGemmArgs {
 
 // big-M GEMM (LDS-tiled 128x128 block, 4 waves)
 void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
+// f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
+void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
+void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
 
@@ -59,7 +62,8 @@ void skw_layernorm(const float* x, int rows, int d, const float* w, const float*
 void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg = nullptr, float* dbg2 = nullptr);
 
 // log-mel front end
-struct SkwMelTables { const float* hann; const float* sin_t; const float* cos_t; const float* filters; int n_mel; int n_fft_bins; };
+struct SkwMelTables { const float* hann; const float* sin_t; const float* cos_t; const float* filters; int n_mel; int n_fft_bins;
+                      const int* grp_lo; const int* grp_hi; /* per filter: the 4-bin groups [lo, hi) that hold its non-zero taps (may be null: all groups) */ };
 // raw log10 mel: mel_raw [b][frame][n_mel] f32 for frames < n_calc[b]; frames beyond get log10(1e-10)
 void skw_mel_frames(const float* pcm, const long* pcm_off, const int* n_samples, const int* n_len, int B, int n_len_max, SkwMelTables t, float* mel_raw, hipStream_t s);
 // per-clip max -> clamp (max-8) and (x+4)/4, in place; tmp: [B] doubles
@@ -93,6 +97,8 @@ struct SkwSeqState {
     float temperature;     // 0: argmax; > 0: logits / t, then a std::discrete_distribution draw from the clip's mt19937
     int32_t pad;
 };
+// whisper_full_with_state: `const int delta_min = 10` mel frames (100 ms) - shortest input transcribed, the loop's stop rule and the decoder's end-of-audio test
+#define SKW_DELTA_MIN 10
 #define SKW_PROMPT_CAP 240   // [prev] + n_text_ctx/2 past tokens + sot, language, task, notimestamps
 #define SKW_RNG_WORDS 625   // std::mt19937 state per clip: mt[624] + index
 struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum; };

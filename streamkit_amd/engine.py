@@ -69,6 +69,8 @@ def lib():
         L.skw_ctx_free.argtypes = [C.c_void_p]
         L.skw_ctx_last_error.restype = C.c_char_p
         L.skw_ctx_last_error.argtypes = [C.c_void_p]
+        L.skw_ctx_set_precision.argtypes = [C.c_void_p, C.c_int]
+        L.skw_ctx_get_precision.argtypes = [C.c_void_p]
         L.skw_ctx_stream.restype = C.c_void_p
         L.skw_ctx_stream.argtypes = [C.c_void_p]
         L.skw_ctx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
@@ -139,6 +141,16 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError("skw engine: " + lib().skw_ctx_last_error(self.h).decode())
+
+    PRECISIONS = {"exact": 0, "f16_mfma": 1}
+
+    def set_precision(self, name):
+        """'exact' (f32-chain contractions, bit-identical to the oracle) or 'f16_mfma' (f16 matrix cores, token-identical)."""
+        self._check(lib().skw_ctx_set_precision(self.h, self.PRECISIONS[name]))
+
+    def get_precision(self):
+        v = lib().skw_ctx_get_precision(self.h)
+        return [k for k, x in self.PRECISIONS.items() if x == v][0]
 
     def default_params(self):
         p = FullParams()

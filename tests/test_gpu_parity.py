@@ -28,13 +28,13 @@ def eng():
 @pytest.fixture(scope="module")
 def tiny(eng, tiny_model_path):
     m = eng.Model(tiny_model_path)
-    return m, eng.Context(m, max_batch=8, max_samples=16000 * 32), OracleModel(tiny_model_path)
+    return m, eng.Context(m, max_batch=12, max_samples=16000 * 32), OracleModel(tiny_model_path)
 
 
 @pytest.fixture(scope="module")
 def micro(eng, micro_model_path):
     m = eng.Model(micro_model_path)
-    return m, eng.Context(m, max_batch=8, max_samples=16000 * 32), OracleModel(micro_model_path)
+    return m, eng.Context(m, max_batch=12, max_samples=16000 * 32), OracleModel(micro_model_path)
 
 
 def test_arithmetic_contract_bitwise(micro):
@@ -94,7 +94,7 @@ def test_decoder_logits_bit_exact(tiny):
         assert bits_equal(ctx.decode_logits(toks[:n]), d2.step(toks[:n], 0)), n
 
 
-CLIPS = [(0, 480000), (1, 480000), (2, 16000 * 7 + 123), (3, 480768), (4, 16000 * 2), (5, 15000), (6, 16000 * 12)]
+CLIPS = [(0, 480000), (1, 480000), (2, 16000 * 7 + 123), (3, 480768), (4, 16000 * 2), (5, 1500), (6, 16000 * 12), (7, 4800), (8, 14400), (9, 488000)]
 
 
 def _same(rg, ro):
@@ -107,7 +107,7 @@ def _same(rg, ro):
 @pytest.mark.parametrize("suppress_nst", [0, 1])
 def test_full_transcription_matches_oracle_ragged_batch(tiny, suppress_nst):
     _, ctx, om = tiny
-    pcms = [synth.clip(c, n) for c, n in CLIPS]                 # ragged: 30 s, 30.048 s (plugin forced cut), short, < 1 s (empty)
+    pcms = [synth.clip(c, n) for c, n in CLIPS]                 # ragged: 30 s, 30.048 s (plugin forced cut), short, < 100 ms (empty), 0.3 s, 0.9 s, 30.5 s (second window of 0.5 s)
     p = ctx.default_params(); p.suppress_nst = suppress_nst
     po = om.default_params(); po.suppress_nst = suppress_nst
     res = ctx.full_batch(pcms, p)
@@ -151,7 +151,7 @@ def test_device_resident_pcm(tiny):
 
 
 def test_full_size_batch_properties(eng, small_model_path):
-    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on two clips."""
+    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on eight clips."""
     m = eng.Model(small_model_path)
     ctx = eng.Context(m, max_batch=64, max_samples=480000)
     pcms = [synth.clip(c) for c in range(64)]
@@ -170,7 +170,7 @@ def test_full_size_batch_properties(eng, small_model_path):
     assert _same(single, res[17])                                       # batching is exact
     om = OracleModel(small_model_path)
     po = om.default_params(); po.suppress_nst = 1
-    for c in (0, 41):
+    for c in (0, 5, 13, 22, 30, 41, 50, 63):                            # 8 of the 64 clips against the oracle (~6 s of CPU each)
         assert _same(res[c], om.full(pcms[c], po)), c
     ctx.close(); m.close()
 
@@ -239,7 +239,7 @@ def test_language_auto_detection_matches_oracle(tiny):
     """lang_id < 0 = whisper.cpp's language "auto": one extra [sot] step on each clip's first window picks its language; clips of one
     batch may end up with different languages (the prompt's language token is per row)."""
     _, ctx, om = tiny
-    clips = [(31, 16000 * 12), (32, 16000 * 30), (33, 16000 * 5), (34, 8000)]       # the last one is too short to transcribe but still detected
+    clips = [(31, 16000 * 12), (32, 16000 * 30), (33, 16000 * 5), (34, 1400)]       # the last one is too short to transcribe (< 100 ms) but still detected
     pcms = [synth.clip(c, n) for c, n in clips]
     p = ctx.default_params(); p.lang_id = -1
     po = om.default_params(); po.lang_id = -1
@@ -256,7 +256,7 @@ def test_small_model_ragged_multi_window_matches_oracle(eng, small_model_path):
     """Whisper-small dimensions (the benchmark's model) on clips that are not the benchmark's: short, one window, two windows
     (the second conditioned on the first through prompt_past), and too short to transcribe — tokens, timestamps, log-probs vs the oracle."""
     m = eng.Model(small_model_path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 50); om = OracleModel(small_model_path)
-    clips = [(71, 16000 * 7 + 311), (72, 16000 * 30), (73, 16000 * 44), (74, 6000)]
+    clips = [(71, 16000 * 7 + 311), (72, 16000 * 30), (73, 16000 * 44), (74, 1200)]
     pcms = [synth.clip(c, n) for c, n in clips]
     p = ctx.default_params(); p.suppress_nst = 1
     po = om.default_params(); po.suppress_nst = 1
