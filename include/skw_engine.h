@@ -62,7 +62,9 @@ typedef struct {
     int32_t text_off, text_len; /* into skw_result.text */
 } skw_segment;
 
-typedef struct { int32_t id, tid; float p, plog, pt, ptsum; } skw_token;
+typedef struct { int32_t id, tid; float p, plog, pt, ptsum;
+                 float margin;   /* top1 - top2 admissible logit when this token was chosen (+inf on sampled passes): distance from a tie (diagnostic) */
+} skw_token;
 
 typedef struct {
     int32_t n_segments, n_tokens, n_windows, n_decode_steps;

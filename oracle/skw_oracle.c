@@ -683,13 +683,13 @@ static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t*
 
 /* whisper_sample_token(best = true) */
 static skwo_token sample_best(const skwo_model* m, decoder_t* dc) {
-    skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
+    skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, INFINITY}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
     { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i]; if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
     for (int i = 0; i < n; ++i) if (r.p < probs[i]) { r.id = i; r.p = probs[i]; r.plog = dc->logprobs[i]; }
     if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }
     { /* diagnostics: margin between the two largest admissible logits */
         float a = -INFINITY, b = -INFINITY; for (int i = 0; i < n; ++i) { float v = dc->logits[i]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
-        if (b > -INFINITY && a - b < dc->min_margin) dc->min_margin = a - b;
+        if (b > -INFINITY) { r.margin = a - b; if (a - b < dc->min_margin) dc->min_margin = a - b; }
     }
     return r;
 }
@@ -734,7 +734,7 @@ int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, in
 }
 /* whisper_sample_token(best = false) */
 static skwo_token sample_dist(const skwo_model* m, decoder_t* dc, mt19937_t* rng) {
-    skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
+    skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, INFINITY}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
     { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i]; if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
     r.id = discrete_draw(probs, n, rng); r.p = probs[r.id]; r.plog = dc->logprobs[r.id];
     if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }

@@ -62,6 +62,7 @@ typedef struct {
 typedef struct {
     int32_t id, tid;
     float p, plog, pt, ptsum;
+    float margin;                /* top1 - top2 admissible logit at this step (+inf on sampled passes): how close the argmax was to a tie */
 } skwo_token;
 
 typedef struct {

@@ -28,6 +28,15 @@ static const char* const g_lang[] = {"en", "zh", "de", "es", "ru", "ko", "fr", "
     "sl", "kn", "et", "mk", "br", "eu", "is", "hy", "ne", "mn", "bs", "kk", "sq", "sw", "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be",
     "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo", "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue"};
 static const int g_n_lang = (int)(sizeof(g_lang) / sizeof(g_lang[0]));
+// whisper.cpp's g_lang also maps the full language names; whisper_lang_id accepts either spelling
+static const char* const g_lang_name[] = {"english", "chinese", "german", "spanish", "russian", "korean", "french", "japanese", "portuguese", "turkish", "polish", "catalan", "dutch",
+    "arabic", "swedish", "italian", "indonesian", "hindi", "finnish", "vietnamese", "hebrew", "ukrainian", "greek", "malay", "czech", "romanian", "danish", "hungarian", "tamil", "norwegian",
+    "thai", "urdu", "croatian", "bulgarian", "lithuanian", "latin", "maori", "malayalam", "welsh", "slovak", "telugu", "persian", "latvian", "bengali", "serbian", "azerbaijani", "slovenian",
+    "kannada", "estonian", "macedonian", "breton", "basque", "icelandic", "armenian", "nepali", "mongolian", "bosnian", "kazakh", "albanian", "swahili", "galician", "marathi", "punjabi",
+    "sinhala", "khmer", "shona", "yoruba", "somali", "afrikaans", "occitan", "georgian", "belarusian", "tajik", "sindhi", "gujarati", "amharic", "yiddish", "lao", "uzbek", "faroese",
+    "haitian creole", "pashto", "turkmen", "nynorsk", "maltese", "sanskrit", "luxembourgish", "myanmar", "tibetan", "tagalog", "malagasy", "assamese", "tatar", "hawaiian", "lingala", "hausa",
+    "bashkir", "javanese", "sundanese", "cantonese"};
+static_assert(sizeof(g_lang_name) / sizeof(g_lang_name[0]) == sizeof(g_lang) / sizeof(g_lang[0]), "one name per code");
 
 static const char* const NST_LIST[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
     "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))",
@@ -62,8 +71,9 @@ struct skw_model {
 };
 
 template <typename T> static T* dev_upload(skw_model* m, const T* h, size_t n) {
-    T* d = nullptr; if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr;
-    hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice); m->allocs.push_back(d); return d;
+    T* d = nullptr; if (hipMalloc((void**)&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
+    if (n && hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    m->allocs.push_back(d); return d;
 }
 static RawT* find_t(std::vector<RawT>& ts, const std::string& name) { for (auto& t : ts) if (t.name == name) return &t; return nullptr; }
 static const float* as_f32(RawT* t, std::vector<float>& tmp) {
@@ -105,9 +115,19 @@ static bool up_ln(skw_model* m, std::vector<RawT>& ts, const std::string& wname,
 }
 
 extern "C" int skw_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-extern "C" int skw_model_lang_id(const char* lang) { if (!lang) return -1; for (int i = 0; i < g_n_lang; ++i) if (!strcmp(g_lang[i], lang)) return i; return -1; }
+extern "C" int skw_model_lang_id(const char* lang) {
+    if (!lang) return -1;
+    for (int i = 0; i < g_n_lang; ++i) if (!strcmp(g_lang[i], lang)) return i;
+    for (int i = 0; i < g_n_lang; ++i) if (!strcmp(g_lang_name[i], lang)) return i;
+    return -1;
+}
 
+static skw_model* model_load_impl(const char* path, int device, char* err, size_t errlen);
 extern "C" skw_model* skw_model_load(const char* path, int device, char* err, size_t errlen) {
+    try { return model_load_impl(path, device, err, errlen); }
+    catch (const std::exception& e) { set_err(err, errlen, "Failed to load Whisper model from '%s': %s", path ? path : "", e.what()); return nullptr; }   // nothing may unwind across the C ABI
+}
+static skw_model* model_load_impl(const char* path, int device, char* err, size_t errlen) {
     int ndev = skw_device_count();
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: libskw_engine requires an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", device, ndev); return nullptr; }
@@ -119,16 +139,25 @@ extern "C" skw_model* skw_model_load(const char* path, int device, char* err, si
     skw_model* m = new skw_model(); m->device = device;
     auto fail = [&](const char* msg) -> skw_model* { set_err(err, errlen, "Failed to load Whisper model from '%s': %s", path, msg); fclose(f); skw_model_free(m); return nullptr; };
     if (fread(&m->hp, 4, 11, f) != 11) return fail("short hparams");
+    {   // a corrupt header must fail here, not as std::bad_alloc across the C ABI
+        const skw_hparams& h = m->hp;
+        auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+        if (!in(h.n_vocab, 1000, 200000) || !in(h.n_audio_ctx, 1, 4096) || !in(h.n_audio_state, 64, 1536) || !in(h.n_audio_head, 1, 32) || !in(h.n_audio_layer, 1, 64) ||
+            !in(h.n_text_ctx, 8, 4096) || !in(h.n_text_state, 64, 1536) || !in(h.n_text_head, 1, 32) || !in(h.n_text_layer, 1, 64) || !in(h.n_mels, 1, 256)) return fail("implausible hparams");
+    }
     int32_t nm = 0, nf = 0;
     if (fread(&nm, 4, 1, f) != 1 || fread(&nf, 4, 1, f) != 1) return fail("short mel filter header");
+    if (nm < 1 || nm > 256 || nf < 1 || nf > 4096) return fail("implausible mel filter header");
     std::vector<float> filt((size_t)nm * nf);
     if (fread(filt.data(), 4, filt.size(), f) != filt.size()) return fail("short mel filters");
     m->n_fft_bins = nf;
     if (nm != m->hp.n_mels) return fail("mel filter count differs from n_mels");
     int32_t nv = 0; if (fread(&nv, 4, 1, f) != 1) return fail("short vocab");
+    if (nv < 0 || nv > 200000) return fail("implausible vocabulary size");
     const int NV = m->hp.n_vocab; m->tok_str.assign(NV, std::string());
     for (int i = 0; i < nv; ++i) {
         uint32_t len = 0; if (fread(&len, 4, 1, f) != 1) return fail("short vocab");
+        if (len > 4096) return fail("implausible token length");
         std::string s(len, '\0'); if (len && fread(&s[0], 1, len, f) != len) return fail("short vocab");
         if (i < NV) m->tok_str[i] = s;
     }
@@ -167,7 +196,8 @@ extern "C" skw_model* skw_model_load(const char* path, int device, char* err, si
         if (fread(&len, 4, 1, f) != 1 || fread(&tt, 4, 1, f) != 1) return fail("short tensor header");
         RawT t; t.n_dims = nd; t.type = tt; t.n = 1;
         if (nd < 1 || nd > 4 || len < 0 || len > 255) return fail("corrupt tensor header");
-        for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
+        for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header"); if (e < 1 || e > (1 << 24)) return fail("corrupt tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
+        if (t.n > ((size_t)1 << 31)) return fail("corrupt tensor header");
         t.name.resize(len); if (len && fread(&t.name[0], 1, len, f) != (size_t)len) return fail("short tensor name");
         size_t esz = tt == 0 ? 4 : tt == 1 ? 2 : 0;
         if (!esz) {   // block-quantised 2-D weights: decoded to f16 here (include/skw_ggml_quant.h, DEVIATION D4)
@@ -275,7 +305,7 @@ struct skw_ctx {
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     hipStream_t cur = nullptr;                       // stream the launch helpers enqueue on (== stream outside the decode groups)
     static const int MAX_GROUPS = 8; hipStream_t gstream[MAX_GROUPS] = {}; hipEvent_t gev[MAX_GROUPS] = {}; int n_groups = 1;
-    struct StepGraph { int g, r0, n; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
+    struct StepGraph { int g, r0, n, precision; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
     char errbuf[512] = {0};
     std::vector<void*> allocs;
     // front end
@@ -545,7 +575,13 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
 // One generation step of a row group as an executable graph: decoder step (positions and tokens read from the device state),
 // logit filters + sampling, and the read-back of the group's active count.  Captured once per (group, rows, filter params).
 static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogitParams& lp) {
-    for (auto& sg : c->step_graphs) if (sg.g == g && sg.r0 == r0 && sg.n == n && memcmp(&sg.lp, &lp, sizeof lp) == 0) return sg.exec;
+    for (size_t i = 0; i < c->step_graphs.size(); ++i) {
+        auto& sg = c->step_graphs[i];
+        if (sg.g == g && sg.r0 == r0 && sg.n == n && sg.precision == c->precision && memcmp(&sg.lp, &lp, sizeof lp) == 0) {
+            if (i + 1 != c->step_graphs.size()) { auto hit = sg; c->step_graphs.erase(c->step_graphs.begin() + i); c->step_graphs.push_back(hit); }   // most recently used last
+            return c->step_graphs.back().exec;
+        }
+    }
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     run_decoder_step(c, r0, n, 0, true, s);
@@ -554,7 +590,11 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
     hipGraphDestroy(graph);
-    if (exec) { skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg); }
+    if (exec) {
+        // bounded: a long-lived server with ragged batches would otherwise keep one executable graph per (group, rows, params) forever
+        if (c->step_graphs.size() >= 24) { hipGraphExecDestroy(c->step_graphs.front().exec); c->step_graphs.erase(c->step_graphs.begin()); }
+        skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.precision = c->precision; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg);
+    }
     return exec;
 }
 
@@ -741,7 +781,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
                 int i0 = 0; int64_t t0 = seek[ci] + 2 * (tk[0].tid - m->tok_beg); std::string text;
                 auto push = [&](int64_t a, int64_t b, int from, int to) {
                     skw_segment sg{}; sg.t0 = a; sg.t1 = b; sg.tok_begin = (int)A.tok.size();
-                    for (int q = from; q < to; ++q) { skw_token o{tk[q].id, tk[q].tid, tk[q].p, tk[q].plog, tk[q].pt, tk[q].ptsum}; A.tok.push_back(o); }
+                    for (int q = from; q < to; ++q) { skw_token o{tk[q].id, tk[q].tid, tk[q].p, tk[q].plog, tk[q].pt, tk[q].ptsum, tk[q].margin}; A.tok.push_back(o); }
                     sg.tok_end = (int)A.tok.size(); sg.text_off = (int)A.text.size(); sg.text_len = (int)text.size(); A.text += text; A.seg.push_back(sg);
                 };
                 for (int i = 0; i < n_tok; ++i) {
@@ -896,7 +936,11 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
     HIPCHK(hipStreamSynchronize(d->stream));
     if (n > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity %d too small for %d frames", out_cap_frames, n); return -1; }
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n * ch, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-    if ((size_t)n_chunks * chunk >= 16) memcpy(st->hist, in + ((size_t)n_chunks * chunk - 16) * ch, sizeof(float) * 16 * ch);   // buffer.copy_within(chunk.., 0)
+    {   // buffer.copy_within(chunk.., 0): the 16 frames that precede the next chunk (a chunk shorter than 16 frames shifts the old history)
+        const size_t fresh = (size_t)n_chunks * chunk;
+        if (fresh >= 16) memcpy(st->hist, in + (fresh - 16) * ch, sizeof(float) * 16 * ch);
+        else { memmove(st->hist, st->hist + fresh * ch, sizeof(float) * (16 - fresh) * ch); memcpy(st->hist + (16 - fresh) * ch, in, sizeof(float) * fresh * ch); }
+    }
     st->last_index = li; *out_frames = n; return 0;
 }
 // quality mode: Kaiser-windowed sinc, 32 taps x decimation factor per phase, whole buffer at once (mono or interleaved stereo)

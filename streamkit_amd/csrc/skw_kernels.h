@@ -101,7 +101,7 @@ struct SkwSeqState {
 #define SKW_DELTA_MIN 10
 #define SKW_PROMPT_CAP 240   // [prev] + n_text_ctx/2 past tokens + sot, language, task, notimestamps
 #define SKW_RNG_WORDS 625   // std::mt19937 state per clip: mt[624] + index
-struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum; };
+struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum, margin; };
 struct SkwLogitParams {
     int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
     int n_lang; int tok_space, tok_sp_dash, tok_sp_quote;

@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
     tk.plog = lg[tk.id] - lse;
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
+    tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;
     if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
     const int i = n_tok;
     if (i < max_tok) toks[i] = tk;
@@ -1329,6 +1330,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
+    tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;
     if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
     const int i = n_tok;
     if (i < max_tok) toks[i] = tk;

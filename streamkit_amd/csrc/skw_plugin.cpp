@@ -4,11 +4,18 @@
 //   /root/reference/sdks/plugin-sdk/native/src/lib.rs:426-856 (the six extern "C" entry points the macro generates)
 // ABI: include/streamkit_native_abi.h.
 //
-// Differences from the reference that a host can observe are all ADDITIVE params (unknown keys are ignored by the
-// reference's serde config, lib.rs:66-104): vad_mode, batch_window_ms, max_batch, flush_tail.
+// Params beyond the reference's are ADDITIVE (unknown keys are ignored by the reference's serde config, lib.rs:66-104):
+// vad_mode, batch_window_ms, max_batch, flush_tail, precision, and gpu_device: "auto".
+// One BEHAVIOURAL difference remains and is not additive: with the default vad_mode "auto" the Silero model at `vad_model_path`
+// gates what Whisper sees exactly as in the reference (skw_silero.h) only when that file exists; when it does not, the
+// reference fails ("Failed to initialize VAD: ...") while this build logs a warning and falls back to an RMS energy gate
+// (p = rms / (rms + 0.01), so vad_threshold then means a level, not a speech probability).  `vad_mode: "silero"` restores the
+// reference's hard failure.  INTEGRATION.md section D lists this with the other observable differences.
 #include "../../include/streamkit_native_abi.h"
 #include "../../include/skw_engine.h"
 #include "skw_segmenter.h"
+#include "skw_silero.h"
+#include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -47,12 +54,13 @@ struct WhisperConfig {
     uint64_t min_silence_duration_ms = 700;
     float max_segment_duration_secs = 30.0f;
     uint64_t n_threads = 0;
-    bool use_gpu = false; int gpu_device = 0;
+    bool use_gpu = false; int gpu_device = 0; bool gpu_device_auto = false;
     bool suppress_blank = true, suppress_non_speech_tokens = true;
     bool emit_vad_events = false;
     // additive
     std::string vad_mode = "auto";   // auto | silero | energy | always
     int batch_window_ms = 2; int max_batch = 64; bool flush_tail = false;
+    std::string precision = "exact"; // exact | f16_mfma  (include/skw_engine.h, SKW_PRECISION_*)
 };
 
 bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
@@ -65,12 +73,17 @@ bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
     auto num = [&](const char* k, double* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Number) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a number"; return false; } *dst = x->num; return true; };
     auto boo = [&](const char* k, bool* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Bool) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a boolean"; return false; } *dst = x->b; return true; };
     double d;
-    if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode)) return false;
+    if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode) || !str("precision", &cfg->precision)) return false;
+    if (cfg->precision != "exact" && cfg->precision != "f16_mfma") { *err = "Invalid config: precision must be \"exact\" or \"f16_mfma\""; return false; }
     d = cfg->vad_threshold; if (!num("vad_threshold", &d)) return false; cfg->vad_threshold = (float)d;
     d = (double)cfg->min_silence_duration_ms; if (!num("min_silence_duration_ms", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: min_silence_duration_ms must be a non-negative integer"; return false; } cfg->min_silence_duration_ms = (uint64_t)d;
     d = cfg->max_segment_duration_secs; if (!num("max_segment_duration_secs", &d)) return false; cfg->max_segment_duration_secs = (float)d;
     d = (double)cfg->n_threads; if (!num("n_threads", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: n_threads must be a non-negative integer"; return false; } cfg->n_threads = (uint64_t)d;
-    d = cfg->gpu_device; if (!num("gpu_device", &d)) return false; if (d != std::floor(d)) { *err = "Invalid config: gpu_device must be an integer"; return false; } cfg->gpu_device = (int)d;
+    {   // gpu_device: an integer as in the reference (lib.rs:31-33), or (additive) the string "auto": instances are dealt round-robin over the visible GPUs
+        const skw::JsonValue* x = v.get("gpu_device");
+        if (x && x->type == skw::JsonValue::String) { if (x->str != "auto") { *err = "Invalid config: gpu_device must be an integer or \"auto\""; return false; } cfg->gpu_device_auto = true; }
+        else { d = cfg->gpu_device; if (!num("gpu_device", &d)) return false; if (d != std::floor(d)) { *err = "Invalid config: gpu_device must be an integer"; return false; } cfg->gpu_device = (int)d; }
+    }
     d = cfg->batch_window_ms; if (!num("batch_window_ms", &d)) return false; cfg->batch_window_ms = (int)d;
     d = cfg->max_batch; if (!num("max_batch", &d)) return false; cfg->max_batch = std::max(1, (int)d);
     if (!boo("use_gpu", &cfg->use_gpu) || !boo("suppress_blank", &cfg->suppress_blank) || !boo("suppress_non_speech_tokens", &cfg->suppress_non_speech_tokens) ||
@@ -122,7 +135,7 @@ std::mutex g_cache_mu;
 std::map<std::string, std::weak_ptr<SharedEngine>> g_cache;   // weak: the model is released when the last instance goes away
 
 std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, std::string* err) {
-    char keybuf[64]; snprintf(keybuf, sizeof keybuf, "|%d|%d", cfg.use_gpu ? 1 : 0, cfg.gpu_device);
+    char keybuf[96]; snprintf(keybuf, sizeof keybuf, "|%d|%d|%s", cfg.use_gpu ? 1 : 0, cfg.gpu_device, cfg.precision.c_str());   // the reference's key (path, use_gpu, gpu_device) + the additive precision
     const std::string key = cfg.model_path + keybuf;
     std::lock_guard<std::mutex> l(g_cache_mu);
     auto it = g_cache.find(key);
@@ -135,9 +148,19 @@ std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, std::string* 
     eng->max_samples = 16000 * 121;   // schema maximum of max_segment_duration_secs (120 s) + one VAD frame of slack
     eng->ctx = skw_ctx_create(eng->model, eng->max_batch, eng->max_samples, ebuf, sizeof ebuf);
     if (!eng->ctx) { *err = std::string("Failed to create Whisper state: ") + ebuf; return nullptr; }
+    skw_ctx_set_precision(eng->ctx, cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT);
     eng->worker = std::thread([e = eng.get()] { e->run(); });
     g_cache[key] = eng;
     return eng;
+}
+
+// gpu_device: "auto" (additive): instance k of the process runs on GPU k mod n_gpus — one SharedEngine (model copy + batch scheduler)
+// per device, which is how the reference's docs spread pipelines over GPUs by hand (docs/.../deployment/gpu.md:64-66)
+std::atomic<unsigned> g_auto_rr{0};
+void resolve_auto_device(WhisperConfig* cfg) {
+    if (!cfg->gpu_device_auto) return;
+    const int n = skw_device_count();
+    cfg->gpu_device = n > 0 ? (int)(g_auto_rr.fetch_add(1) % (unsigned)n) : 0;
 }
 
 // ------------------------------------------------------------------ the plugin instance (lib.rs:199-221)
@@ -150,17 +173,42 @@ struct WhisperPlugin {
     }
 };
 
+// Silero gate behind the segmenter's Vad interface; the weights of one file are shared by every instance that names it
+struct SileroGate : skw::Vad {
+    skw::SileroVad v;
+    explicit SileroGate(std::shared_ptr<const skw::SileroWeights> w) : v(std::move(w)) {}
+    float process_chunk(const float* f) override { return v.process_chunk(f); }
+    void reset() override { v.reset(); }
+};
+std::mutex g_vad_mu; std::map<std::string, std::weak_ptr<const skw::SileroWeights>> g_vad_cache;
+std::shared_ptr<const skw::SileroWeights> get_silero(const std::string& path, std::string* err) {
+    std::lock_guard<std::mutex> l(g_vad_mu);
+    auto it = g_vad_cache.find(path);
+    if (it != g_vad_cache.end()) if (auto sp = it->second.lock()) return sp;
+    auto w = std::make_shared<skw::SileroWeights>();
+    if (!skw::SileroVad::load_weights(path, w.get(), err)) return nullptr;
+    g_vad_cache[path] = w; return w;
+}
+
+// SileroVAD::new at lib.rs:382-383 ("Failed to initialize VAD: {e}") / :557-560 ("Failed to reload VAD: {e}", added by the caller)
 std::unique_ptr<skw::Vad> make_vad(const WhisperConfig& cfg, WhisperPlugin* p, std::string* err) {
     std::string mode = cfg.vad_mode;
     if (mode == "auto") {
-        // Silero inference (vad.rs:67-120) is not part of this build; the gate that decides what reaches Whisper is
-        // replaced by an energy gate unless the host asks for something else. Logged once per instance.
-        if (p) p->log(SK_LOG_WARN, "Silero VAD model '%s' is not evaluated by this build; using vad_mode=energy (set vad_mode explicitly to silence this)", cfg.vad_model_path.c_str());
-        mode = "energy";
+        struct stat sb;
+        if (stat(cfg.vad_model_path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) mode = "silero";
+        else {
+            // the reference fails here; this build keeps running on an energy gate and says so (header comment)
+            if (p) p->log(SK_LOG_WARN, "Silero VAD model '%s' not found; using vad_mode=energy (set vad_mode to \"silero\" to make this an error)", cfg.vad_model_path.c_str());
+            mode = "energy";
+        }
     }
     if (mode == "always") return std::unique_ptr<skw::Vad>(new skw::AlwaysSpeechVad());
     if (mode == "energy") return std::unique_ptr<skw::Vad>(new skw::EnergyVad());
-    if (mode == "silero") { *err = "Failed to initialize VAD: Silero ONNX inference is not available in this build (use vad_mode energy or always)"; return nullptr; }
+    if (mode == "silero") {
+        std::string e; auto w = get_silero(cfg.vad_model_path, &e);
+        if (!w) { *err = "Failed to initialize VAD: " + e; return nullptr; }
+        return std::unique_ptr<skw::Vad>(new SileroGate(w));
+    }
     *err = "Failed to initialize VAD: unknown vad_mode '" + mode + "'"; return nullptr;
 }
 
@@ -252,11 +300,12 @@ const char* const kSchema =
     "\"max_segment_duration_secs\":{\"type\":\"number\",\"description\":\"Maximum segment duration before forced transcription (seconds)\",\"default\":30.0,\"minimum\":5.0,\"maximum\":120.0},"
     "\"n_threads\":{\"type\":\"integer\",\"description\":\"Number of threads for decoding (0 = auto: min(4, num_cores), 8-12 recommended for modern CPUs)\",\"default\":0,\"minimum\":0,\"maximum\":32},"
     "\"use_gpu\":{\"type\":\"boolean\",\"description\":\"Enable GPU acceleration (this build always runs on the MI355X selected by gpu_device)\",\"default\":false},"
-    "\"gpu_device\":{\"type\":\"integer\",\"description\":\"GPU device ID to use (0 = first GPU, 1 = second GPU, etc.)\",\"default\":0,\"minimum\":0,\"maximum\":7},"
+    "\"gpu_device\":{\"type\":[\"integer\",\"string\"],\"description\":\"GPU device ID to use (0 = first GPU, 1 = second GPU, etc.); (additive) \\\"auto\\\" deals instances round-robin over the visible GPUs\",\"default\":0,\"minimum\":0,\"maximum\":7},"
     "\"suppress_blank\":{\"type\":\"boolean\",\"description\":\"Suppress blank/silent audio segments\",\"default\":true},"
     "\"suppress_non_speech_tokens\":{\"type\":\"boolean\",\"description\":\"Suppress non-speech tokens like [BLANK_AUDIO], [MUSIC], [APPLAUSE], etc.\",\"default\":true},"
     "\"emit_vad_events\":{\"type\":\"boolean\",\"description\":\"Emit VAD speech start/end out-of-band to the telemetry bus (does not flow through graph pins).\",\"default\":false},"
-    "\"vad_mode\":{\"type\":\"string\",\"description\":\"(additive) auto | energy | always | silero\",\"default\":\"auto\"},"
+    "\"vad_mode\":{\"type\":\"string\",\"description\":\"(additive) auto (Silero when vad_model_path exists, else an energy gate) | silero | energy | always\",\"default\":\"auto\"},"
+    "\"precision\":{\"type\":\"string\",\"description\":\"(additive) exact (f32-chain contractions, bit-reproducible) | f16_mfma (f16 matrix cores)\",\"default\":\"exact\"},"
     "\"batch_window_ms\":{\"type\":\"integer\",\"description\":\"(additive) how long the per-GPU scheduler waits for concurrent instances before launching a batch\",\"default\":2},"
     "\"max_batch\":{\"type\":\"integer\",\"description\":\"(additive) largest number of segments transcribed in one GPU batch\",\"default\":64},"
     "\"flush_tail\":{\"type\":\"boolean\",\"description\":\"(additive) transcribe buffered speech when the input stream ends (the reference drops it)\",\"default\":false}"
@@ -276,6 +325,7 @@ CPluginHandle plugin_create_instance(const char* params, CLogCallback log_cb, vo
     auto p = std::unique_ptr<WhisperPlugin>(new WhisperPlugin()); p->log_cb = log_cb; p->log_ud = log_ud;
     std::string err;
     if (!parse_config(params, &p->config, &err)) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
+    resolve_auto_device(&p->config);
     p->engine = get_engine(p->config, &err);
     if (!p->engine) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     p->vad = make_vad(p->config, p.get(), &err);
@@ -315,14 +365,15 @@ CResult plugin_update_params(CPluginHandle handle, const char* params) {
     WhisperConfig nc;   // serde deserialises a fresh config from the new JSON (defaults for missing keys), lib.rs:498-499
     std::string err;
     if (!parse_config(params, &nc, &err)) return err_result(err);
-    if (nc.model_path != self->config.model_path || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
+    if (nc.gpu_device_auto) nc.gpu_device = self->config.gpu_device;        // an "auto" instance stays on the device it was dealt
+    if (nc.model_path != self->config.model_path || nc.precision != self->config.precision || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
         auto eng = get_engine(nc, &err);
         if (!eng) return err_result("Failed to reload Whisper model: " + err);
         self->engine = eng;
     }
     if (nc.vad_model_path != self->config.vad_model_path || nc.vad_threshold != self->config.vad_threshold || nc.vad_mode != self->config.vad_mode) {
         auto v = make_vad(nc, self, &err);
-        if (!v) return err_result("Failed to reload VAD: " + err);
+        if (!v) { const std::string pre = "Failed to initialize VAD: "; return err_result("Failed to reload VAD: " + (err.compare(0, pre.size(), pre) == 0 ? err.substr(pre.size()) : err)); }
         self->vad = std::move(v);
     }
     if (nc.min_silence_duration_ms != self->config.min_silence_duration_ms) self->seg.set_min_silence_ms(nc.min_silence_duration_ms);

@@ -31,7 +31,7 @@ class Segment(C.Structure):
 
 
 class Token(C.Structure):
-    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float), ("margin", C.c_float)]
 
 
 class Result(C.Structure):
@@ -101,7 +101,7 @@ def lib():
 
 def _result_to_dict(r):
     text = C.string_at(r.text, r.text_len) if r.text else b""
-    toks = [(r.tokens[i].id, r.tokens[i].tid, r.tokens[i].p, r.tokens[i].plog) for i in range(r.n_tokens)]
+    toks = [(r.tokens[i].id, r.tokens[i].tid, r.tokens[i].p, r.tokens[i].plog, r.tokens[i].margin) for i in range(r.n_tokens)]
     segs = [dict(t0=r.segments[i].t0, t1=r.segments[i].t1,
                  tokens=[t[0] for t in toks[r.segments[i].tok_begin:r.segments[i].tok_end]],
                  text=text[r.segments[i].text_off:r.segments[i].text_off + r.segments[i].text_len]) for i in range(r.n_segments)]

@@ -100,7 +100,7 @@ CLIPS = [(0, 480000), (1, 480000), (2, 16000 * 7 + 123), (3, 480768), (4, 16000 
 def _same(rg, ro):
     return ([t[0] for t in rg["tokens"]] == [t[0] for t in ro["tokens"]] and
             [(s["t0"], s["t1"], s["text"]) for s in rg["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in ro["segments"]] and
-            [t[3] for t in rg["tokens"]] == [t[3] for t in ro["tokens"]] and
+            [t[3] for t in rg["tokens"]] == [t[3] for t in ro["tokens"]] and [t[4] for t in rg["tokens"]] == [t[4] for t in ro["tokens"]] and
             rg["n_windows"] == ro["n_windows"] and rg["fallback_requested"] == ro["fallback_requested"])
 
 

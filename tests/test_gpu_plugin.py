@@ -154,3 +154,78 @@ def test_concurrent_instances_form_batches_and_keep_their_own_results(plugin, ti
         outs = node.outputs()
         assert len(outs) == 1 and json.loads(outs[0][2].decode()) == _expected_transcription(om, pcm, 0)
         node.destroy()
+
+
+def test_silero_vad_gates_what_whisper_sees(plugin, tiny_model_path):
+    """W2: with a Silero model file at vad_model_path (vad_mode auto) the 512-sample frames are gated by the restated v5 network
+    (vad.rs:67-120 contract); the oracle's own Silero probabilities + the segmentation oracle say which samples reach Whisper."""
+    from silero_lib import OracleSilero, speechlike, synth_silero_path
+    om = OracleModel(tiny_model_path)
+    vad_path = synth_silero_path()
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_model_path": vad_path, "min_silence_duration_ms": 320, "emit_vad_events": True})
+    assert not any("energy" in l for l in node.logs())                       # auto -> silero because the file exists
+    pattern = ((20, 0.0), (150, 0.25), (40, 0.0), (100, 0.2), (45, 0.0))
+    pcm = speechlike(355, seed=2, pattern=pattern)
+    _feed(node, pcm, packet=960)
+    ov = OracleSilero(vad_path)
+    prob = np.array([ov.process_chunk(pcm[i * 512:(i + 1) * 512]) for i in range(355)], np.float32)
+    cuts = oracle_lib.segment_sim(prob, 0.5, 320, 30.0)
+    assert len(cuts) == 2 and all(c[3] == 1 for c in cuts)                   # two silence cuts
+    speech_frames = np.flatnonzero(prob >= 0.5)
+    outs = node.outputs()
+    assert len(outs) == 2
+    pos = 0
+    for (start_ms, end_ms, n_samples, _, _, _), out in zip(cuts, outs):
+        idx = speech_frames[pos:pos + n_samples // 512]; pos += n_samples // 512
+        seg = np.concatenate([pcm[i * 512:(i + 1) * 512] for i in idx])
+        assert idx[0] * 32 == start_ms
+        assert json.loads(out[2].decode()) == _expected_transcription(om, seg, start_ms)
+    tel = [t for t in node.telemetry() if t[0] == "vad.speech_start"]
+    assert len(tel) == 2 and abs(tel[0][1]["speech_probability"] - float(prob[speech_frames[0]])) < 1e-6
+    node.destroy()
+
+
+def test_vad_modes_and_failure_strings(plugin, tiny_model_path, tmp_path):
+    from silero_lib import synth_silero_path
+    with pytest.raises(RuntimeError) as e:                                    # lib.rs:382-383 + vad.rs:46
+        plugin.create_node({"model_path": tiny_model_path, "vad_mode": "silero", "vad_model_path": str(tmp_path / "nope.onnx")})
+    assert "Failed to initialize VAD: Failed to load VAD model from '%s'" % (tmp_path / "nope.onnx") in str(e.value)
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_model_path": str(tmp_path / "nope.onnx")})   # auto + no file: energy gate, logged
+    assert any("using vad_mode=energy" in l for l in node.logs())
+    assert node.update_params({"model_path": tiny_model_path, "vad_mode": "silero", "vad_model_path": str(tmp_path / "nope.onnx")}) == -1
+    assert node.last_error().startswith("Failed to reload VAD: Failed to load VAD model from")                    # lib.rs:557-560
+    assert node.update_params({"model_path": tiny_model_path, "vad_model_path": synth_silero_path()}) == 0
+    node.destroy()
+
+
+def test_precision_param_f16_mfma(plugin, tiny_model_path):
+    """(additive) precision: "f16_mfma" runs the f16 matrix-core kernels behind the same ABI; the transcript equals the exact
+    instance's unless the exact argmax was a near-tie (tests/test_gpu_f16.py holds the detailed bar)."""
+    pcm = synth.clip(4, 16000 * 12)
+    outs = {}
+    for prec in ("exact", "f16_mfma"):
+        node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True, "precision": prec})
+        _feed(node, pcm); assert node.flush() == 0
+        o = node.outputs(); assert len(o) == 1
+        outs[prec] = json.loads(o[0][2].decode()); node.destroy()
+    a, b = outs["exact"], outs["f16_mfma"]
+    assert [s["start_time_ms"] for s in a["segments"]][:1] == [s["start_time_ms"] for s in b["segments"]][:1] and b["text"]
+    with pytest.raises(RuntimeError):
+        plugin.create_node({"model_path": tiny_model_path, "precision": "bf8"})
+
+
+def test_gpu_device_auto_deals_instances_over_gpus(plugin, tiny_model_path):
+    """(additive) gpu_device: "auto": instance k -> GPU k mod n.  On a one-GPU box every instance lands on device 0 and shares one engine."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    nodes = [plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True, "gpu_device": "auto"}) for _ in range(max(2, n_dev))]
+    pcm = synth.clip(6, 16000 * 6)
+    want = None
+    for nd in nodes:
+        _feed(nd, pcm); assert nd.flush() == 0
+        o = nd.outputs(); assert len(o) == 1
+        want = want or o[0][2]
+        assert o[0][2] == want                                                # every GPU gives the same transcript (exact mode)
+        nd.destroy()
+    with pytest.raises(RuntimeError):
+        plugin.create_node({"model_path": tiny_model_path, "gpu_device": "first"})
