@@ -493,6 +493,7 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
         { SkwGemmArgs a = gemm_args(c->y16, d, L.k, M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; GEMM(c, a, d); }
         { // V^T via the swapped product: rows = features (weights as the A operand), columns = tokens
             SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt; a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
+            if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.v.w; a.ldw = L.v.k_pad; a.M = M; a.N = L.v.n_out; }   // the f16 kernel takes V^T in the natural orientation (tokens x features)
             GEMM(c, a, d);
         }
         if (l == 0) { tap(c, "l0.q", c->Qh, nc, d, TAP_HEADS); tap(c, "l0.k", c->Kh, nc, d, TAP_HEADS); tap(c, "l0.v", c->Vt, nc, d, TAP_VT); }
@@ -524,6 +525,7 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
             { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; GEMM(c, a, d); }
             { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
                 SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv; a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
+                if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; }
                 GEMM(c, a, d);
             }
         }

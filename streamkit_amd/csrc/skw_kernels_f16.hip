@@ -25,14 +25,71 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 1-KiB piece = 8 rows x 128 B per wave-instruction); the LDS image is lane-linear, so the bank swizzle (16-byte chunk c of row
 // r sits at chunk position c ^ (r & 7)) is applied to the per-lane SOURCE address and again on the fragment reads.  Two LDS
 // buffers, one barrier per K step: the DMA of step k+1 flies under the MFMAs of step k.
+//
+// Epilogue shape.  The MFMA hands a lane FOUR CONSECUTIVE ROWS of its first operand (rows 4g .. 4g+3) for one column of the
+// second.  The operand that supplies those rows ("X") is therefore the one whose index runs along memory in the output: the
+// weights (n) for every row-major / per-head output, the tokens for V^T.  When the output's n (or key) axis is stored in kperm
+// order, the X tile's LDS row c is loaded from source row perm(c) (a free choice: the DMA source address is per lane), so that
+// LDS row order == memory order and each lane owns 4 adjacent output elements: one 8-byte (f16) or 16-byte (f32) store per
+// MFMA tile instead of four 2- / 4-byte scatters.  The arithmetic per element is unchanged (bias, scale, GELU table, f16 rounding).
+__device__ __forceinline__ int inv_kperm32(int p) { return ((p & 7) << 2) | ((p >> 3) & 3); }      // memory position in a 32-block -> logical index
+template <int EPI> struct Epi16 {
+    static constexpr bool X_IS_M = (EPI == EPI_VT_F16);                                              // V^T: memory runs along the tokens
+    static constexpr bool PERM = (EPI == EPI_F16_KPERM || EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD || EPI == EPI_HEADS_F16 || EPI == EPI_VT_F16);
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// four adjacent output elements: memory position p0 .. p0+3 along X (p0 % 4 == 0), logical X indices x[0..3], the other index y
+template <int EPI>
+__device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, const int (&x)[4], f32x4 v) {
+    if (EPI == EPI_F32) {                       // X = n, natural order: x[r] = p0 + r
+        if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
+        if (a.res) { const f32x4 r = *(const f32x4*)(a.res + (long)y * a.ldres + p0); v[0] = v[0] + r[0]; v[1] = v[1] + r[1]; v[2] = v[2] + r[2]; v[3] = v[3] + r[3]; }
+        *(f32x4*)((float*)a.C + (long)y * a.ldc + p0) = v;
+    } else if (EPI == EPI_CONV2) {
+        const f32x4 b = *(const f32x4*)(a.bias + p0); const f32x4 pe = *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + p0);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = pe[r] + gelu_dev(v[r] + b[r], a.gelu_tab);
+        *(f32x4*)((float*)a.C + (long)y * a.ldc + p0) = o;
+    } else if (EPI == EPI_F16_PLAIN) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float t = v[r]; if (a.bias) t = t + a.bias[p0 + r]; if (a.has_scale) t = t * a.scale; o[r] = f2h(t); }
+        *(f16x4*)((half_t*)a.C + (long)y * a.ldc + p0) = o;
+    } else if (EPI == EPI_F16_KPERM || EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD || EPI == EPI_HEADS_F16) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = v[r]; if (a.bias) t = t + a.bias[x[r]];
+            if (EPI == EPI_F16_KPERM || EPI == EPI_HEADS_F16) { if (a.has_scale) t = t * a.scale; o[r] = f2h(t); }
+            else o[r] = f2h(gelu_dev(t, a.gelu_tab));
+        }
+        long row;
+        if (EPI == EPI_GELU_F16_KPERM_ROWPAD) row = ((long)(y / a.n_ctx) * (a.n_ctx + 2) + (y % a.n_ctx) + 1) * a.ldc + p0;
+        else if (EPI == EPI_HEADS_F16) { const int b = y / a.n_ctx, i = y % a.n_ctx; row = ((long)(b * a.H + (p0 >> 6)) * a.Tpad + i) * 64 + (p0 & 63); }
+        else row = (long)y * a.ldc + p0;
+        *(f16x4*)((half_t*)a.C + row) = o;
+    } else if (EPI == EPI_VT_F16) {             // X = virtual token row b * Tpad + key (memory position p0 = b * Tpad + key position), y = feature
+        const int b = p0 / a.Tpad, kp = p0 % a.Tpad; const float bias = a.bias ? a.bias[y] : 0.0f;
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (x[r] % a.Tpad < a.n_ctx) ? f2h(a.bias ? v[r] + bias : v[r]) : (half_t)0.0f;    // pad keys stay zero
+        *(f16x4*)((half_t*)a.C + ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp) = o;
+    }
+}
+
 template <int EPI, int BM, int BN, int NWM, int NWN>
 __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwGemmArgs a) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_PIECES = BM / 8 / NW, B_PIECES = BN / 8 / NW;      // 1-KiB pieces per wave per K step
+    constexpr bool X_IS_M = Epi16<EPI>::X_IS_M, PERM = Epi16<EPI>::PERM;
+    constexpr int TX = X_IS_M ? TM : TN, TY = X_IS_M ? TN : TM;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "whole pieces per wave");
     __shared__ __attribute__((aligned(1024))) char lds[2 * (BM + BN) * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nbn = (a.N + BN - 1) / BN, nbm = (a.M + BM - 1) / BM, nblk = nbn * nbm;
+    // V^T: the M axis is walked in virtual rows b * Tpad + key so that 32-key kperm blocks never straddle two clips
+    const int Mv = X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
+    const int nbn = (a.N + BN - 1) / BN, nbm = (Mv + BM - 1) / BM, nblk = nbn * nbm;
     int bid = blockIdx.x;
     { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }   // XCD-aware, bijective
     const int bm = bid / nbn, bn = bid % nbn;       // the n-tiles of one m-tile run back to back on one XCD: the A panel is read from HBM once
@@ -44,13 +101,17 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     const half_t* gA[A_PIECES]; const half_t* gB[B_PIECES];
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
-        int gm = m0 + (wave * A_PIECES + i) * 8 + prow; if (gm > a.M - 1) gm = a.M - 1;     // rows past M are computed on a copy of the last row and never stored
+        int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
+        int gm = m0 + c;
+        if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
+        if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
         const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
         gA[i] = a.A + off + pchunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i) {
-        int gn = n0 + (wave * B_PIECES + i) * 8 + prow; if (gn > a.N - 1) gn = a.N - 1;
+        int c = (wave * B_PIECES + i) * 8 + prow; if (!X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
+        int gn = n0 + c; if (gn > a.N - 1) gn = a.N - 1;
         gB[i] = a.W + (long)gn * a.ldw + pchunk * 8;
     }
     auto stage = [&](int buf, int kb) {
@@ -62,14 +123,15 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
         for (int i = 0; i < B_PIECES; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 0);
     };
-    f32x4 acc[TM][TN];
+    f32x4 acc[TX][TY];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TX; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // fragment read offsets inside a buffer: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * khalf + g; row & 7 == r16 & 7
     const int fo0 = ((g ^ (r16 & 7)) << 4), fo1 = fo0 ^ 64;
     const int aoff = (wr * WTM + r16) * 128, boff = BM * 128 + (wc * WTN + r16) * 128;
+    const int xoff = X_IS_M ? aoff : boff, yoff = X_IS_M ? boff : aoff;
     const int nk = a.K >> 6;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -80,38 +142,46 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int fo = kk ? fo1 : fo0;
-            f16x8 fa[TM], fb[TN];
+            f16x8 fx[TX], fy[TY];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) fb[t] = *(const f16x8*)(base + boff + t * 2048 + fo);
+            for (int t = 0; t < TX; ++t) fx[t] = *(const f16x8*)(base + xoff + t * 2048 + fo);
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *(const f16x8*)(base + aoff + t * 2048 + fo);
+            for (int t = 0; t < TY; ++t) fy[t] = *(const f16x8*)(base + yoff + t * 2048 + fo);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TX; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MFMA16X32(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TY; ++j) acc[i][j] = MFMA16X32(fx[i], fy[j], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    const int x_base = (X_IS_M ? m0 + wr * WTM : n0 + wc * WTN) + 4 * g, y_base = (X_IS_M ? n0 + wc * WTN : m0 + wr * WTM) + r16;
+    const int x_lim = X_IS_M ? Mv : a.N, y_lim = X_IS_M ? a.N : a.M;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TX; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TY; ++j) {
+            const int p0 = x_base + i * 16, y = y_base + j * 16;
+            if (p0 < x_lim && y < y_lim) {
+                int x[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * WTM + i * 16 + g * 4 + r, n = n0 + wc * WTN + j * 16 + r16;
-                if (m < a.M && n < a.N) epi_store<EPI>(a, m, n, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) x[r] = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;
+                epi_store4<EPI>(a, y, p0, x, acc[i][j]);
             }
+        }
 }
 
 template <int EPI> static void launch_gemm16(const SkwGemmArgs& a, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves) when both extents fill it, 128 x 128 (4 waves, two blocks per CU) otherwise
     static const int force = getenv("SKW_GEMM16_TILE") ? atoi(getenv("SKW_GEMM16_TILE")) : 0;
-    const bool big = force ? force == 256 : (a.M >= 256 && a.N >= 256 && a.M % 256 == 0 && a.N % 256 == 0);
-    if (big) hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(((a.M + 255) / 256) * ((a.N + 255) / 256)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(((a.M + 127) / 128) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
+    const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
+    const bool big = force ? force == 256 : (Mv >= 256 && a.N >= 256 && Mv % 256 == 0 && a.N % 256 == 0);
+    if (big) hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(((Mv + 255) / 256) * ((a.N + 255) / 256)), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(((Mv + 127) / 128) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
 }
-// f16-MFMA form of skw_gemm (K must be a multiple of 64: every Whisper geometry's state, 4 x state and conv im2col widths are)
+// f16-MFMA form of skw_gemm.  Requirements (every Whisper geometry meets them): K % 64 == 0, N % 32 == 0, ldc / ldres % 4 == 0.
+// EPI_VT_F16 is called in the NATURAL orientation here (A = tokens [M][K], W = weights [N][K], bias per n), unlike the exact
+// kernel's operand-swapped call: the output is the same V^T image.
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
     switch (a.epi) {
         case EPI_F32: launch_gemm16<EPI_F32>(a, s); break;

@@ -76,7 +76,7 @@ def test_dynamic_sessions_eight_paced_streams(tiny_model_path):
     plug = minihost.Plugin(); L = minihost.lib()
     L.mh_run_paced.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_long, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.mh_run_paced.restype = C.c_int
-    n, ut, gap = 8, 16000 * 3, 16000 * 1
+    n, ut, gap = 8, 512 * 94, 512 * 32                                           # 3.008 s utterances, 1.024 s gaps: whole VAD frames
     pcms, utts = [], []
     for i in range(n):
         x = np.zeros(ut * 2 + gap * 2, np.float32); u = []
