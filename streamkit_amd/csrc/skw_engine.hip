@@ -459,6 +459,7 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM_SMALL, fl, by);
     // (a VALU row-parallel variant — lane = batch row, v_fma_mix chains — was measured slower: a dependent v_fma costs 8-10 cycles
     //  on gfx950, no better than the MFMA's 40 cycles per 4 k)
+    if (c->precision == SKW_PRECISION_F16_MFMA && skw_gemm16_small(a, c->cur)) return;
     skw_gemm_smallm(a, c->cur);
 }
 
@@ -534,7 +535,7 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
 }
 
 // one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
-__global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; }
+__global__ void k_set_tokens(SkwSeqState* st, int tok, int pos) { st[blockIdx.x].cur_token = tok; st[blockIdx.x].cur_pos = pos; st[blockIdx.x].active = 1; }
 // whisper_lang_auto_detect_with_state: the language whose token has the largest logit after the [sot] step (lowest id on a tie)
 __global__ void k_lang_argmax(const float* logits, int n_vocab, int tok_sot, int n_lang, int* out) {
     const float* lg = logits + (long)blockIdx.x * n_vocab; float bv = -INFINITY; int bi = 0x7fffffff;
@@ -557,11 +558,11 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, dy16, nullptr, s); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, s); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, dy16, nullptr, s); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, s); }
+        { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
         { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, dy16, nullptr, s); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }

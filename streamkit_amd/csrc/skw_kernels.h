@@ -50,6 +50,7 @@ struct SkwGemmArgs {
 void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
 // f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
+bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
@@ -76,11 +77,12 @@ void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, cons
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s);
+// active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s);
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, hipStream_t s);
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s);
 
 // per-sequence decoding state kept on the device (whisper_decoder + the bits of whisper_full_with_state's loop that depend on it)
 struct SkwSeqState {

@@ -762,10 +762,11 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // A block is 4 waves = 4 heads of one sequence.
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
-                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo) {
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
+    if (active && !active[b * active_stride]) return;      // a finished sequence keeps its slot in the batch but no longer reads its caches (its row is never sampled again)
     const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
     const half_t* K = kbase + (long)b * batch_stride + h * 64;
     const half_t* V = vbase + (long)b * batch_stride + h * 64;
@@ -860,7 +861,8 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
 template <int MAXT, int WPH>
 __global__ __launch_bounds__(192 * WPH, 1) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
-                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo) {
+                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride) {
+    if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
     __shared__ float plds[3][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[3 * WPH][64 * 72];
     __shared__ float smax[3][WPH];
@@ -982,19 +984,20 @@ __global__ __launch_bounds__(192 * WPH, 1) void k_dec_cross_attn(const half_t* q
             for (int r = 0; r < 4; ++r) out[(long)b * ldo + skw_kperm(h * 64 + (half * CT + ct) * 16 + 4 * g + r)] = f2h(oacc[ct][r]);
     }
 }
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, hipStream_t s) {
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
-    if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d);
+    const int as = (int)(sizeof(SkwSeqState) / 4);
+    if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, hipStream_t s) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d);
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4));
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d);
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

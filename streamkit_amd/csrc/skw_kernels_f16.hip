@@ -339,3 +339,102 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
     const int qblocks = (n_ctx + A16_QB - 1) / A16_QB;
     hipLaunchKernelGGL(k_attn_encoder16, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks);
 }
+
+// ------------------------------------------------------------------ decode GEMM (M <= 64 rows per block row), f16 MFMA
+// Weight-streaming form for the batched single-token step (K8-K10).  One workgroup = one 16-column strip of W x 64 rows of A;
+// its four waves split the K axis (each chains its quarter on the matrix cores: K/128 MFMAs per row tile instead of the exact
+// kernel's K/4 dependent f32 MFMAs), the partial tiles meet in LDS and wave t finishes row tile t.  As in k_gemm16 the weights
+// are the MFMA's first operand, so a lane ends up with four adjacent outputs of one row: 16-byte residual loads and stores.
+// Operands come straight from global memory (16-byte buffer loads with hardware range checks; a ring of RD k-blocks in flight).
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
+    constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
+    constexpr int RD = 6;
+    __shared__ f32x4 red[4][4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16, my0 = blockIdx.y * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nkw = (a.K >> 5) >> 2, kb_lo = w * nkw;                 // k-blocks (of 32) per wave; host guarantees K % 128 == 0
+    int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+    const unsigned oob = 0x7fffff00u;
+    const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    unsigned ao[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
+    u32x4 fw[RD], fa[RD][4];
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        const bool in = j < nkw;
+        fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * 64 : oob, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb0 = 0; kb0 < nkw; kb0 += RD) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+            const f16x8 xw = __builtin_bit_cast(f16x8, fw[j]);
+            f16x8 xa[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[t] = __builtin_bit_cast(f16x8, fa[j][t]);
+            const int nb = kb0 + j + RD; const bool in = nb < nkw;       // refill the slot just read (zeros past the wave's K range: fma(0, 0, acc) == acc)
+            fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * 64 : oob, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16X32(xw, xa[t], acc[t]);          // D[n = 4g + r][m = 16 t + r16]
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[w][t][lane] = acc[t];
+    __syncthreads();
+    const int t = w;                                   // wave t finishes row tile t
+    f32x4 v = red[0][t][lane];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
+    const int m = my0 + t * 16 + r16, p0 = n0 + 4 * g;
+    if (m >= a.M || p0 >= a.N) return;
+    if (EPI == EPI_F32) {
+        if ((a.ldc & 3) || p0 + 3 >= a.N) {            // logits: ldc = n_vocab is odd and the last strip is ragged
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
+        } else { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F32>(a, m, p0, x, v); }
+    } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
+    else if (EPI == EPI_GELU_F16_KPERM) {
+        int x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31);
+        epi_store4<EPI_GELU_F16_KPERM>(a, m, p0, x, v);
+    } else if (EPI == EPI_DEC_QKV) {                   // n in [0, d): q (+bias, *scale); [d, 2d): K cache (*scale); [2d, 3d): V cache (+bias)
+        const int d = a.n_ctx; f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (p0 < 2 * d) x = x * a.scale; o[r] = f2h(x); }
+        if (p0 < d) *(f16x4*)((half_t*)a.C + (long)m * a.ldc + p0) = o;
+        else {
+            const long po = a.pos_ptr ? (long)a.pos_ptr[(long)m * a.pos_stride] * d : 0;
+            half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
+            *(f16x4*)dst = o;
+        }
+    }
+}
+template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((k_gemm16_small<EPI>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
+}
+// f16-MFMA form of skw_gemm_smallm; returns false when the geometry is outside what it handles (K % 128 != 0): the caller then
+// launches the exact kernel, which handles everything.
+bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
+    if (a.K & 127) return false;
+    switch (a.epi) {
+        case EPI_F32: launch_gemm16_small<EPI_F32>(a, s); return true;
+        case EPI_F16_PLAIN: launch_gemm16_small<EPI_F16_PLAIN>(a, s); return true;
+        case EPI_GELU_F16_KPERM: launch_gemm16_small<EPI_GELU_F16_KPERM>(a, s); return true;
+        case EPI_DEC_QKV: launch_gemm16_small<EPI_DEC_QKV>(a, s); return true;
+        default: return false;
+    }
+}
