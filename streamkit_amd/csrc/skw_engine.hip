@@ -904,7 +904,8 @@ extern "C" int skw_debug_math(skw_ctx* c, int kind, const float* in, float* out,
 
 // ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
 struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
-                 size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0; };
+                 size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0;
+                 double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flag = 0; };
 extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
     int ndev = skw_device_count();
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: the resampler kernels require an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
@@ -913,7 +914,7 @@ extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&d->d_n, sizeof(int)) != hipSuccess || hipMalloc((void**)&d->d_li, sizeof(double)) != hipSuccess) { set_err(err, errlen, "device allocation failed"); delete d; return nullptr; }
     return d;
 }
-extern "C" void skw_dsp_free(skw_dsp* d) { if (!d) return; hipSetDevice(d->device); hipStreamSynchronize(d->stream); hipFree(d->d_in); hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); hipFree(d->d_coef); hipFree(d->d_n); hipFree(d->d_li); hipStreamDestroy(d->stream); delete d; }
+extern "C" void skw_dsp_free(skw_dsp* d) { if (!d) return; hipSetDevice(d->device); hipStreamSynchronize(d->stream); hipFree(d->d_in); hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); hipFree(d->d_coef); hipFree(d->d_n); hipFree(d->d_li); hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset); hipFree(d->d_flag); hipStreamDestroy(d->stream); delete d; }
 extern "C" const char* skw_dsp_last_error(const skw_dsp* d) { return d->errbuf; }
 static int dsp_reserve(skw_dsp* d, size_t n_in, size_t n_out) {
     char* errbuf = d->errbuf;
@@ -933,9 +934,16 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
     if (dsp_reserve(d, n_in, (size_t)out_cap_frames * ch)) return -1;
     HIPCHK(hipMemcpyAsync(d->d_in, st->hist, sizeof(float) * 16 * ch, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipMemcpyAsync(d->d_in + 16 * ch, in, sizeof(float) * (size_t)n_chunks * chunk * ch, hipMemcpyHostToDevice, d->stream));
-    skw_resample_linear_launch(d->d_in, ch, st->last_index, 1.0 / st->ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames, d->stream);
+    if ((size_t)n_chunks + 1 > d->cap_chunks) {
+        hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset); d->cap_chunks = ((size_t)n_chunks + 1) * 2;
+        HIPCHK(hipMalloc((void**)&d->d_start, d->cap_chunks * sizeof(double))); HIPCHK(hipMalloc((void**)&d->d_count, d->cap_chunks * sizeof(int))); HIPCHK(hipMalloc((void**)&d->d_offset, d->cap_chunks * sizeof(int)));
+        if (!d->d_flag) HIPCHK(hipMalloc((void**)&d->d_flag, sizeof(int)));
+    }
+    skw_resample_linear_launch(d->d_in, ch, st->last_index, 1.0 / st->ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames,
+                               d->d_start, d->d_count, d->d_offset, d->d_flag, d->stream);
     int n = 0; double li = 0;
     HIPCHK(hipMemcpyAsync(&n, d->d_n, sizeof(int), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipMemcpyAsync(&li, d->d_li, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(&d->last_flag, d->d_flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     if (n > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity %d too small for %d frames", out_cap_frames, n); return -1; }
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n * ch, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
@@ -946,34 +954,96 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
     }
     st->last_index = li; *out_frames = n; return 0;
 }
-// quality mode: Kaiser-windowed sinc, 32 taps x decimation factor per phase, whole buffer at once (mono or interleaved stereo)
-extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_frames, int channels, int in_rate, int out_rate, float* out, long out_cap_frames, long* out_frames) {
-    char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device));
+// quality mode: Kaiser-windowed sinc, 32 taps x decimation factor per phase (mono or interleaved stereo)
+static int dsp_polyphase_coefs(skw_dsp* d, int in_rate, int out_rate, int* L_o, int* M_o, int* T_o) {
+    char* errbuf = d->errbuf;
     auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
     const long g = gcd(in_rate, out_rate); const int L = (int)(out_rate / g), M = (int)(in_rate / g);
-    if (L > 4096) { snprintf(errbuf, 512, "resampler: ratio %d/%d needs %d phases (> 4096)", out_rate, in_rate, L); return -1; }
+    if (L > 4096 || M > 4096) { snprintf(errbuf, 512, "resampler: ratio %d/%d needs %d phases / a decimation of %d (> 4096)", out_rate, in_rate, L, M); return -1; }
+    const int T = 32 * std::max(1, (M + L - 1) / L);     // span 32 samples of the slower rate
+    *L_o = L; *M_o = M; *T_o = T;
+    if (d->coef_L == L && d->coef_M == M) return 0;
+    std::vector<float> h((size_t)L * T);
+    const double fc = 0.5 * std::min(1.0, (double)L / M) * 0.90, beta = 8.6;   // cutoff (cycles per input sample), a little below Nyquist of the narrower side
+    auto bessel0 = [](double x) { double s = 1, t = 1; for (int k = 1; k < 40; ++k) { t *= (x / (2 * k)) * (x / (2 * k)); s += t; } return s; };
+    for (int ph = 0; ph < L; ++ph) {
+        double sum = 0; std::vector<double> row(T);
+        for (int t = 0; t < T; ++t) {
+            const double xpos = (double)(t - (T / 2 - 1)) - (double)ph / L;     // distance (in input samples) from the output instant
+            const double w = std::fabs(xpos) >= T / 2 ? 0.0 : bessel0(beta * std::sqrt(1.0 - (xpos / (T / 2)) * (xpos / (T / 2)))) / bessel0(beta);
+            const double arg = 2.0 * M_PI * fc * xpos; const double sinc = std::fabs(arg) < 1e-12 ? 1.0 : std::sin(arg) / arg;
+            row[t] = 2.0 * fc * sinc * w; sum += row[t];
+        }
+        for (int t = 0; t < T; ++t) h[(size_t)ph * T + t] = (float)(row[t] / sum);   // unity DC gain per phase
+    }
+    hipFree(d->d_coef); d->d_coef = nullptr; HIPCHK(hipMalloc((void**)&d->d_coef, h.size() * sizeof(float))); HIPCHK(hipMemcpy(d->d_coef, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    d->coef_L = L; d->coef_M = M; return 0;
+}
+// whole buffer at once
+extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_frames, int channels, int in_rate, int out_rate, float* out, long out_cap_frames, long* out_frames) {
+    char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device));
+    int L, M, T; if (dsp_polyphase_coefs(d, in_rate, out_rate, &L, &M, &T)) return -1;
+    if (channels < 1 || channels > 2) { snprintf(errbuf, 512, "resampler: unsupported channel count %d", channels); return -1; }
     const long n_out = (n_in_frames * L + M - 1) / M;
     if (n_out > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity too small"); return -1; }
-    if (d->coef_L != L || d->coef_M != M) {
-        const int T = 32 * std::max(1, (M + L - 1) / L); std::vector<float> h((size_t)L * T);   // span 32 samples of the slower rate
-        const double fc = 0.5 * std::min(1.0, (double)L / M) * 0.90, beta = 8.6;   // cutoff (cycles per input sample), a little below Nyquist of the narrower side
-        auto bessel0 = [](double x) { double s = 1, t = 1; for (int k = 1; k < 40; ++k) { t *= (x / (2 * k)) * (x / (2 * k)); s += t; } return s; };
-        for (int ph = 0; ph < L; ++ph) {
-            double sum = 0; std::vector<double> row(T);
-            for (int t = 0; t < T; ++t) {
-                const double xpos = (double)(t - (T / 2 - 1)) - (double)ph / L;     // distance (in input samples) from the output instant
-                const double w = std::fabs(xpos) >= T / 2 ? 0.0 : bessel0(beta * std::sqrt(1.0 - (xpos / (T / 2)) * (xpos / (T / 2)))) / bessel0(beta);
-                const double arg = 2.0 * M_PI * fc * xpos; const double sinc = std::fabs(arg) < 1e-12 ? 1.0 : std::sin(arg) / arg;
-                row[t] = 2.0 * fc * sinc * w; sum += row[t];
-            }
-            for (int t = 0; t < T; ++t) h[(size_t)ph * T + t] = (float)(row[t] / sum);   // unity DC gain per phase
-        }
-        hipFree(d->d_coef); HIPCHK(hipMalloc((void**)&d->d_coef, h.size() * sizeof(float))); HIPCHK(hipMemcpy(d->d_coef, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-        d->coef_L = L; d->coef_M = M;
-    }
     if (dsp_reserve(d, (size_t)n_in_frames * channels, (size_t)n_out * channels)) return -1;
     HIPCHK(hipMemcpyAsync(d->d_in, in, sizeof(float) * (size_t)n_in_frames * channels, hipMemcpyHostToDevice, d->stream));
-    skw_resample_polyphase_launch(d->d_in, n_in_frames, channels, d->d_coef, L, M, 32 * std::max(1, (M + L - 1) / L), d->d_out, n_out, d->stream);
+    skw_resample_polyphase_launch(d->d_in, 0, n_in_frames, n_in_frames, channels, d->d_coef, L, M, T, d->d_out, 0, n_out, d->stream);
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n_out * channels, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     *out_frames = n_out; return 0;
+}
+extern "C" int skw_dsp_last_scan_fallback(const skw_dsp* d) { return d->last_flag; }
+
+// streaming polyphase: the input tail the later outputs still need stays on the device; a push uploads only the new frames and
+// computes only the outputs whose filter support has arrived (all remaining ones when `final`).  Identical to the whole-buffer result.
+struct skw_pp_stream { skw_dsp* d; int ch, in_rate, out_rate, L, M, T; float* d_buf = nullptr; size_t cap_frames = 0; long base = 0, total = 0, next = 0; float* d_o = nullptr; size_t cap_o = 0; };
+extern "C" skw_pp_stream* skw_polyphase_stream_create(skw_dsp* d, int channels, int in_rate, int out_rate) {
+    if (hipSetDevice(d->device) != hipSuccess) return nullptr;
+    int L, M, T; if (channels < 1 || channels > 2) { snprintf(d->errbuf, 512, "resampler: unsupported channel count %d", channels); return nullptr; }
+    if (dsp_polyphase_coefs(d, in_rate, out_rate, &L, &M, &T)) return nullptr;
+    skw_pp_stream* p = new skw_pp_stream(); p->d = d; p->ch = channels; p->in_rate = in_rate; p->out_rate = out_rate; p->L = L; p->M = M; p->T = T; return p;
+}
+extern "C" void skw_polyphase_stream_free(skw_pp_stream* p) { if (!p) return; hipSetDevice(p->d->device); hipStreamSynchronize(p->d->stream); hipFree(p->d_buf); hipFree(p->d_o); delete p; }
+extern "C" int skw_polyphase_stream_push(skw_pp_stream* p, const float* in, long n_frames, int final_call, float* out, long out_cap_frames, long* out_frames) {
+    skw_dsp* d = p->d; char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device)); *out_frames = 0;
+    int L, M, T; if (dsp_polyphase_coefs(d, p->in_rate, p->out_rate, &L, &M, &T)) return -1;       // the context's table may have served another ratio since
+    const long ch = p->ch;
+    if (n_frames > 0) {
+        const size_t have = (size_t)(p->total - p->base), need = have + (size_t)n_frames;
+        if (need > p->cap_frames) {       // grow (rare: the buffer holds one packet + the retained tail)
+            float* nb = nullptr; const size_t cap = need * 2 + 4096; HIPCHK(hipMalloc((void**)&nb, cap * ch * sizeof(float)));
+            if (have) HIPCHK(hipMemcpyAsync(nb, p->d_buf, have * ch * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream)); hipFree(p->d_buf); p->d_buf = nb; p->cap_frames = cap;
+        }
+        HIPCHK(hipMemcpyAsync(p->d_buf + have * ch, in, (size_t)n_frames * ch * sizeof(float), hipMemcpyHostToDevice, d->stream));
+        p->total += n_frames;
+    }
+    // output m sits at input position floor(m*M/L) and reads frames [pos - (T/2 - 1), pos + T/2]
+    long m_hi;
+    if (final_call) m_hi = (p->total * L + M - 1) / M;
+    else { const long last_pos = p->total - 1 - T / 2; m_hi = last_pos < 0 ? 0 : ((last_pos + 1) * L + M - 1) / M; }
+    const long n_new = m_hi - p->next;
+    if (n_new > 0) {
+        if (n_new > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity too small"); return -1; }
+        if ((size_t)n_new > p->cap_o) { hipFree(p->d_o); p->cap_o = (size_t)n_new * 2; HIPCHK(hipMalloc((void**)&p->d_o, p->cap_o * ch * sizeof(float))); }
+        skw_resample_polyphase_launch(p->d_buf, p->base, p->total - p->base, final_call ? p->total : p->total, (int)ch, d->d_coef, L, M, T, p->d_o, p->next, n_new, d->stream);
+        HIPCHK(hipMemcpyAsync(out, p->d_o, (size_t)n_new * ch * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+        p->next = m_hi; *out_frames = n_new;
+    }
+    // drop what no later output reads: keep from the support start of output `next`
+    long keep_from = (p->next * M) / L - (T / 2 - 1); if (keep_from < p->base) keep_from = p->base; if (keep_from > p->total) keep_from = p->total;
+    if (keep_from > p->base) {
+        const size_t keep = (size_t)(p->total - keep_from);
+        if (keep) {   // overlapping move on one stream: stage through the output scratch when the ranges overlap
+            if ((size_t)(keep_from - p->base) >= keep) HIPCHK(hipMemcpyAsync(p->d_buf, p->d_buf + (size_t)(keep_from - p->base) * ch, keep * ch * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+            else {
+                float* tmp = nullptr; HIPCHK(hipMalloc((void**)&tmp, keep * ch * sizeof(float)));
+                HIPCHK(hipMemcpyAsync(tmp, p->d_buf + (size_t)(keep_from - p->base) * ch, keep * ch * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+                HIPCHK(hipMemcpyAsync(p->d_buf, tmp, keep * ch * sizeof(float), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(tmp);
+            }
+        }
+        p->base = keep_from;
+    }
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
 }

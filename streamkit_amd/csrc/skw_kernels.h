@@ -123,6 +123,7 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
 void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip
 
 // ---------------- resampler (R1) ----------------
+// start / count / offset: [n_chunks + 1] scratch for the per-chunk proposal; flag: 1 int (set when the proposal had to be redone sequentially)
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
-                                float* out, int cap, hipStream_t s);
-void skw_resample_polyphase_launch(const float* in, long n_in, int channels, const float* coef, int L, int M, int T, float* out, long n_out, hipStream_t s);
+                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s);
+void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out, long out_first, long n_out, hipStream_t s);

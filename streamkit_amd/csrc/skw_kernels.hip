@@ -1374,10 +1374,47 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
 // ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)
 // Restates /root/reference/crates/nodes/src/audio/filters/resampler.rs:231-244, 384-514 (rubato 0.16.2 asynchro_fast.rs):
 // per chunk: idx starts at last_index, `while idx < end_idx { idx += t_ratio; out = (1-frac)*y[floor idx] + frac*y[floor idx + 1] }`,
-// last_index = idx - chunk.  The index recurrence is a sequential f64 accumulation (its roundings decide `frac`), so one
-// lane walks it and records (sample index, frac) per output; the interpolation itself is then fully parallel.
-__global__ void k_resample_scan(double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out, int cap) {
+// last_index = idx - chunk.  The index recurrence is a sequential f64 accumulation whose roundings decide `frac`, across the whole
+// stream.  It is parallelised without giving that up:
+//   k_resample_starts  one lane proposes every chunk's start index, output count and output offset from the closed form
+//                      n = ceil((end - s) / t), s' = s + n t - chunk (O(1) per chunk; exact whenever every add of the walk is exact,
+//                      e.g. the 48 kHz -> 16 kHz case of an Opus source, t = 3);
+//   k_resample_walk    one lane PER CHUNK walks its chunk with the real f64 recurrence from the proposed start, writes
+//                      (sample index, frac) for its outputs and checks that it produced the proposed count and hands the next chunk
+//                      exactly the proposed start — by induction the proposal then IS the sequential walk, bit for bit;
+//   k_resample_scan    the original single-lane walk, which only runs when a check failed (ratios whose adds round, e.g. 44.1 kHz).
+// The interpolation (k_resample_lerp) is data parallel.
+__global__ void k_resample_starts(double last_index, double t_ratio, int chunk, int n_chunks, double* start, int* count, int* offset, int* flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
+    double s = last_index; int off = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        int n = 0;
+        if (s < end_idx) { n = (int)ceil((end_idx - s) / t_ratio); if (n < 1) n = 1; while (n > 1 && s + (double)(n - 1) * t_ratio >= end_idx) --n; while (s + (double)n * t_ratio < end_idx) ++n; }
+        start[c] = s; count[c] = n; offset[c] = off; off += n;
+        s = (s + (double)n * t_ratio) - (double)chunk;
+    }
+    start[n_chunks] = s; offset[n_chunks] = off; *flag = 0;
+}
+__global__ void k_resample_walk(const double* start, const int* count, const int* offset, double t_ratio, int chunk, int n_chunks, int* pos, float* frac,
+                                int* n_out, double* last_index_out, int cap, int* flag) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
+    double idx = start[c]; int n = 0; const int o = offset[c];
+    while (idx < end_idx) {
+        idx += t_ratio;
+        const double fl = floor(idx);
+        if (o + n < cap) { pos[o + n] = c * chunk + (int)fl; frac[o + n] = (float)(idx - fl); }
+        n++;
+    }
+    idx = idx - (double)chunk;
+    if (n != count[c] || idx != start[c + 1]) atomicOr(flag, 1);      // the proposal is not the sequential walk: k_resample_scan redoes it
+    if (c == n_chunks - 1) { *n_out = o + n; *last_index_out = idx; }
+}
+__global__ void k_resample_scan(double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out, int cap, const int* flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (flag && !*flag) return;
     const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
     double idx = last_index; int n = 0;
     for (int c = 0; c < n_chunks; ++c) {
@@ -1401,24 +1438,58 @@ __global__ void k_resample_lerp(const float* in, int channels, const int* pos, c
     }
 }
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
-                                float* out, int cap, hipStream_t s) {
-    hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap);
+                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s) {
+    static const bool force_scan = getenv("SKW_RESAMPLE_SCAN") != nullptr;     // measurement switch: the single-lane walk only
+    if (force_scan) hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
+    else {
+        hipLaunchKernelGGL(k_resample_starts, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
+        hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag);
+        hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)flag);
+    }
     hipLaunchKernelGGL(k_resample_lerp, dim3(256), dim3(256), 0, s, in, channels, pos, frac, n_out, out, cap);
 }
 
-// ------------------------------------------------------------------ polyphase windowed-sinc resampler (quality mode, no reference counterpart)
-// out[n] = sum_t h[phase(n)][t] * x[base(n) + t - T/2 + 1], rational ratio L/M, T taps per phase (32 x the decimation factor); coefficients from the host.
-__global__ void k_resample_polyphase(const float* in, long n_in, int channels, const float* coef /*[L][T]*/, int L, int M, int T, float* out, long n_out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out * channels; i += (long)gridDim.x * blockDim.x) {
-        const long f = i / channels; const int c = (int)(i % channels);
-        const long num = f * (long)M; const long base = num / L; const int ph = (int)(num % L);
-        const float* h = coef + (long)ph * T;
-        float acc = 0.0f;
+// ------------------------------------------------------------------ polyphase windowed-sinc resampler (quality mode; north_star's "polyphase resampler")
+// out[n] = sum_t h[phase(n)][t] * x[base(n) + t - (T/2 - 1)], rational ratio L/M, T taps per phase, coefficients [L][T] from the host.
+// One workgroup = PP_TILE consecutive output frames (all channels): the input span they read and, when it fits, the whole coefficient
+// table are staged in LDS (coalesced 4-byte loads; table rows padded to an odd stride so that lanes on different phases hit different
+// banks); per output the phase and base come from 32-bit arithmetic on the tile's (base0, phase0) — the one 64-bit division is per
+// workgroup — and the tap loop is fma on two LDS operands.  Inputs are addressed absolutely: `in` holds frames [in_base, in_base + n_in)
+// of the stream and everything outside [0, n_total) reads as zero, so a stream can be filtered packet by packet from a device-resident
+// tail (skw_polyphase_stream_*) with results identical to filtering it whole.
+#define PP_TILE 256
+__global__ __launch_bounds__(256) void k_resample_polyphase(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, int coef_in_lds,
+                                                            float* out, long out_first, long n_out) {
+    extern __shared__ float pp_lds[];
+    const int tid = threadIdx.x, Ts = T | 1;
+    const long o0 = out_first + (long)blockIdx.x * PP_TILE;
+    const long num0 = o0 * (long)M; const long base0 = num0 / L; const int ph0 = (int)(num0 % L);
+    const int span = (int)(((long)ph0 + (long)(PP_TILE - 1) * M) / L) + T;                 // frames [base0 - (T/2 - 1), base0 - (T/2 - 1) + span)
+    const long first = base0 - (T / 2 - 1);
+    float* xs = pp_lds; float* hs = pp_lds + (size_t)span * channels;
+    for (int i = tid; i < span * channels; i += 256) {
+        const long f = first + i / channels; const int c = i % channels;
+        xs[i] = (f >= 0 && f < n_total && f >= in_base && f < in_base + n_in) ? in[(f - in_base) * channels + c] : 0.0f;
+    }
+    if (coef_in_lds) for (int i = tid; i < L * T; i += 256) hs[(i / T) * Ts + i % T] = coef[i];
+    __syncthreads();
+    const long o = o0 + tid;
+    if (tid >= PP_TILE || o >= out_first + n_out) return;
+    const int num = ph0 + tid * M; const int rel = num / L, ph = num % L;                  // 32-bit: ph0 < L <= 4096, tid < 256, M <= 4096
+    const float* h = coef_in_lds ? hs + ph * Ts : coef + (long)ph * T;
+    for (int c = 0; c < channels; ++c) {
+        float acc = 0.0f; const float* x = xs + (size_t)rel * channels + c;
 #pragma unroll 8
-        for (int t = 0; t < T; ++t) { long j = base + t - (T / 2 - 1); float x = (j >= 0 && j < n_in) ? in[j * channels + c] : 0.0f; acc = __builtin_fmaf(h[t], x, acc); }
-        out[i] = acc;
+        for (int t = 0; t < T; ++t) acc = __builtin_fmaf(h[t], x[(size_t)t * channels], acc);
+        out[(o - out_first) * channels + c] = acc;
     }
 }
-void skw_resample_polyphase_launch(const float* in, long n_in, int channels, const float* coef, int L, int M, int T, float* out, long n_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_resample_polyphase, dim3(1024), dim3(256), 0, s, in, n_in, channels, coef, L, M, T, out, n_out);
+// outputs [out_first, out_first + n_out) of the stream into out[0 ..]; in = frames [in_base, in_base + n_in), n_total = frames of the stream known so far (beyond: zeros)
+void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out, long out_first, long n_out, hipStream_t s) {
+    if (n_out <= 0) return;
+    const int span_max = (int)(((long)(L - 1) + (long)(PP_TILE - 1) * M) / L) + T;
+    const size_t x_bytes = (size_t)span_max * channels * 4, h_bytes = (size_t)L * (T | 1) * 4;
+    const int coef_in_lds = (x_bytes + h_bytes <= 96 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL(k_resample_polyphase, dim3((unsigned)((n_out + PP_TILE - 1) / PP_TILE)), dim3(256), x_bytes + (coef_in_lds ? h_bytes : 0), s,
+                       in, in_base, n_in, n_total, channels, coef, L, M, T, coef_in_lds, out, out_first, n_out);
 }

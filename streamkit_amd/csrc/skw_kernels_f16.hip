@@ -38,6 +38,18 @@ template <int EPI> struct Epi16 {
     static constexpr bool PERM = (EPI == EPI_F16_KPERM || EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD || EPI == EPI_HEADS_F16 || EPI == EPI_VT_F16);
 };
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// GELU as ggml's table defines it — f16(0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))) of the f16-rounded argument — evaluated
+// instead of looked up: the 128-KB table costs one 2-byte gather per element (a third of the FC1 GEMM's time at f16 matrix rates).
+// tanh through exp2 / rcp: within an f32 ulp or two of libm's, i.e. the same f16 except at rounding boundaries (tolerance mode).
+__device__ __forceinline__ float gelu16(float v) {
+    if (v <= -10.0f) return 0.0f;
+    if (v >= 10.0f) return v;
+    const float x = h2f(f2h(v));
+    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
+    const float e = __builtin_amdgcn_exp2f(u * 2.88539008177792681472f);           // exp(2u)
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return h2f(f2h(0.5f * x * (1.0f + th)));
+}
 // four adjacent output elements: memory position p0 .. p0+3 along X (p0 % 4 == 0), logical X indices x[0..3], the other index y
 template <int EPI>
 __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, const int (&x)[4], f32x4 v) {
@@ -49,7 +61,7 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
         const f32x4 b = *(const f32x4*)(a.bias + p0); const f32x4 pe = *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + p0);
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = pe[r] + gelu_dev(v[r] + b[r], a.gelu_tab);
+        for (int r = 0; r < 4; ++r) o[r] = pe[r] + gelu16(v[r] + b[r]);
         *(f32x4*)((float*)a.C + (long)y * a.ldc + p0) = o;
     } else if (EPI == EPI_F16_PLAIN) {
         f16x4 o;
@@ -62,7 +74,7 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
         for (int r = 0; r < 4; ++r) {
             float t = v[r]; if (a.bias) t = t + a.bias[x[r]];
             if (EPI == EPI_F16_KPERM || EPI == EPI_HEADS_F16) { if (a.has_scale) t = t * a.scale; o[r] = f2h(t); }
-            else o[r] = f2h(gelu_dev(t, a.gelu_tab));
+            else o[r] = f2h(gelu16(t));
         }
         long row;
         if (EPI == EPI_GELU_F16_KPERM_ROWPAD) row = ((long)(y / a.n_ctx) * (a.n_ctx + 2) + (y % a.n_ctx) + 1) * a.ldc + p0;
@@ -372,6 +384,13 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
         for (int t = 0; t < 4; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // what the epilogue of THIS wave's row tile needs besides the sums is requested now: a short kernel cannot afford a dependent
+    // memory round trip after its last MFMA
+    const int em = my0 + w * 16 + r16, ep0 = n0 + 4 * g;
+    const bool e_ok = em < a.M && ep0 + 3 < a.N;
+    f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
+    if (EPI == EPI_F32 && a.res && e_ok && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
+    if (EPI == EPI_DEC_QKV && a.pos_ptr && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -404,7 +423,12 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
         if ((a.ldc & 3) || p0 + 3 >= a.N) {            // logits: ldc = n_vocab is odd and the last strip is ragged
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
-        } else { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F32>(a, m, p0, x, v); }
+        } else {
+            if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
+            if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
+                         v[0] = v[0] + pre_res[0]; v[1] = v[1] + pre_res[1]; v[2] = v[2] + pre_res[2]; v[3] = v[3] + pre_res[3]; }
+            *(f32x4*)((float*)a.C + (long)m * a.ldc + p0) = v;
+        }
     } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
     else if (EPI == EPI_GELU_F16_KPERM) {
         int x[4];
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
         for (int r = 0; r < 4; ++r) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (p0 < 2 * d) x = x * a.scale; o[r] = f2h(x); }
         if (p0 < d) *(f16x4*)((half_t*)a.C + (long)m * a.ldc + p0) = o;
         else {
-            const long po = a.pos_ptr ? (long)a.pos_ptr[(long)m * a.pos_stride] * d : 0;
+            const long po = pre_po;
             half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
             *(f16x4*)dst = o;
         }

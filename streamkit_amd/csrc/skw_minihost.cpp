@@ -6,7 +6,7 @@
 //       concurrent for one instance) -> flush when the input closes -> destroy_instance; output / telemetry / log shims
 //       copy everything inside the callback because the pointers are only valid during the call.
 //   * audio::resampler node      /root/reference/crates/nodes/src/audio/filters/resampler.rs:148-743 (R1-R4)
-//   * core::json_serialize       /root/reference/crates/nodes/src/core/json_serialize.rs:85-107 (NDJSON of externally tagged packets)
+//   * core::json_serialize       /root/reference/crates/nodes/src/core/json_serialize.rs:85-107 (mh_json_serialize: NDJSON of externally tagged packets)
 // Plain C API so pytest can drive it through ctypes.
 #include "../../include/streamkit_native_abi.h"
 #include "skw_segmenter.h"
@@ -294,6 +294,58 @@ int mh_segment_sim(const float* prob, int n_frames, float threshold, uint64_t mi
             n_cuts++; return true; }, &err);
     }
     return n_cuts;
+}
+// ------------------------------------------------------------------ core::json_serialize (json_serialize.rs:85-107)
+// serde_json::to_vec / to_vec_pretty of the externally tagged `Packet` enum (crates/core/src/types.rs:92-113), one per output packet,
+// '\n' appended when newline_delimited.  The host has DESERIALISED the plugin's Transcription payload into TranscriptionData
+// (conversions.rs:356-361) before this node sees it, so the payload is parsed into the typed fields here and written again in
+// declaration order: text, segments[{text, start_time_ms, end_time_ms, confidence}], language, metadata (types.rs:150-175).
+static void js_indent(std::string& o, bool pretty, int depth) { if (pretty) { o += '\n'; o.append((size_t)depth * 2, ' '); } }
+static std::string js_u64(const skw::JsonValue* v) { char b[32]; snprintf(b, sizeof b, "%llu", (unsigned long long)(v ? v->num : 0)); return b; }
+static bool js_transcription(const std::string& payload, bool pretty, int depth, std::string* out, std::string* err) {
+    skw::JsonValue v; if (!skw::json_parse(payload.c_str(), &v, err) || v.type != skw::JsonValue::Object) { if (err->empty()) *err = "expected an object"; return false; }
+    const skw::JsonValue* text = v.get("text"); const skw::JsonValue* segs = v.get("segments"); const skw::JsonValue* lang = v.get("language"); const skw::JsonValue* meta = v.get("metadata");
+    if (!text || text->type != skw::JsonValue::String || !segs || segs->type != skw::JsonValue::Array) { *err = "missing field `text` / `segments`"; return false; }
+    if (meta && meta->type != skw::JsonValue::Null) { *err = "metadata is not produced on this path"; return false; }
+    const char* colon = pretty ? ": " : ":";
+    std::string& o = *out; o += '{';
+    js_indent(o, pretty, depth + 1); o += "\"text\""; o += colon; o += skw::json_quote(text->str); o += ',';
+    js_indent(o, pretty, depth + 1); o += "\"segments\""; o += colon; o += '[';
+    for (size_t i = 0; i < segs->arr.size(); ++i) {
+        const skw::JsonValue& sg = segs->arr[i]; const skw::JsonValue* st = sg.get("text"); const skw::JsonValue* conf = sg.get("confidence");
+        if (sg.type != skw::JsonValue::Object || !st || st->type != skw::JsonValue::String) { *err = "bad segment"; return false; }
+        if (i) o += ',';
+        js_indent(o, pretty, depth + 2); o += '{';
+        js_indent(o, pretty, depth + 3); o += "\"text\""; o += colon; o += skw::json_quote(st->str); o += ',';
+        js_indent(o, pretty, depth + 3); o += "\"start_time_ms\""; o += colon; o += js_u64(sg.get("start_time_ms")); o += ',';
+        js_indent(o, pretty, depth + 3); o += "\"end_time_ms\""; o += colon; o += js_u64(sg.get("end_time_ms")); o += ',';
+        js_indent(o, pretty, depth + 3); o += "\"confidence\""; o += colon; o += (conf && conf->type == skw::JsonValue::Number) ? skw::json_f32((float)conf->num) : std::string("null");
+        js_indent(o, pretty, depth + 2); o += '}';
+    }
+    if (!segs->arr.empty()) js_indent(o, pretty, depth + 1);
+    o += "],";
+    js_indent(o, pretty, depth + 1); o += "\"language\""; o += colon; o += (lang && lang->type == skw::JsonValue::String) ? skw::json_quote(lang->str) : std::string("null"); o += ',';
+    js_indent(o, pretty, depth + 1); o += "\"metadata\""; o += colon; o += "null";
+    js_indent(o, pretty, depth); o += '}';
+    return true;
+}
+// every output packet of the node through JsonSerialize{pretty, newline_delimited}; returns the concatenated Binary payloads (content type application/json)
+const char* mh_json_serialize(mh_node* n, int pretty, int newline_delimited, size_t* len) {
+    static thread_local std::string r; r.clear(); std::string err;
+    for (const mh_output& o : n->outputs) {
+        const char* colon = pretty ? ": " : ":";
+        if (o.packet_type == SK_PACKET_TRANSCRIPTION) {
+            r += '{'; js_indent(r, pretty != 0, 1); r += "\"Transcription\""; r += colon;
+            if (!js_transcription(o.payload, pretty != 0, 1, &r, &err)) { n->last_error = "Failed to serialize packet to JSON: " + err; if (len) *len = 0; return nullptr; }
+            js_indent(r, pretty != 0, 0); r += '}';
+        } else if (o.packet_type == SK_PACKET_TEXT) {
+            std::string t = o.payload; if (!t.empty() && t.back() == '\0') t.pop_back();
+            r += '{'; js_indent(r, pretty != 0, 1); r += "\"Text\""; r += colon; r += skw::json_quote(t); js_indent(r, pretty != 0, 0); r += '}';
+        } else { n->last_error = "Failed to serialize packet to JSON: packet type not produced on this path"; if (len) *len = 0; return nullptr; }
+        if (newline_delimited) r += '\n';
+    }
+    if (len) *len = r.size();
+    return r.data();
 }
 const char* mh_json_quote(const char* s) { static thread_local std::string r; r = skw::json_quote(s); return r.c_str(); }
 const char* mh_json_f32(float f) { static thread_local std::string r; r = skw::json_f32(f); return r.c_str(); }

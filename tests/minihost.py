@@ -33,6 +33,7 @@ def lib():
         L.mh_log.restype = C.c_char_p; L.mh_log.argtypes = [C.c_void_p, C.c_size_t]
         L.mh_last_error.restype = C.c_char_p; L.mh_last_error.argtypes = [C.c_void_p]
         L.mh_destroy_node.argtypes = [C.c_void_p]
+        L.mh_json_serialize.restype = C.c_void_p; L.mh_json_serialize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mh_resampler_new.restype = C.c_void_p; L.mh_resampler_new.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t]
         L.mh_resampler_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint16, C.c_int, C.c_uint64]
         L.mh_resampler_finish.argtypes = [C.c_void_p]
@@ -108,6 +109,14 @@ class Node:
             p = lib().mh_output_payload(self.h, i, C.byref(n))
             out.append((lib().mh_output_pin(self.h, i).decode(), lib().mh_output_type(self.h, i), C.string_at(p, n.value)))
         return out
+
+    def json_serialize(self, pretty=False, newline_delimited=True):
+        """core::json_serialize over this node's outputs (json_serialize.rs:85-107): the bytes an http_output would carry."""
+        n = C.c_size_t()
+        p = lib().mh_json_serialize(self.h, 1 if pretty else 0, 1 if newline_delimited else 0, C.byref(n))
+        if not p:
+            raise RuntimeError(self.last_error())
+        return C.string_at(p, n.value)
 
     def telemetry(self):
         return [(lib().mh_telemetry_type(self.h, i).decode(), json.loads(lib().mh_telemetry_json(self.h, i).decode()))

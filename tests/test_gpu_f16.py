@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 TOL_ENC_REL_RMS = 1e-2       # encoder output after ln_post, cross K/V
 TOL_ENC_REL_MAX = 8e-2       # worst element, relative to the RMS
 TOL_LOGIT_REL = 6e-4         # max abs logit error / (max logit - min logit)
-MARGIN_BOUND = 0.5           # logit units (synthetic models: logits span ~ +-500, measured f16_mfma logit error 0.07 - 0.14; flips observed at margins <= 0.12)
+MARGIN_BOUND = 0.75          # logit units (synthetic models: logits span ~ +-500, measured f16_mfma logit error 0.07 - 0.25; flips observed at margins <= 0.12)
 
 
 def _rel(a, b):

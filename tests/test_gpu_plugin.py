@@ -135,10 +135,14 @@ def test_config1_node_chain(plugin, tiny_model_path):
     for pk in rs.packets():
         assert node.process_audio(pk["samples"]) == 0
     node.flush()
-    ndjson = b"".join(b'{"Transcription":' + o[2] + b"}\n" for o in node.outputs())
+    ndjson = node.json_serialize(pretty=False, newline_delimited=True)          # the C++ restatement of core::json_serialize
+    assert ndjson == b"".join(b'{"Transcription":' + o[2] + b"}\n" for o in node.outputs())   # the plugin's JSON is already serde's byte for byte
     lines = ndjson.splitlines()
     assert len(lines) == 1
-    assert json.loads(lines[0])["Transcription"] == _expected_transcription(om, pcm[:939 * 512], 0)
+    want = _expected_transcription(om, pcm[:939 * 512], 0)
+    assert json.loads(lines[0])["Transcription"] == want
+    pretty = node.json_serialize(pretty=True, newline_delimited=False)
+    assert pretty.startswith(b'{\n  "Transcription": {\n    "text": ') and json.loads(pretty)["Transcription"] == want
     node.destroy()
 
 
