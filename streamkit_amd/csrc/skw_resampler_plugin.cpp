@@ -29,11 +29,10 @@ struct Resampler {
     bool init = false, needs = false; uint32_t rate = 0; uint16_t channels = 0;
     skw_dsp* dsp = nullptr; skw_resampler_state st{};
     std::vector<float> sample_buffer, output_buffer, scratch;
-    // mode "polyphase" (additive): streaming form of skw_resample_polyphase.  pp_in holds input frames from absolute frame pp_base
-    // (a multiple of M, so local and absolute phases coincide); outputs [0, pp_next) have been produced.
-    bool polyphase = false; int L = 1, M = 1, T = 32; std::vector<float> pp_in; long pp_base = 0, pp_total = 0, pp_next = 0;
+    // mode "polyphase" (additive): streaming form of skw_resample_polyphase, state on the device
+    bool polyphase = false; int L = 1, M = 1, T = 32; skw_pp_stream* pp = nullptr;
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
-    ~Resampler() { if (dsp) skw_dsp_free(dsp); }
+    ~Resampler() { if (pp) skw_polyphase_stream_free(pp); if (dsp) skw_dsp_free(dsp); }
 };
 
 bool emit(Resampler* r, COutputCallback cb, void* ud, const float* d, size_t n, std::string* err) {
@@ -54,24 +53,15 @@ bool run_chunks(Resampler* r, skw_resampler_state* st, const float* in, int n_ch
     out->resize((size_t)n * r->channels); return true;
 }
 
-// streaming polyphase: produce every output whose filter support is already here (all of them at end of stream), keep what later outputs need
-bool polyphase_step(Resampler* r, bool final_call, std::vector<float>* out, std::string* err) {
+// streaming polyphase: every output whose filter support has arrived (all of them at end of stream); the input tail that later
+// outputs need stays in HBM (skw_polyphase_stream_*), a packet uploads only its own frames
+bool polyphase_step(Resampler* r, const float* in, long n_frames, bool final_call, std::vector<float>* out, std::string* err) {
     out->clear();
-    const long ch = r->channels, n_loc = (long)(r->pp_in.size() / ch);
-    // output m sits at input position floor(m*M/L) and reads frames [pos - (T/2 - 1), pos + T/2]
-    long m_hi = final_call ? (r->pp_total * r->L + r->M - 1) / r->M : 0;
-    if (!final_call) { const long last_pos = r->pp_total - 1 - r->T / 2; m_hi = last_pos < 0 ? 0 : ((last_pos + 1) * r->L + r->M - 1) / r->M; }   // every m with floor(m*M/L) <= last_pos
-    if (m_hi <= r->pp_next || n_loc == 0) return true;
-    const long base_out = r->pp_base / r->M * r->L;                       // first output index of the local buffer (pp_base is a multiple of M)
-    const long n_out_loc = (n_loc * r->L + r->M - 1) / r->M; std::vector<float> all((size_t)n_out_loc * ch); long got = 0;
-    if (skw_resample_polyphase(r->dsp, r->pp_in.data(), n_loc, (int)ch, (int)r->rate, (int)r->target, all.data(), n_out_loc, &got) != 0) { *err = std::string("Resampling failed: ") + skw_dsp_last_error(r->dsp); return false; }
-    const long lo = r->pp_next - base_out, hi = std::min(m_hi - base_out, got);
-    if (hi > lo) out->assign(all.begin() + lo * ch, all.begin() + hi * ch);
-    r->pp_next = base_out + std::max(lo, hi);
-    // drop input no future output reads: keep from the support start of output pp_next, rounded down to a multiple of M
-    long keep_from = (r->pp_next * r->M) / r->L - (r->T / 2 - 1); if (keep_from < 0) keep_from = 0; keep_from = keep_from / r->M * r->M;
-    if (keep_from > r->pp_base) { r->pp_in.erase(r->pp_in.begin(), r->pp_in.begin() + (keep_from - r->pp_base) * ch); r->pp_base = keep_from; }
-    return true;
+    if (!r->pp) return true;
+    const long cap = (n_frames + 2L * r->T + 8) * r->L / r->M + 64 + (final_call ? (long)r->T * r->L / r->M + 64 : 0);
+    out->resize((size_t)cap * r->channels); long got = 0;
+    if (skw_polyphase_stream_push(r->pp, in, n_frames, final_call ? 1 : 0, out->data(), cap, &got) != 0) { *err = std::string("Resampling failed: ") + skw_dsp_last_error(r->dsp); return false; }
+    out->resize((size_t)got * r->channels); return true;
 }
 
 const char* const kSchema =
@@ -125,6 +115,7 @@ CResult process_packet(CPluginHandle h, const char* pin, const CPacket* pk, COut
             if (!r->dsp) return err_result(std::string("Failed to create resampler: ") + eb);
             skw_resampler_init(&r->st, (double)r->target / (double)r->rate, (int)r->chunk_frames, r->channels);
             { long a = r->rate, b = r->target; while (b) { long t2 = a % b; a = b; b = t2; } r->L = (int)(r->target / a); r->M = (int)(r->rate / a); r->T = 32 * std::max(1, (r->M + r->L - 1) / r->L); }
+            if (r->polyphase) { r->pp = skw_polyphase_stream_create(r->dsp, r->channels, (int)r->rate, (int)r->target); if (!r->pp) return err_result(std::string("Failed to create resampler: ") + skw_dsp_last_error(r->dsp)); }
         }
     }
     if (fr->sample_rate != r->rate || fr->channels != r->channels) {
@@ -136,8 +127,7 @@ CResult process_packet(CPluginHandle h, const char* pin, const CPacket* pk, COut
         if (!drain(r, cb, ud, &err)) return err_result(err); return ok_result();
     }
     if (r->polyphase) {
-        r->pp_in.insert(r->pp_in.end(), fr->samples, fr->samples + fr->sample_count); r->pp_total += (long)(fr->sample_count / r->channels);
-        if (!polyphase_step(r, false, &r->scratch, &err)) return err_result(err);
+        if (!polyphase_step(r, fr->samples, (long)(fr->sample_count / r->channels), false, &r->scratch, &err)) return err_result(err);
         if (r->scratch.empty()) return ok_result();
         if (r->out_frame > 0) { r->output_buffer.insert(r->output_buffer.end(), r->scratch.begin(), r->scratch.end()); if (!drain(r, cb, ud, &err)) return err_result(err); }
         else if (!emit(r, cb, ud, r->scratch.data(), r->scratch.size(), &err)) return err_result(err);
@@ -163,7 +153,7 @@ CResult flush(CPluginHandle h, COutputCallback cb, void* ud, CTelemetryCallback,
     if (!h) return err_result("Invalid handle (null)");
     Resampler* r = (Resampler*)h; std::string err;
     if (r->needs && r->polyphase) {
-        if (!polyphase_step(r, true, &r->scratch, &err)) return err_result(err);
+        if (!polyphase_step(r, nullptr, 0, true, &r->scratch, &err)) return err_result(err);
         if (!r->scratch.empty()) {
             if (r->out_frame > 0) { r->output_buffer.insert(r->output_buffer.end(), r->scratch.begin(), r->scratch.end()); if (!drain(r, cb, ud, &err)) return err_result(err); }
             else if (!emit(r, cb, ud, r->scratch.data(), r->scratch.size(), &err)) return err_result(err);

@@ -89,6 +89,11 @@ def lib():
         L.skw_resampler_init.argtypes = [C.POINTER(ResamplerState), C.c_double, C.c_int, C.c_int]
         L.skw_resample_linear.argtypes = [C.c_void_p, C.POINTER(ResamplerState), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.skw_resample_polyphase.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        L.skw_dsp_last_scan_fallback.argtypes = [C.c_void_p]
+        L.skw_polyphase_stream_create.restype = C.c_void_p
+        L.skw_polyphase_stream_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.skw_polyphase_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        L.skw_polyphase_stream_free.argtypes = [C.c_void_p]
         L.skw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
         L.skw_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.skw_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
@@ -279,6 +284,13 @@ class Dsp:
             raise RuntimeError(lib().skw_dsp_last_error(self.h).decode())
         return out[:n.value * st.channels].copy()
 
+    def last_scan_fallback(self):
+        """1 when the last resample_linear needed the single-lane index walk (the parallel proposal failed its on-device check)."""
+        return lib().skw_dsp_last_scan_fallback(self.h)
+
+    def polyphase_stream(self, channels, in_rate, out_rate):
+        return PolyphaseStream(self, channels, in_rate, out_rate)
+
     def resample_polyphase(self, interleaved, channels, in_rate, out_rate):
         x = np.ascontiguousarray(interleaved, dtype=np.float32)
         n_in = x.size // channels
@@ -293,3 +305,27 @@ class Dsp:
         if self.h:
             lib().skw_dsp_free(self.h)
             self.h = None
+
+
+class PolyphaseStream:
+    """Streaming polyphase resampler with its input tail resident on the device (skw_polyphase_stream_*)."""
+
+    def __init__(self, dsp, channels, in_rate, out_rate):
+        self.dsp, self.ch, self.in_rate, self.out_rate = dsp, channels, in_rate, out_rate
+        self.h = lib().skw_polyphase_stream_create(dsp.h, channels, in_rate, out_rate)
+        if not self.h:
+            raise RuntimeError(lib().skw_dsp_last_error(dsp.h).decode())
+
+    def push(self, interleaved, final=False):
+        x = np.ascontiguousarray(interleaved if interleaved is not None else np.zeros(0, np.float32), dtype=np.float32)
+        n_in = x.size // self.ch
+        cap = (n_in + 4096) * self.out_rate // self.in_rate + 4096
+        out = np.empty(cap * self.ch, dtype=np.float32)
+        n = C.c_long()
+        if lib().skw_polyphase_stream_push(self.h, x.ctypes.data if n_in else None, n_in, 1 if final else 0, out.ctypes.data, cap, C.byref(n)) != 0:
+            raise RuntimeError(lib().skw_dsp_last_error(self.dsp.h).decode())
+        return out[:n.value * self.ch].copy()
+
+    def close(self):
+        if self.h:
+            lib().skw_polyphase_stream_free(self.h); self.h = None

@@ -109,3 +109,34 @@ def test_resampler_plugin_polyphase_streaming_equals_whole_buffer(dsp, in_rate, 
     node.destroy()
     with pytest.raises(RuntimeError):
         p.create_node({"target_sample_rate": 16000, "mode": "cubic"})
+
+
+@pytest.mark.parametrize("in_rate,exact_adds", [(48000, True), (32000, True), (96000, True), (44100, False), (22050, False)])
+def test_parallel_index_walk_is_proven_or_falls_back(dsp, in_rate, exact_adds):
+    """A whole 30 s file in one call: the per-chunk parallel walk is used only when its on-device check proves it equal to the
+    sequential f64 recurrence (every ratio whose index adds are exact, the Opus 48 kHz case among them); otherwise the
+    single-lane walk runs.  Either way the output is the rubato restatement, bit for bit."""
+    chunk = 960; n_chunks = int(in_rate * 30 // chunk)
+    x = _signal(chunk * n_chunks, 1, seed=7)
+    st = dsp.linear_stream(16000 / in_rate, chunk, 1)
+    got = dsp.resample_linear(st, x, n_chunks)
+    assert dsp.last_scan_fallback() == (0 if exact_adds else 1)
+    orc = oracle_lib.OracleResampler(16000 / in_rate, chunk, 1)
+    ref = np.concatenate([orc.process(x[c * chunk:(c + 1) * chunk][None])[0] for c in range(n_chunks)])
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("in_rate,ch", [(48000, 1), (44100, 2), (8000, 1), (96000, 1)])
+def test_polyphase_stream_keeps_its_tail_on_the_device(dsp, in_rate, ch):
+    """skw_polyphase_stream_push with ragged packets == the whole-buffer filter, sample for sample."""
+    n = in_rate * 2 + 777
+    x = _signal(n, ch, seed=in_rate + ch)
+    whole = dsp.resample_polyphase(x, ch, in_rate, 16000)
+    s = dsp.polyphase_stream(ch, in_rate, 16000)
+    rng = np.random.default_rng(1); pos = 0; parts = []
+    while pos < n:
+        k = int(rng.integers(1, 5000)); parts.append(s.push(x[pos * ch:(pos + k) * ch])); pos += k
+    parts.append(s.push(None, final=True))
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape and np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+    s.close()
