@@ -616,6 +616,7 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long
                                                     SkwMelTables t, float* mel_raw) {
     __shared__ float x[400];
     __shared__ float bufA[800], bufB[800];
+    __shared__ float cs_t[400], sn_t[400];           // twiddles: 25 x 400 + 4 x 200 reads per frame, served from LDS instead of L1/L2
     const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int ns_raw = n_samples[b], nl = n_len[b];
     if (i >= nl) return;
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long
     const int ns = ns_raw + 200;
     int n_calc = ns / 160 + 1; if (n_calc > nl) n_calc = nl;
     if (i >= n_calc) { if (tid < t.n_mel) outp[tid] = (float)log10(1e-10); return; }
+    for (int j = tid; j < 400; j += 128) { cs_t[j] = t.cos_t[j]; sn_t[j] = t.sin_t[j]; }
     const float* p = pcm + pcm_off[b];
     const int offset = i * 160;
     int lim = ns - offset; if (lim > 400) lim = 400;
@@ -641,11 +643,12 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long
     for (int u = tid; u < 400; u += 128) {
         int o = u / 25, k = u % 25;
         float re = 0.0f, im = 0.0f;
+        const int step = (k * 16) % 400; int idx = 0;          // (k * n * 16) % 400 without a division per term
         for (int n = 0; n < 25; ++n) {
-            int idx = (k * n * 16) % 400;
             float xin = x[o + 16 * n];
-            re += xin * t.cos_t[idx];
-            im -= xin * t.sin_t[idx];
+            re += xin * cs_t[idx];
+            im -= xin * sn_t[idx];
+            idx += step; if (idx >= 400) idx -= 400;
         }
         bufA[2 * (o * 25 + k)] = re; bufA[2 * (o * 25 + k) + 1] = im;
     }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long
         for (int u = tid; u < 200; u += 128) {
             int gi = u / half_n, k = u % half_n;
             int idx = k * step;
-            float re = t.cos_t[idx], im = -t.sin_t[idx];
+            float re = cs_t[idx], im = -sn_t[idx];
             const float* ev = src + 2 * (gi * half_n + k); const float* od = src + 2 * ((gi + groups) * half_n + k);
             float er = ev[0], ei = ev[1], orr = od[0], oi = od[1];
             float* o0 = dst + 2 * (gi * N + k); float* o1 = dst + 2 * (gi * N + k + half_n);

@@ -358,13 +358,13 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
 // kernel's K/4 dependent f32 MFMAs), the partial tiles meet in LDS and wave t finishes row tile t.  As in k_gemm16 the weights
 // are the MFMA's first operand, so a lane ends up with four adjacent outputs of one row: 16-byte residual loads and stores.
 // Operands come straight from global memory (16-byte buffer loads with hardware range checks; a ring of RD k-blocks in flight).
-template <int EPI>
+template <int EPI, int MT>
 __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
     constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
-    constexpr int RD = 6;
-    __shared__ f32x4 red[4][4][64];
+    constexpr int RD = (MT == 4) ? 6 : 12;               // k-blocks in flight per wave
+    __shared__ f32x4 red[4][MT][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 16, my0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * 16, my0 = blockIdx.y * (16 * MT);
     const int r16 = lane & 15, g = lane >> 4;
     const int nkw = (a.K >> 5) >> 2, kb_lo = w * nkw;                 // k-blocks (of 32) per wave; host guarantees K % 128 == 0
     int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
@@ -372,47 +372,48 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
-    unsigned ao[4];
+    unsigned ao[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
-    u32x4 fw[RD], fa[RD][4];
+    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
+    u32x4 fw[RD], fa[RD][MT];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
         const bool in = j < nkw;
         fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * 64 : oob, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
+        for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // what the epilogue of THIS wave's row tile needs besides the sums is requested now: a short kernel cannot afford a dependent
     // memory round trip after its last MFMA
-    const int em = my0 + w * 16 + r16, ep0 = n0 + 4 * g;
-    const bool e_ok = em < a.M && ep0 + 3 < a.N;
+    const int em = my0 + w * 16 + r16, ep0 = n0 + 4 * g;      // (waves w >= MT have no row tile to finish)
+    const bool e_ok = w < MT && em < a.M && ep0 + 3 < a.N;
     f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
     if (EPI == EPI_F32 && a.res && e_ok && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
-    if (EPI == EPI_DEC_QKV && a.pos_ptr && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
-    f32x4 acc[4];
+    if (EPI == EPI_DEC_QKV && a.pos_ptr && w < MT && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
+    f32x4 acc[MT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb0 = 0; kb0 < nkw; kb0 += RD) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const f16x8 xw = __builtin_bit_cast(f16x8, fw[j]);
-            f16x8 xa[4];
+            f16x8 xa[MT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xa[t] = __builtin_bit_cast(f16x8, fa[j][t]);
+            for (int t = 0; t < MT; ++t) xa[t] = __builtin_bit_cast(f16x8, fa[j][t]);
             const int nb = kb0 + j + RD; const bool in = nb < nkw;       // refill the slot just read (zeros past the wave's K range: fma(0, 0, acc) == acc)
             fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * 64 : oob, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
+            for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16X32(xw, xa[t], acc[t]);          // D[n = 4g + r][m = 16 t + r16]
+            for (int t = 0; t < MT; ++t) acc[t] = MFMA16X32(xw, xa[t], acc[t]);          // D[n = 4g + r][m = 16 t + r16]
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) red[w][t][lane] = acc[t];
+    for (int t = 0; t < MT; ++t) red[w][t][lane] = acc[t];
     __syncthreads();
+    if (w >= MT) return;
     const int t = w;                                   // wave t finishes row tile t
     f32x4 v = red[0][t][lane];
 #pragma unroll
@@ -447,8 +448,13 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
         }
     }
 }
+// Rows per workgroup: every workgroup re-reads its row block of A from L2 (the weights are the small operand here), and one CU
+// takes in only ~70 GB/s, so fewer rows per workgroup = more workgroups each loading less: 16-row blocks unless told otherwise.
 template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((k_gemm16_small<EPI>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
+    static const int mt = getenv("SKW_DEC_MT") ? atoi(getenv("SKW_DEC_MT")) : 1;
+    if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemm16_small<EPI, 2>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm16_small<EPI, 1>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
 }
 // f16-MFMA form of skw_gemm_smallm; returns false when the geometry is outside what it handles (K % 128 != 0): the caller then
 // launches the exact kernel, which handles everything.
