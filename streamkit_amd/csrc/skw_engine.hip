@@ -463,6 +463,21 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     skw_gemm_smallm(a, c->cur);
 }
 
+// decode GEMM fed by a LayerNorm of x: one fused kernel in the f16 precision, LayerNorm kernel + GEMM otherwise
+static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical);
+static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s) {
+    static const bool no_fuse = getenv("SKW_DEC_NO_LN_FUSE") != nullptr;      // measurement switch
+    if (c->precision == SKW_PRECISION_F16_MFMA && !no_fuse) {
+        a.ln_x = x; a.ln_w = ln.w; a.ln_b = ln.b;
+        double fl, by; fl = 2.0 * a.M * a.N * a.K; by = 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N;
+        ProfScope p(c, PC_GEMM_SMALL, fl, by);
+        if (skw_gemm16_small_ln(a, c->cur)) return;
+        a.ln_x = nullptr;
+    }
+    { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * a.M * a.K); skw_layernorm(x, a.M, a.K, ln.w, ln.b, y16, nullptr, s); }
+    GEMM_S(c, a, a.K);
+}
+
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
     SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
 }
@@ -555,17 +570,14 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         const DecLayer& L = m->dec[l];
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
-        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, dy16, nullptr, s); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_S(c, a, a.K); }
+          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, dy16, nullptr, s); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s); }
         { ProfScope p_(c, PC_DEC_ATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, dy16, nullptr, s); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s); }
         { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
     }
     if (want_logits) {

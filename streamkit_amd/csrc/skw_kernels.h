@@ -44,13 +44,15 @@ struct SkwGemmArgs {
     const float* pe; int n_ctx;     // EPI_CONV2: pe [n_ctx][N]; EPI_HEADS/VT: rows per batch item
     int H; int Tpad;                // EPI_HEADS / EPI_VT
     int epi;
+    const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
 };
 
 // big-M GEMM (LDS-tiled 128x128 block, 4 waves)
 void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
 // f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
-bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
+bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);
+bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);   // the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);

@@ -862,16 +862,16 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // 16-byte load = 8 keys of one channel), B = p broadcast to every column, so each output channel is the same key-ascending fma chain
 // as the scalar form; an 8-deep ring keeps V^T in flight (4 .. 16 deep measure the same within 2 %).  HBM-bound: 55.3 MB per sequence per step over all layers.
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
-template <int MAXT, int WPH>
-__global__ __launch_bounds__(192 * WPH, 1) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
+template <int MAXT, int WPH, int HPW>
+__global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
                                                            const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride) {
     if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
-    __shared__ float plds[3][MAXT * 64];
-    __shared__ __attribute__((aligned(16))) half_t klds[3 * WPH][64 * 72];
-    __shared__ float smax[3][WPH];
-    __shared__ double ssum[3][WPH];
+    __shared__ float plds[HPW][MAXT * 64];
+    __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
+    __shared__ float smax[HPW][WPH];
+    __shared__ double ssum[HPW][WPH];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
-    const int hraw = blockIdx.x * 3 + hs, b = blockIdx.y;
+    const int hraw = blockIdx.x * HPW + hs, b = blockIdx.y;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
     const half_t* K = kbase + (long)b * k_batch_stride + h * 64;
@@ -990,8 +990,13 @@ __global__ __launch_bounds__(192 * WPH, 1) void k_dec_cross_attn(const half_t* q
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
-    if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
+    // heads per workgroup: 3 (256 workgroups of 12 waves at 64 rows x 12 heads: every CU) unless that leaves CUs without a workgroup —
+    // a 32-row group would run on half the chip — in which case one head per workgroup
+    static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
+    const int hpw = hpw_env ? hpw_env : (((H + 2) / 3) * B >= 224 ? 3 : 1);
+    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
+    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
 }
 
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s) {

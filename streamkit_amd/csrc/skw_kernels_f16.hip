@@ -45,10 +45,9 @@ __device__ __forceinline__ float gelu16(float v) {
     if (v <= -10.0f) return 0.0f;
     if (v >= 10.0f) return v;
     const float x = h2f(f2h(v));
-    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    const float e = __builtin_amdgcn_exp2f(u * 2.88539008177792681472f);           // exp(2u)
-    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return h2f(f2h(0.5f * x * (1.0f + th)));
+    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  -2u log2(e) = x (c1 + c2 x^2)
+    const float z = x * __builtin_fmaf(x * x, -2.88539008177792681472f * 0.79788456080286535588f * 0.044715f, -2.88539008177792681472f * 0.79788456080286535588f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));          // the caller rounds to f16 (conv2 adds the positional embedding to the f16 value)
 }
 // four adjacent output elements: memory position p0 .. p0+3 along X (p0 % 4 == 0), logical X indices x[0..3], the other index y
 template <int EPI>
@@ -61,7 +60,7 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
         const f32x4 b = *(const f32x4*)(a.bias + p0); const f32x4 pe = *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + p0);
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = pe[r] + gelu16(v[r] + b[r]);
+        for (int r = 0; r < 4; ++r) o[r] = pe[r] + h2f(f2h(gelu16(v[r] + b[r])));
         *(f32x4*)((float*)a.C + (long)y * a.ldc + p0) = o;
     } else if (EPI == EPI_F16_PLAIN) {
         f16x4 o;
@@ -352,6 +351,39 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
     hipLaunchKernelGGL(k_attn_encoder16, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks);
 }
 
+// what a wave does with a finished 16 x 16 tile: lane (r16, g) holds rows-of-W 4g .. 4g+3 (four adjacent outputs) of row m
+template <int EPI>
+__device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m, int p0, f32x4 v, f32x4 pre_res, long pre_po) {
+    if (m >= a.M || p0 >= a.N) return;
+    if (EPI == EPI_F32) {
+        if ((a.ldc & 3) || p0 + 3 >= a.N) {            // logits: ldc = n_vocab is odd and the last strip is ragged
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
+        } else {
+            if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
+            if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
+                         v[0] = v[0] + pre_res[0]; v[1] = v[1] + pre_res[1]; v[2] = v[2] + pre_res[2]; v[3] = v[3] + pre_res[3]; }
+            *(f32x4*)((float*)a.C + (long)m * a.ldc + p0) = v;
+        }
+    } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
+    else if (EPI == EPI_GELU_F16_KPERM) {
+        int x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31);
+        epi_store4<EPI_GELU_F16_KPERM>(a, m, p0, x, v);
+    } else if (EPI == EPI_DEC_QKV) {                   // n in [0, d): q (+bias, *scale); [d, 2d): K cache (*scale); [2d, 3d): V cache (+bias)
+        const int d = a.n_ctx; f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (p0 < 2 * d) x = x * a.scale; o[r] = f2h(x); }
+        if (p0 < d) *(f16x4*)((half_t*)a.C + (long)m * a.ldc + p0) = o;
+        else {
+            const long po = pre_po;
+            half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
+            *(f16x4*)dst = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ decode GEMM (M <= 64 rows per block row), f16 MFMA
 // Weight-streaming form for the batched single-token step (K8-K10).  One workgroup = one 16-column strip of W x 64 rows of A;
 // its four waves split the K axis (each chains its quarter on the matrix cores: K/128 MFMAs per row tile instead of the exact
@@ -418,36 +450,102 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
     f32x4 v = red[0][t][lane];
 #pragma unroll
     for (int s = 1; s < 4; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
-    const int m = my0 + t * 16 + r16, p0 = n0 + 4 * g;
-    if (m >= a.M || p0 >= a.N) return;
-    if (EPI == EPI_F32) {
-        if ((a.ldc & 3) || p0 + 3 >= a.N) {            // logits: ldc = n_vocab is odd and the last strip is ragged
+    gemm16_small_finish<EPI>(a, my0 + t * 16 + r16, n0 + 4 * g, v, pre_res, pre_po);
+}
+// ------------------------------------------------------------------ decode GEMM with the LayerNorm that feeds it folded in
+// C = LN(x) . W^T for a 16-row block: the workgroup normalises its 16 rows itself (wave w takes rows 4w .. 4w+3 with exactly the
+// arithmetic of k_layernorm: f64 statistics, then scale, gain, bias, f16 rounding) into an LDS image in kperm order, and the four
+// waves then take their K quarter's fragments from LDS.  Every column strip repeats the normalisation of its rows (49 KB of x per
+// workgroup instead of 25 KB of ready-made f16), which costs ~0.7 us inside the kernel and removes a 5 us LayerNorm launch plus a
+// kernel boundary from the serial chain of a decode step — 36 times per step.
+__device__ __forceinline__ double wave_sum_f64_(double v) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
-        } else {
-            if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
-            if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
-                         v[0] = v[0] + pre_res[0]; v[1] = v[1] + pre_res[1]; v[2] = v[2] + pre_res[2]; v[3] = v[3] + pre_res[3]; }
-            *(f32x4*)((float*)a.C + (long)m * a.ldc + p0) = v;
-        }
-    } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
-    else if (EPI == EPI_GELU_F16_KPERM) {
-        int x[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
+    constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
+    constexpr int RD = 12;                                      // K = d <= 1536: a wave's whole K quarter of W is in flight at once
+    __shared__ __attribute__((aligned(16))) half_t ya[16 * 1536];
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16, my0 = blockIdx.y * 16;
+    const int r16 = lane & 15, g = lane >> 4, d = a.K;
+    const int nkw = (d >> 5) >> 2, kb_lo = w * nkw;
+    int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    const unsigned oob = 0x7fffff00u;
+    const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    u32x4 fw[RD];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = ((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31);
-        epi_store4<EPI_GELU_F16_KPERM>(a, m, p0, x, v);
-    } else if (EPI == EPI_DEC_QKV) {                   // n in [0, d): q (+bias, *scale); [d, 2d): K cache (*scale); [2d, 3d): V cache (+bias)
-        const int d = a.n_ctx; f16x4 o;
+    for (int j = 0; j < RD; ++j) fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo != oob) ? wo + j * 64 : oob, 0, 0);
+    const int em = my0 + r16, ep0 = n0 + 4 * g;                 // wave 0 finishes the tile
+    f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
+    if (EPI == EPI_F32 && a.res && w == 0 && em < a.M && ep0 + 3 < a.N && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
+    if (EPI == EPI_DEC_QKV && a.pos_ptr && w == 0 && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
+    // ---- LayerNorm of rows 4w .. 4w+3 -> ya (row stride d halves; 16-byte chunk c of row r sits at chunk c ^ (r & 7))
+    {
+        float wv[24], bv[24];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (p0 < 2 * d) x = x * a.scale; o[r] = f2h(x); }
-        if (p0 < d) *(f16x4*)((half_t*)a.C + (long)m * a.ldc + p0) = o;
-        else {
-            const long po = pre_po;
-            half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
-            *(f16x4*)dst = o;
+        for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; const bool in = i < d; wv[c] = in ? a.ln_w[i] : 0.0f; bv[c] = in ? a.ln_b[i] : 0.0f; }
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = 4 * w + rr, row = my0 + lr;
+            if (row >= a.M) continue;                            // wave-uniform; the rows past M are multiplied but never stored
+            const float* xr = a.ln_x + (long)row * d;
+            float v[24]; double sum = 0.0;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; v[c] = (i < d) ? xr[i] : 0.0f; }
+#pragma unroll
+            for (int c = 0; c < 24; ++c) sum += (double)v[c];
+            sum = wave_sum_f64_(sum);
+            const float mean = (float)(sum / (double)d);
+            double sum2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; if (i < d) { const float t = v[c] - mean; v[c] = t; sum2 += (double)(t * t); } }
+            sum2 = wave_sum_f64_(sum2);
+            const float variance = (float)(sum2 / (double)d);
+            const float scale = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < 24; ++c) {
+                const int i = lane + 64 * c;
+                if (i < d) { float t = v[c] * scale; t = t * wv[c]; t = t + bv[c]; const int p = skw_kperm(i); ya[lr * d + (((p >> 3) ^ (lr & 7)) << 3) + (p & 7)] = f2h(t); }
+            }
         }
     }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+        if (j < nkw) {                                           // uniform
+            const f16x8 xa = *(const f16x8*)(ya + r16 * d + ((((kb_lo + j) * 4 + g) ^ (r16 & 7)) << 3));
+            acc = MFMA16X32(__builtin_bit_cast(f16x8, fw[j]), xa, acc);
+        }
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 v = red[0][lane];
+#pragma unroll
+    for (int s2 = 1; s2 < 4; ++s2) { const f32x4 o = red[s2][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }
+    gemm16_small_finish<EPI>(a, em, ep0, v, pre_res, pre_po);
 }
+template <int EPI> static void launch_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((k_gemm16_small_ln<EPI>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
+}
+// A = LayerNorm(a.ln_x; a.ln_w, a.ln_b) over K = d; false when the geometry is outside what it handles (the caller then runs the
+// LayerNorm kernel and a plain GEMM)
+bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
+    if ((a.K & 127) || a.K > 1536 || !a.ln_x) return false;
+    switch (a.epi) {
+        case EPI_F16_PLAIN: launch_gemm16_small_ln<EPI_F16_PLAIN>(a, s); return true;
+        case EPI_GELU_F16_KPERM: launch_gemm16_small_ln<EPI_GELU_F16_KPERM>(a, s); return true;
+        case EPI_DEC_QKV: launch_gemm16_small_ln<EPI_DEC_QKV>(a, s); return true;
+        default: return false;
+    }
+}
+
 // Rows per workgroup: every workgroup re-reads its row block of A from L2 (the weights are the small operand here), and one CU
 // takes in only ~70 GB/s, so fewer rows per workgroup = more workgroups each loading less: 16-row blocks unless told otherwise.
 template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
