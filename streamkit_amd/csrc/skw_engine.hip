@@ -753,13 +753,20 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             c->cur = c->stream;
             return hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, c->gstream[g]);
         };
+        // The host learns whether a group still has live rows only by waiting for its stream, and a wait + relaunch per step leaves the
+        // GPU idle for the turnaround.  So steps are enqueued `ahead` at a time and the count is read once per block: a step that
+        // runs after the last row of its group has finished changes nothing (its attention and sampling kernels return at once for
+        // finished rows; what the GEMMs write for them is scratch), it only costs its launches.
         const int step_cap = SKW_PROMPT_CAP + lp.n_max + 2;
-        for (int i = 0; i < step_cap; ++i) {
-            for (int g = 0; g < G; ++g) if (g_live[g]) {
-                if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
-                else { run_decoder_step(c, g_r0[g], g_n[g], i, true, c->gstream[g]); HIPCHK(sample(g)); }
-            }
-            tot_steps++;
+        static const int ahead_env = getenv("SKW_DECODE_AHEAD") ? atoi(getenv("SKW_DECODE_AHEAD")) : 0;
+        const int ahead = profiling ? 1 : std::max(1, ahead_env ? ahead_env : 8);
+        for (int i = 0; i < step_cap; i += ahead) {
+            const int nstep = std::min(ahead, step_cap - i);
+            for (int k = 0; k < nstep; ++k)
+                for (int g = 0; g < G; ++g) if (g_live[g]) {
+                    if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
+                    else { run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); HIPCHK(sample(g)); }
+                }
             bool any = false;
             for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); if (c->h_n_active[g] <= 0) g_live[g] = false; else any = true; }
             if (!any) break;
@@ -771,6 +778,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         HIPCHK(hipStreamSynchronize(c->stream));
         { float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[2], c->ev[3]); hipEventElapsedTime(&b, c->ev[3], c->ev[4]); enc_ms += a; dec_ms += b; }
         tot_windows += Bw;
+        { int mx = 0; for (int j = 0; j < Bw; ++j) mx = std::max(mx, c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens); tot_steps += mx; }   // decoder steps until the last row finished
         // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];

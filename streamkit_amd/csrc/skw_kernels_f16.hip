@@ -12,6 +12,7 @@
 //
 // Reference call site of everything here: /root/reference/plugins/native/whisper/src/lib.rs:644-646 (`whisper_state.full`).
 #include "skw_dev_common.h"
+#include <algorithm>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16X32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
@@ -101,30 +102,35 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     // V^T: the M axis is walked in virtual rows b * Tpad + key so that 32-key kperm blocks never straddle two clips
     const int Mv = X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
     const int nbn = (a.N + BN - 1) / BN, nbm = (Mv + BM - 1) / BM, nblk = nbn * nbm;
-    int bid = blockIdx.x;
-    { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }   // XCD-aware, bijective
-    const int bm = bid / nbn, bn = bid % nbn;       // the n-tiles of one m-tile run back to back on one XCD: the A panel is read from HBM once
-    const int m0 = bm * BM, n0 = bn * BN;
     const int wr = wave / NWN, wc = wave % NWN, r16 = lane & 15, g = lane >> 4;
-
     // staging addresses: piece q covers tile rows 8q .. 8q+7; lane -> row 8q + (lane >> 3), chunk position lane & 7
     const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
     const half_t* gA[A_PIECES]; const half_t* gB[B_PIECES];
+    // persistent workgroups: tile ids blockIdx.x, + gridDim.x, ...  (gridDim.x is a multiple of 8, so all tiles of a workgroup fall
+    // into the contiguous run of tiles the XCD-aware remap gives its XCD; the n-tiles of one m-tile run back to back on one XCD, so
+    // the A panel is read from HBM once)
+    auto tile_origin = [&](int tile, int& m0, int& n0) {
+        int q = nblk >> 3, r = nblk & 7, x = tile & 7, y = tile >> 3;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        m0 = (bid / nbn) * BM; n0 = (bid % nbn) * BN;
+    };
+    auto tile_sources = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) {
-        int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
-        int gm = m0 + c;
-        if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
-        if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
-        const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
-        gA[i] = a.A + off + pchunk * 8;
-    }
+        for (int i = 0; i < A_PIECES; ++i) {
+            int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
+            int gm = m0 + c;
+            if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
+            if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
+            const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
+            gA[i] = a.A + off + pchunk * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < B_PIECES; ++i) {
-        int c = (wave * B_PIECES + i) * 8 + prow; if (!X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
-        int gn = n0 + c; if (gn > a.N - 1) gn = a.N - 1;
-        gB[i] = a.W + (long)gn * a.ldw + pchunk * 8;
-    }
+        for (int i = 0; i < B_PIECES; ++i) {
+            int c = (wave * B_PIECES + i) * 8 + prow; if (!X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
+            int gn = n0 + c; if (gn > a.N - 1) gn = a.N - 1;
+            gB[i] = a.W + (long)gn * a.ldw + pchunk * 8;
+        }
+    };
     auto stage = [&](int buf, int kb) {
         char* base = lds + buf * (BM + BN) * 128;
 #pragma unroll
@@ -134,61 +140,78 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
         for (int i = 0; i < B_PIECES; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 0);
     };
-    f32x4 acc[TX][TY];
-#pragma unroll
-    for (int i = 0; i < TX; ++i)
-#pragma unroll
-        for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // fragment read offsets inside a buffer: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * khalf + g; row & 7 == r16 & 7
     const int fo0 = ((g ^ (r16 & 7)) << 4), fo1 = fo0 ^ 64;
     const int aoff = (wr * WTM + r16) * 128, boff = BM * 128 + (wc * WTN + r16) * 128;
     const int xoff = X_IS_M ? aoff : boff, yoff = X_IS_M ? boff : aoff;
     const int nk = a.K >> 6;
+    const int x_lim = X_IS_M ? Mv : a.N, y_lim = X_IS_M ? a.N : a.M;
+    int tile = blockIdx.x;
+    if (tile >= nblk) return;
+    int m0, n0; tile_origin(tile, m0, n0); tile_sources(m0, n0);
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
-        const char* base = lds + (kb & 1) * (BM + BN) * 128;
-        if (kb + 1 < nk) stage((kb + 1) & 1, kb + 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int fo = kk ? fo1 : fo0;
-            f16x8 fx[TX], fy[TY];
-#pragma unroll
-            for (int t = 0; t < TX; ++t) fx[t] = *(const f16x8*)(base + xoff + t * 2048 + fo);
-#pragma unroll
-            for (int t = 0; t < TY; ++t) fy[t] = *(const f16x8*)(base + yoff + t * 2048 + fo);
-#pragma unroll
-            for (int i = 0; i < TX; ++i)
-#pragma unroll
-                for (int j = 0; j < TY; ++j) acc[i][j] = MFMA16X32(fx[i], fy[j], acc[i][j]);
-        }
+    for (;;) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-    const int x_base = (X_IS_M ? m0 + wr * WTM : n0 + wc * WTN) + 4 * g, y_base = (X_IS_M ? n0 + wc * WTN : m0 + wr * WTM) + r16;
-    const int x_lim = X_IS_M ? Mv : a.N, y_lim = X_IS_M ? a.N : a.M;
+        f32x4 acc[TX][TY];
 #pragma unroll
-    for (int i = 0; i < TX; ++i)
+        for (int i = 0; i < TX; ++i)
 #pragma unroll
-        for (int j = 0; j < TY; ++j) {
-            const int p0 = x_base + i * 16, y = y_base + j * 16;
-            if (p0 < x_lim && y < y_lim) {
-                int x[4];
+            for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nk; ++kb) {
+            const char* base = lds + (kb & 1) * (BM + BN) * 128;
+            if (kb + 1 < nk) stage((kb + 1) & 1, kb + 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;
-                epi_store4<EPI>(a, y, p0, x, acc[i][j]);
+            for (int kk = 0; kk < 2; ++kk) {
+                const int fo = kk ? fo1 : fo0;
+                f16x8 fx[TX], fy[TY];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) fx[t] = *(const f16x8*)(base + xoff + t * 2048 + fo);
+#pragma unroll
+                for (int t = 0; t < TY; ++t) fy[t] = *(const f16x8*)(base + yoff + t * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < TX; ++i)
+#pragma unroll
+                    for (int j = 0; j < TY; ++j) acc[i][j] = MFMA16X32(fx[i], fy[j], acc[i][j]);
             }
+            if (kb + 1 < nk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
         }
+        // every wave must have read the last K step before the next tile's first step lands in buffer 0 (nk == 1: same buffer; nk odd: the last step's)
+        __syncthreads();
+        const int x_base = (X_IS_M ? m0 + wr * WTM : n0 + wc * WTN) + 4 * g, y_base = (X_IS_M ? n0 + wc * WTN : m0 + wr * WTM) + r16;
+        tile += gridDim.x;
+        const bool more = tile < nblk;
+        if (more) { tile_origin(tile, m0, n0); tile_sources(m0, n0); stage(0, 0); }      // the next tile's first K step flies under this tile's epilogue
+#pragma unroll
+        for (int i = 0; i < TX; ++i)
+#pragma unroll
+            for (int j = 0; j < TY; ++j) {
+                const int p0 = x_base + i * 16, y = y_base + j * 16;
+                if (p0 < x_lim && y < y_lim) {
+                    int x[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;
+                    epi_store4<EPI>(a, y, p0, x, acc[i][j]);
+                }
+            }
+        if (!more) break;
+    }
 }
 
+static int skw_cu_count() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
+    return n;
+}
 template <int EPI> static void launch_gemm16(const SkwGemmArgs& a, hipStream_t s) {
-    // tile choice: 256 x 256 (8 waves) when both extents fill it, 128 x 128 (4 waves, two blocks per CU) otherwise
+    // tile choice: 256 x 256 (8 waves, one workgroup per CU) when both extents fill it, 128 x 128 (4 waves, two per CU) otherwise;
+    // persistent workgroups: one grid slot per resident workgroup (rounded to the 8 XCDs), each walks tile ids slot, slot + grid, ...
     static const int force = getenv("SKW_GEMM16_TILE") ? atoi(getenv("SKW_GEMM16_TILE")) : 0;
     const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
     const bool big = force ? force == 256 : (Mv >= 256 && a.N >= 256 && Mv % 256 == 0 && a.N % 256 == 0);
-    if (big) hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(((Mv + 255) / 256) * ((a.N + 255) / 256)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(((Mv + 127) / 128) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
+    const int cus = skw_cu_count() & ~7;
+    if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
+    else { const int nblk = ((Mv + 127) / 128) * ((a.N + 127) / 128); hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(std::min(nblk, 2 * cus)), dim3(256), 0, s, a); }
 }
 // f16-MFMA form of skw_gemm.  Requirements (every Whisper geometry meets them): K % 64 == 0, N % 32 == 0, ldc / ldres % 4 == 0.
 // EPI_VT_F16 is called in the NATURAL orientation here (A = tokens [M][K], W = weights [N][K], bias per n), unlike the exact
