@@ -507,33 +507,53 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
     f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
     if (EPI == EPI_F32 && a.res && w == 0 && em < a.M && ep0 + 3 < a.N && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
     if (EPI == EPI_DEC_QKV && a.pos_ptr && w == 0 && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
-    // ---- LayerNorm of rows 4w .. 4w+3 -> ya (row stride d halves; 16-byte chunk c of row r sits at chunk c ^ (r & 7))
+    // ---- LayerNorm of the block's 16 rows -> ya (row stride d halves; 16-byte chunk c of row r sits at chunk c ^ (r & 7)).
+    // Sixteen threads per row, all rows at once.  A thread owns whole kperm groups — the eight k with k % 4 == q of a 32-block, which
+    // are adjacent in the image — so it loads x with stride 4 (its three neighbours fill in the 128-byte line) and stores each group
+    // with one 16-byte LDS write.  Statistics as ggml_norm: f64 sums, mean and variance rounded to f32, then scale, gain, bias, f16.
     {
-        float wv[24], bv[24];
+        const int lr = threadIdx.x >> 4, t16 = threadIdx.x & 15, row = my0 + lr;
+        const int ngrp = d >> 3;                                  // kperm groups per row; thread t16 takes groups t16, t16 + 16, ...
+        const float* xr = a.ln_x + (long)min(row, a.M - 1) * d;
+        constexpr int GMAX = 12;                                  // d <= 1536: 192 groups / 16 threads
+        float v[GMAX][8];
+        double sum = 0.0;
 #pragma unroll
-        for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; const bool in = i < d; wv[c] = in ? a.ln_w[i] : 0.0f; bv[c] = in ? a.ln_b[i] : 0.0f; }
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            const int lr = 4 * w + rr, row = my0 + lr;
-            if (row >= a.M) continue;                            // wave-uniform; the rows past M are multiplied but never stored
-            const float* xr = a.ln_x + (long)row * d;
-            float v[24]; double sum = 0.0;
+        for (int j = 0; j < GMAX; ++j) {
+            const int gi = t16 + 16 * j;
+            if (gi < ngrp) {
+                const float* xp = xr + (gi >> 2) * 32 + (gi & 3);
 #pragma unroll
-            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; v[c] = (i < d) ? xr[i] : 0.0f; }
+                for (int e = 0; e < 8; ++e) v[j][e] = xp[4 * e];
+            }
+        }
 #pragma unroll
-            for (int c = 0; c < 24; ++c) sum += (double)v[c];
-            sum = wave_sum_f64_(sum);
-            const float mean = (float)(sum / (double)d);
-            double sum2 = 0.0;
+        for (int j = 0; j < GMAX; ++j) if (t16 + 16 * j < ngrp) {
 #pragma unroll
-            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; if (i < d) { const float t = v[c] - mean; v[c] = t; sum2 += (double)(t * t); } }
-            sum2 = wave_sum_f64_(sum2);
-            const float variance = (float)(sum2 / (double)d);
-            const float scale = 1.0f / sqrtf(variance + 1e-5f);
+            for (int e = 0; e < 8; ++e) sum += (double)v[j][e];
+        }
 #pragma unroll
-            for (int c = 0; c < 24; ++c) {
-                const int i = lane + 64 * c;
-                if (i < d) { float t = v[c] * scale; t = t * wv[c]; t = t + bv[c]; const int p = skw_kperm(i); ya[lr * d + (((p >> 3) ^ (lr & 7)) << 3) + (p & 7)] = f2h(t); }
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = (float)(sum / (double)d);
+        double sum2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < GMAX; ++j) if (t16 + 16 * j < ngrp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[j][e] - mean; v[j][e] = t; sum2 += (double)(t * t); }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o, 64);
+        const float variance = (float)(sum2 / (double)d);
+        const float scale = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < GMAX; ++j) {
+            const int gi = t16 + 16 * j;
+            if (gi < ngrp) {
+                const int k0 = (gi >> 2) * 32 + (gi & 3);
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float t = v[j][e] * scale; t = t * a.ln_w[k0 + 4 * e]; t = t + a.ln_b[k0 + 4 * e]; o[e] = f2h(t); }
+                *(f16x8*)(ya + lr * d + ((gi ^ (lr & 7)) << 3)) = o;
             }
         }
     }

@@ -27,6 +27,14 @@ def test_engine_exports_every_declared_symbol(built):
         assert hasattr(L, n), "libskw_engine.so lacks %s" % n
 
 
+def test_vad_library_exports_every_declared_symbol(built):
+    L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libskw_vad.so"))
+    names = _declared_functions("skw_vad.h")
+    assert names == ["skw_vad_create", "skw_vad_free", "skw_vad_process_chunk", "skw_vad_reset", "skw_vad_state"]
+    for n in names:
+        assert hasattr(L, n), "libskw_vad.so lacks %s" % n
+
+
 def test_plugin_exports_the_one_symbol(built):
     assert hasattr(C.CDLL(os.path.join(ROOT, "streamkit_amd", "libresampler.so")), "streamkit_native_plugin_api")
     L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libwhisper.so"))
@@ -59,6 +67,7 @@ def test_plugin_metadata_matches_reference_node(built):
                     "suppress_blank": True, "suppress_non_speech_tokens": True, "emit_vad_events": False}
     for k, v in ref_defaults.items():
         assert props[k]["default"] == v, k
+    assert props["precision"]["default"] == "exact" and props["vad_mode"]["default"] == "auto"      # additive params keep reference behaviour by default
     assert props["gpu_device"]["maximum"] == 7 and props["min_silence_duration_ms"]["minimum"] == 100
 
 
@@ -95,3 +104,7 @@ def test_plugin_rejects_bad_config_before_touching_the_gpu(built):
     p = minihost.Plugin()
     with pytest.raises(RuntimeError, match="Invalid config"):
         p.create_node({"vad_threshold": "high"})
+    with pytest.raises(RuntimeError, match="Invalid config: precision"):
+        p.create_node({"precision": "fp8"})
+    with pytest.raises(RuntimeError, match="Invalid config: gpu_device"):
+        p.create_node({"gpu_device": "first"})

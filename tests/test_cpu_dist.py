@@ -46,3 +46,16 @@ def test_shard_and_gather_world2():
         for c in range(16):
             ref = _fake_result(c)
             assert allr[c]["ids"] == [t[0] for t in ref["tokens"]] and allr[c]["n_segments"] == len(ref["segments"])
+
+
+def test_bench_launcher_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N devices it must fail loudly (exit code != 0, nothing printed as
+    a result line) instead of timing one GPU and calling it N.  On the GPU-less build box every N > 1 is such a case."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but only" in r.stderr and "{" not in r.stdout
