@@ -922,6 +922,28 @@ extern "C" int skw_debug_math(skw_ctx* c, int kind, const float* in, float* out,
     HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost)); hipFree(di); hipFree(dout); return 0;
 }
 
+// measurement hook (tools/gemm16_probe.py): one f16-MFMA GEMM of the given shape on scratch buffers, timed with HIP events on the engine stream.
+// probe: bit 0 no K-loop DMA, bit 1 no MFMAs, bit 2 no epilogue stores; epi: EPI_* of skw_kernels.h (n_ctx / H / Tpad taken from the model)
+extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int probe, int iters, float* ms_per_launch) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    half_t *A = nullptr, *W = nullptr; void* C = nullptr; float *bias = nullptr, *res = nullptr;
+    const size_t cbytes = (size_t)M * N * 4 + (size_t)64 * c->Tpad * N;
+    HIPCHK(hipMalloc((void**)&A, (size_t)M * K * 2)); HIPCHK(hipMalloc((void**)&W, (size_t)N * K * 2)); HIPCHK(hipMalloc(&C, cbytes)); HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)); HIPCHK(hipMalloc((void**)&res, (size_t)M * N * 4));
+    { std::vector<uint16_t> h((size_t)std::max(M, N) * K); uint32_t x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16(((x >> 8) & 0xffff) / 65536.0f - 0.5f); }
+      HIPCHK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice)); }
+    HIPCHK(hipMemset(bias, 0, (size_t)std::max(M, N) * 4)); HIPCHK(hipMemset(res, 0, (size_t)M * N * 4));
+    SkwGemmArgs a{}; a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = N; a.bias = bias; a.epi = epi; a.scale = 1.0f; a.probe = probe;
+    a.gelu_tab = c->m->gelu_tab; a.pe = res; a.n_ctx = c->m->hp.n_audio_ctx; a.H = N / 64; a.Tpad = c->Tpad; if (epi == EPI_F32) { a.res = res; a.ldres = N; }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) skw_gemm16(a, c->stream);
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) skw_gemm16(a, c->stream);
+    HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_per_launch = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(C); hipFree(bias); hipFree(res);
+    return 0;
+}
+
 // ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
 struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
                  size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0;

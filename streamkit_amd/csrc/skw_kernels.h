@@ -44,6 +44,7 @@ struct SkwGemmArgs {
     const float* pe; int n_ctx;     // EPI_CONV2: pe [n_ctx][N]; EPI_HEADS/VT: rows per batch item
     int H; int Tpad;                // EPI_HEADS / EPI_VT
     int epi;
+    int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
 };
 

@@ -160,9 +160,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kb = 0; kb < nk; ++kb) {
             const char* base = lds + (kb & 1) * (BM + BN) * 128;
-            if (kb + 1 < nk) stage((kb + 1) & 1, kb + 1);
+            if (kb + 1 < nk && !(a.probe & 1)) stage((kb + 1) & 1, kb + 1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                if (a.probe & 2) break;
                 const int fo = kk ? fo1 : fo0;
                 f16x8 fx[TX], fy[TY];
 #pragma unroll
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
 #pragma unroll
             for (int j = 0; j < TY; ++j) {
                 const int p0 = x_base + i * 16, y = y_base + j * 16;
-                if (p0 < x_lim && y < y_lim) {
+                if (p0 < x_lim && y < y_lim && !((a.probe & 4) && acc[i][j][0] != 12345.678f)) {
                     int x[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;
