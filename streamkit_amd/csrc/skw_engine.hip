@@ -466,8 +466,10 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
 // decode GEMM fed by a LayerNorm of x: one fused kernel in the f16 precision, LayerNorm kernel + GEMM otherwise
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical);
 static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s) {
-    static const bool no_fuse = getenv("SKW_DEC_NO_LN_FUSE") != nullptr;      // measurement switch
-    if (c->precision == SKW_PRECISION_F16_MFMA && !no_fuse) {
+    // measured (profiles/r02): the fused kernel costs 20 us at N = 2304 / 3072 and 10 us at N = 768 where LayerNorm (5 us) + plain GEMM
+    // (5 - 6 us) cost 11: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
+    static const bool fuse = getenv("SKW_DEC_LN_FUSE") != nullptr;
+    if (c->precision == SKW_PRECISION_F16_MFMA && fuse) {
         a.ln_x = x; a.ln_w = ln.w; a.ln_b = ln.b;
         double fl, by; fl = 2.0 * a.M * a.N * a.K; by = 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N;
         ProfScope p(c, PC_GEMM_SMALL, fl, by);

@@ -90,6 +90,32 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
     }
 }
 
+// ---- staged epilogue.  Per-lane stores of a 16 x 16 MFMA tile reach memory as 16 rows x 32- or 64-byte pieces (measured: 1.2 TB/s
+// of f16 output, 2.7 TB/s of f32 read + write — half of every K = 768 GEMM's time).  Instead the finished tile is parked in the LDS
+// buffer the K loop no longer needs, as [y][x] rows in output precision (16-byte chunk ck of row y at chunk ck ^ (y & mask): the 16
+// rows a wave-instruction writes land on different banks), and all threads then move whole rows: 16 bytes per lane, 512-byte or
+// 1-KiB contiguous runs per row, residual / positional-embedding operands read the same way.
+template <int EPI> struct Epi16Out { static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_CONV2); };
+// the value an output element takes before the row-wise operands (residual, positional embedding) are added; f16-valued for f16 outputs
+template <int EPI>
+__device__ __forceinline__ float epi_value(const SkwGemmArgs& a, int y, int xlog, float v) {
+    if (EPI == EPI_F32) { if (a.bias) v = v + a.bias[xlog]; return v; }
+    if (EPI == EPI_CONV2) { v = v + a.bias[xlog]; return h2f(f2h(gelu16(v))); }
+    if (EPI == EPI_VT_F16) { if (a.bias) v = v + a.bias[y]; return (xlog % a.Tpad < a.n_ctx) ? h2f(f2h(v)) : 0.0f; }      // pad keys stay zero
+    if (a.bias) v = v + a.bias[xlog];
+    if (EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD) return h2f(f2h(gelu16(v)));
+    if (a.has_scale) v = v * a.scale;
+    return h2f(f2h(v));
+}
+// where the 16-byte chunk starting at memory position px of row y lives (element offset into C), or -1 when it is not stored
+template <int EPI>
+__device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, int px) {
+    if (EPI == EPI_GELU_F16_KPERM_ROWPAD) return ((long)(y / a.n_ctx) * (a.n_ctx + 2) + (y % a.n_ctx) + 1) * a.ldc + px;
+    if (EPI == EPI_HEADS_F16) { const int b = y / a.n_ctx, i = y % a.n_ctx; return ((long)(b * a.H + (px >> 6)) * a.Tpad + i) * 64 + (px & 63); }
+    if (EPI == EPI_VT_F16) { const int b = px / a.Tpad, kp = px % a.Tpad; return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
+    return (long)y * a.ldc + px;
+}
+
 template <int EPI, int BM, int BN, int NWM, int NWN>
 __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwGemmArgs a) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 16, TN = WTN / 16;
@@ -179,22 +205,55 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
         }
         // every wave must have read the last K step before the next tile's first step lands in buffer 0 (nk == 1: same buffer; nk odd: the last step's)
         __syncthreads();
-        const int x_base = (X_IS_M ? m0 + wr * WTM : n0 + wc * WTN) + 4 * g, y_base = (X_IS_M ? n0 + wc * WTN : m0 + wr * WTM) + r16;
+        const int X0 = X_IS_M ? m0 : n0, Y0 = X_IS_M ? n0 : m0;                 // tile origin along memory (X) and across it (Y)
         tile += gridDim.x;
         const bool more = tile < nblk;
-        if (more) { tile_origin(tile, m0, n0); tile_sources(m0, n0); stage(0, 0); }      // the next tile's first K step flies under this tile's epilogue
+        if (more) { tile_origin(tile, m0, n0); tile_sources(m0, n0); if (!(a.probe & 1)) stage(0, 0); }      // the next tile's first K step flies under this tile's epilogue (buffer 0)
+        if (!(a.probe & 4)) {
+            constexpr bool F32OUT = Epi16Out<EPI>::F32OUT;
+            constexpr int BX = X_IS_M ? BM : BN, BY = X_IS_M ? BN : BM, WTX = X_IS_M ? WTM : WTN, WTY = X_IS_M ? WTN : WTM;
+            constexpr int ESZ = F32OUT ? 4 : 2, ROWB = BX * ESZ, CPR = ROWB / 16;           // bytes per staged row, 16-byte chunks per row
+            constexpr int RP = ((BM + BN) * 128) / ROWB < BY ? ((BM + BN) * 128) / ROWB : BY;   // rows per pass: what one LDS buffer holds
+            constexpr int NPASS = BY / RP, CE = 16 / ESZ;                                    // elements per chunk
+            static_assert(BY % RP == 0 && (CPR & (CPR - 1)) == 0, "whole passes, power-of-two chunks per row");
+            char* stg = lds + (BM + BN) * 128;                                               // buffer 1
+            const int wX = X_IS_M ? wr : wc, wY = X_IS_M ? wc : wr;
+            for (int pass = 0; pass < NPASS; ++pass) {
+                // phase A: this pass's rows, from the waves that hold them
 #pragma unroll
-        for (int i = 0; i < TX; ++i)
+                for (int j = 0; j < TY; ++j) {
+                    const int yl = wY * WTY + j * 16 + r16;
+                    if ((wY * WTY + j * 16) / RP != pass) continue;                          // wave-uniform
+                    const int y = Y0 + yl, ylp = yl - pass * RP;
 #pragma unroll
-            for (int j = 0; j < TY; ++j) {
-                const int p0 = x_base + i * 16, y = y_base + j * 16;
-                if (p0 < x_lim && y < y_lim && !((a.probe & 4) && acc[i][j][0] != 12345.678f)) {
-                    int x[4];
+                    for (int i = 0; i < TX; ++i) {
+                        const int xl = wX * WTX + i * 16 + 4 * g, p0 = X0 + xl;
+                        float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;
-                    epi_store4<EPI>(a, y, p0, x, acc[i][j]);
+                        for (int r = 0; r < 4; ++r) { const int xlog = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r; o[r] = epi_value<EPI>(a, y, xlog, acc[i][j][r]); }
+                        const int ck = xl / CE;
+                        char* dst = stg + ylp * ROWB + ((ck ^ (ylp & (CPR - 1))) << 4);
+                        if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
+                        else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                    }
                 }
+                __syncthreads();
+                // phase B: whole rows out, 16 bytes per lane
+                for (int cid = tid; cid < RP * CPR; cid += NW * 64) {
+                    const int ylp = cid / CPR, pc = cid % CPR, ck = pc ^ (ylp & (CPR - 1));
+                    const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
+                    if (y >= y_lim || px >= x_lim) continue;
+                    const long off = epi_chunk_offset<EPI>(a, y, px);
+                    if (F32OUT) {
+                        f32x4 v = *(const f32x4*)(stg + ylp * ROWB + (pc << 4));
+                        if (EPI == EPI_F32 && a.res) { const f32x4 rr = *(const f32x4*)(a.res + (long)y * a.ldres + px); v[0] = v[0] + rr[0]; v[1] = v[1] + rr[1]; v[2] = v[2] + rr[2]; v[3] = v[3] + rr[3]; }
+                        if (EPI == EPI_CONV2) { const f32x4 pe = *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + px); v[0] = pe[0] + v[0]; v[1] = pe[1] + v[1]; v[2] = pe[2] + v[2]; v[3] = pe[3] + v[3]; }
+                        *(f32x4*)((float*)a.C + off) = v;
+                    } else *(u32x4*)((half_t*)a.C + off) = *(const u32x4*)(stg + ylp * ROWB + (pc << 4));
+                }
+                __syncthreads();
             }
+        }
         if (!more) break;
     }
 }
