@@ -233,3 +233,19 @@ def test_language_auto_detect_is_consistent_in_oracle(micro_model_path):
     p.lang_id = auto["lang_id"]
     fixed = om.full(pcm, p)
     assert fixed["lang_id"] == auto["lang_id"] and fixed["tokens"] == auto["tokens"] and fixed["segments"] == auto["segments"]
+
+
+def test_prompt_past_survives_a_no_speech_window(oracle_tiny):
+    """whisper_full_with_state re-inserts the prompt portion it took for a window unconditionally and appends the window's own tokens
+    only when it is speech: a 75 s clip whose middle window is classed no-speech (thresholds chosen so) yields segments
+    from windows 0 and 2 only, and window 2 is still decoded with window 0's text as its prompt (one extra [prev] + carried tokens
+    show up as decoder steps)."""
+    pcm = synth.clip(11, 16000 * 75)
+    p = oracle_tiny.default_params(); p.no_speech_thold = -1.0; p.logprob_thold = -0.3; p.temperature_inc = 0.0
+    r = oracle_tiny.full(pcm, p)
+    assert r["n_windows"] == 3
+    win = sorted({min(2, max(0, s["t0"]) // 3000) for s in r["segments"][:-1]} | {2})
+    assert not any(3000 <= s["t0"] < 5900 for s in r["segments"]) and any(0 <= s["t0"] < 3000 for s in r["segments"]) and win == [0, 2]
+    q = oracle_tiny.default_params(); q.temperature_inc = 0.0
+    rq = oracle_tiny.full(pcm, q)                                             # with the default thresholds every window is speech
+    assert rq["n_windows"] == 3 and len(rq["tokens"]) > len(r["tokens"])

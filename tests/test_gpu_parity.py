@@ -266,3 +266,15 @@ def test_small_model_ragged_multi_window_matches_oracle(eng, small_model_path):
         assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
     assert res[2]["n_windows"] >= 2 and res[3]["segments"] == []
     ctx.close(); m.close()
+
+
+def test_no_speech_middle_window_keeps_the_carried_prompt(eng, tiny_model_path):
+    """prompt_past across a window classed no-speech (tests/test_cpu_oracle.py::test_prompt_past_survives_a_no_speech_window): engine == oracle."""
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=2, max_samples=16000 * 80); om = OracleModel(tiny_model_path)
+    pcms = [synth.clip(11, 16000 * 75), synth.clip(12, 16000 * 40)]
+    p = ctx.default_params(); p.no_speech_thold = -1.0; p.logprob_thold = -0.3; p.temperature_inc = 0.0
+    po = om.default_params(); po.no_speech_thold = -1.0; po.logprob_thold = -0.3; po.temperature_inc = 0.0
+    for pcm, rg in zip(pcms, ctx.full_batch(pcms, p)):
+        ro = om.full(pcm, po)
+        assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"]
+    ctx.close(); m.close()
