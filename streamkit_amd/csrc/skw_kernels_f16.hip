@@ -96,13 +96,15 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
 // rows a wave-instruction writes land on different banks), and all threads then move whole rows: 16 bytes per lane, 512-byte or
 // 1-KiB contiguous runs per row, residual / positional-embedding operands read the same way.
 template <int EPI> struct Epi16Out { static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_CONV2); };
-// the value an output element takes before the row-wise operands (residual, positional embedding) are added; f16-valued for f16 outputs
+// the value an output element takes before the row-wise operands (residual, positional embedding) are added; f16-valued for f16 outputs.
+// `bias` is the element's bias (0 when the GEMM has none): the caller takes it from the tile's LDS copy — a global load per element
+// here is a dependent round trip each (hipcc waits vmcnt(0) per use while LDS-DMA is in flight) and was 60 % of the epilogue.
 template <int EPI>
-__device__ __forceinline__ float epi_value(const SkwGemmArgs& a, int y, int xlog, float v) {
-    if (EPI == EPI_F32) { if (a.bias) v = v + a.bias[xlog]; return v; }
-    if (EPI == EPI_CONV2) { v = v + a.bias[xlog]; return h2f(f2h(gelu16(v))); }
-    if (EPI == EPI_VT_F16) { if (a.bias) v = v + a.bias[y]; return (xlog % a.Tpad < a.n_ctx) ? h2f(f2h(v)) : 0.0f; }      // pad keys stay zero
-    if (a.bias) v = v + a.bias[xlog];
+__device__ __forceinline__ float epi_value(const SkwGemmArgs& a, int xlog, float v, float bias) {
+    if (EPI == EPI_F32) { if (a.bias) v = v + bias; return v; }
+    if (EPI == EPI_CONV2) { v = v + bias; return h2f(f2h(gelu16(v))); }
+    if (EPI == EPI_VT_F16) { if (a.bias) v = v + bias; return (xlog % a.Tpad < a.n_ctx) ? h2f(f2h(v)) : 0.0f; }      // pad keys stay zero
+    if (a.bias) v = v + bias;
     if (EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD) return h2f(f2h(gelu16(v)));
     if (a.has_scale) v = v * a.scale;
     return h2f(f2h(v));
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     constexpr bool X_IS_M = Epi16<EPI>::X_IS_M, PERM = Epi16<EPI>::PERM;
     constexpr int TX = X_IS_M ? TM : TN, TY = X_IS_M ? TN : TM;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "whole pieces per wave");
-    __shared__ __attribute__((aligned(1024))) char lds[2 * (BM + BN) * 128];
+    __shared__ __attribute__((aligned(1024))) char lds[2 * (BM + BN) * 128 + 1024];        // two K-step buffers + the tile's bias values
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // V^T: the M axis is walked in virtual rows b * Tpad + key so that 32-key kperm blocks never straddle two clips
     const int Mv = X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
@@ -217,20 +219,27 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             constexpr int NPASS = BY / RP, CE = 16 / ESZ;                                    // elements per chunk
             static_assert(BY % RP == 0 && (CPR & (CPR - 1)) == 0, "whole passes, power-of-two chunks per row");
             char* stg = lds + (BM + BN) * 128;                                               // buffer 1
+            float* bias_l = (float*)(lds + 2 * (BM + BN) * 128);                             // bias of the tile's 256 (or 128) features, in memory-position order
             const int wX = X_IS_M ? wr : wc, wY = X_IS_M ? wc : wr;
+            {   // features run along X (weights) except for V^T, where they run along Y
+                constexpr int NB = X_IS_M ? BY : BX;
+                if (tid < NB) { const int pos = (X_IS_M ? Y0 : X0) + tid; const int f = (PERM && !X_IS_M) ? ((pos & ~31) | inv_kperm32(pos & 31)) : pos; bias_l[tid] = (a.bias && f < a.N) ? a.bias[f] : 0.0f; }
+                __syncthreads();
+            }
             for (int pass = 0; pass < NPASS; ++pass) {
                 // phase A: this pass's rows, from the waves that hold them
 #pragma unroll
                 for (int j = 0; j < TY; ++j) {
                     const int yl = wY * WTY + j * 16 + r16;
                     if ((wY * WTY + j * 16) / RP != pass) continue;                          // wave-uniform
-                    const int y = Y0 + yl, ylp = yl - pass * RP;
+                    const int ylp = yl - pass * RP;
 #pragma unroll
                     for (int i = 0; i < TX; ++i) {
                         const int xl = wX * WTX + i * 16 + 4 * g, p0 = X0 + xl;
                         float o[4];
+                        const f32x4 bx = X_IS_M ? (f32x4){bias_l[yl], bias_l[yl], bias_l[yl], bias_l[yl]} : *(const f32x4*)(bias_l + xl);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const int xlog = PERM ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r; o[r] = epi_value<EPI>(a, y, xlog, acc[i][j][r]); }
+                        for (int r = 0; r < 4; ++r) o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
                         const int ck = xl / CE;
                         char* dst = stg + ylp * ROWB + ((ck ^ (ylp & (CPR - 1))) << 4);
                         if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
@@ -238,18 +247,31 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                     }
                 }
                 __syncthreads();
-                // phase B: whole rows out, 16 bytes per lane
-                for (int cid = tid; cid < RP * CPR; cid += NW * 64) {
-                    const int ylp = cid / CPR, pc = cid % CPR, ck = pc ^ (ylp & (CPR - 1));
-                    const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
-                    if (y >= y_lim || px >= x_lim) continue;
-                    const long off = epi_chunk_offset<EPI>(a, y, px);
-                    if (F32OUT) {
-                        f32x4 v = *(const f32x4*)(stg + ylp * ROWB + (pc << 4));
-                        if (EPI == EPI_F32 && a.res) { const f32x4 rr = *(const f32x4*)(a.res + (long)y * a.ldres + px); v[0] = v[0] + rr[0]; v[1] = v[1] + rr[1]; v[2] = v[2] + rr[2]; v[3] = v[3] + rr[3]; }
-                        if (EPI == EPI_CONV2) { const f32x4 pe = *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + px); v[0] = pe[0] + v[0]; v[1] = pe[1] + v[1]; v[2] = pe[2] + v[2]; v[3] = pe[3] + v[3]; }
-                        *(f32x4*)((float*)a.C + off) = v;
-                    } else *(u32x4*)((half_t*)a.C + off) = *(const u32x4*)(stg + ylp * ROWB + (pc << 4));
+                // phase B: whole rows out, 16 bytes per lane; the row-wise operands of a batch of chunks are requested together
+                constexpr int NCH = RP * CPR / (NW * 64), BATCH = !F32OUT ? 2 : (NCH < 4 ? NCH : 4);     // (f16 outputs have no row-wise operand to wait for)
+                static_assert((RP * CPR) % (NW * 64) == 0 && NCH % BATCH == 0, "whole chunks per thread");
+#pragma unroll 1
+                for (int c0 = 0; c0 < NCH; c0 += BATCH) {
+                    long off[BATCH]; f32x4 opnd[BATCH]; int lofs[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        const int cid = tid + (c0 + u) * NW * 64, ylp = cid / CPR, pc = cid % CPR, ck = pc ^ (ylp & (CPR - 1));
+                        const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
+                        lofs[u] = ylp * ROWB + (pc << 4);
+                        off[u] = (y >= y_lim || px >= x_lim || (a.probe & 8)) ? -1 : epi_chunk_offset<EPI>(a, y, px);
+                        if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? *(const f32x4*)(a.res + (long)y * a.ldres + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_CONV2) opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        if (off[u] < 0) continue;
+                        if (F32OUT) {
+                            f32x4 v = *(const f32x4*)(stg + lofs[u]);
+                            if (EPI == EPI_F32) { if (a.res) { v[0] = v[0] + opnd[u][0]; v[1] = v[1] + opnd[u][1]; v[2] = v[2] + opnd[u][2]; v[3] = v[3] + opnd[u][3]; } }
+                            else { v[0] = opnd[u][0] + v[0]; v[1] = opnd[u][1] + v[1]; v[2] = opnd[u][2] + v[2]; v[3] = opnd[u][3] + v[3]; }
+                            *(f32x4*)((float*)a.C + off[u]) = v;
+                        } else *(u32x4*)((half_t*)a.C + off[u]) = *(const u32x4*)(stg + lofs[u]);
+                    }
                 }
                 __syncthreads();
             }
