@@ -239,7 +239,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         float o[4];
                         const f32x4 bx = X_IS_M ? (f32x4){bias_l[yl], bias_l[yl], bias_l[yl], bias_l[yl]} : *(const f32x4*)(bias_l + xl);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
+                        for (int r = 0; r < 4; ++r) { const int xlog = (PERM && X_IS_M) ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;      // (only V^T looks at the logical index: its pad keys)
+                            o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, xlog, acc[i][j][r], bx[r]); }
                         const int ck = xl / CE;
                         char* dst = stg + ylp * ROWB + ((ck ^ (ylp & (CPR - 1))) << 4);
                         if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
