@@ -43,12 +43,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // instead of looked up: the 128-KB table costs one 2-byte gather per element (a third of the FC1 GEMM's time at f16 matrix rates).
 // tanh through exp2 / rcp: within an f32 ulp or two of libm's, i.e. the same f16 except at rounding boundaries (tolerance mode).
 __device__ __forceinline__ float gelu16(float v) {
-    if (v <= -10.0f) return 0.0f;
-    if (v >= 10.0f) return v;
     const float x = h2f(f2h(v));
-    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  -2u log2(e) = x (c1 + c2 x^2)
+    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  -2u log2(e) = x (c1 + c2 x^2).  ggml's x <= -10 -> 0 and x >= 10 -> x cases are the
+    // formula's own limits (exp2 overflows to inf / underflows to 0), so they need no branches.
     const float z = x * __builtin_fmaf(x * x, -2.88539008177792681472f * 0.79788456080286535588f * 0.044715f, -2.88539008177792681472f * 0.79788456080286535588f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));          // the caller rounds to f16 (conv2 adds the positional embedding to the f16 value)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));          // the caller rounds to f16
 }
 // four adjacent output elements: memory position p0 .. p0+3 along X (p0 % 4 == 0), logical X indices x[0..3], the other index y
 template <int EPI>
@@ -102,19 +101,24 @@ template <int EPI> struct Epi16Out { static constexpr bool F32OUT = (EPI == EPI_
 template <int EPI>
 __device__ __forceinline__ float epi_value(const SkwGemmArgs& a, int xlog, float v, float bias) {
     if (EPI == EPI_F32) { if (a.bias) v = v + bias; return v; }
-    if (EPI == EPI_CONV2) { v = v + bias; return h2f(f2h(gelu16(v))); }
-    if (EPI == EPI_VT_F16) { if (a.bias) v = v + bias; return (xlog % a.Tpad < a.n_ctx) ? h2f(f2h(v)) : 0.0f; }      // pad keys stay zero
+    if (EPI == EPI_CONV2) { v = v + bias; return h2f(f2h(gelu16(v))); }                      // (f16-valued GELU + f32 positional embedding)
+    if (EPI == EPI_VT_F16) { if (a.bias) v = v + bias; return v; }                         // (pad keys are zeroed by the caller, which knows the key index)
     if (a.bias) v = v + bias;
-    if (EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD) return h2f(f2h(gelu16(v)));
+    if (EPI == EPI_GELU_F16_KPERM || EPI == EPI_GELU_F16_KPERM_ROWPAD) return gelu16(v);      // (f16 outputs are rounded once, when they are staged)
     if (a.has_scale) v = v * a.scale;
-    return h2f(f2h(v));
+    return v;
 }
-// where the 16-byte chunk starting at memory position px of row y lives (element offset into C), or -1 when it is not stored
+// where the 16-byte chunk starting at memory position px of row y lives (element offset into C).  (qb, rb) = (Y0 / n_ctx, Y0 % n_ctx) for
+// the row-indexed layouts and (X0 / Tpad, X0 % Tpad) for V^T, computed once per tile: a tile is shorter than a clip, so the quotient
+// of any of its rows is qb or qb + 1 — no division per chunk.
 template <int EPI>
-__device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, int px) {
-    if (EPI == EPI_GELU_F16_KPERM_ROWPAD) return ((long)(y / a.n_ctx) * (a.n_ctx + 2) + (y % a.n_ctx) + 1) * a.ldc + px;
-    if (EPI == EPI_HEADS_F16) { const int b = y / a.n_ctx, i = y % a.n_ctx; return ((long)(b * a.H + (px >> 6)) * a.Tpad + i) * 64 + (px & 63); }
-    if (EPI == EPI_VT_F16) { const int b = px / a.Tpad, kp = px % a.Tpad; return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
+__device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, int px, int dy, int dx, int qb, int rb) {
+    if (EPI == EPI_GELU_F16_KPERM_ROWPAD || EPI == EPI_HEADS_F16) {
+        int i = rb + dy, b = qb; if (i >= a.n_ctx) { i -= a.n_ctx; b += 1; }
+        if (EPI == EPI_HEADS_F16) return ((long)(b * a.H + (px >> 6)) * a.Tpad + i) * 64 + (px & 63);
+        return ((long)b * (a.n_ctx + 2) + i + 1) * a.ldc + px;
+    }
+    if (EPI == EPI_VT_F16) { int kp = rb + dx, b = qb; if (kp >= a.Tpad) { kp -= a.Tpad; b += 1; } return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
     return (long)y * a.ldc + px;
 }
 
@@ -221,6 +225,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             char* stg = lds + (BM + BN) * 128;                                               // buffer 1
             float* bias_l = (float*)(lds + 2 * (BM + BN) * 128);                             // bias of the tile's 256 (or 128) features, in memory-position order
             const int wX = X_IS_M ? wr : wc, wY = X_IS_M ? wc : wr;
+            const int div = X_IS_M ? a.Tpad : (a.n_ctx > 0 ? a.n_ctx : 1), org = X_IS_M ? X0 : Y0;
+            const int qb = org / div, rb = org % div;                                          // (scalar: once per tile)
             {   // features run along X (weights) except for V^T, where they run along Y
                 constexpr int NB = X_IS_M ? BY : BX;
                 if (tid < NB) { const int pos = (X_IS_M ? Y0 : X0) + tid; const int f = (PERM && !X_IS_M) ? ((pos & ~31) | inv_kperm32(pos & 31)) : pos; bias_l[tid] = (a.bias && f < a.N) ? a.bias[f] : 0.0f; }
@@ -239,12 +245,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         float o[4];
                         const f32x4 bx = X_IS_M ? (f32x4){bias_l[yl], bias_l[yl], bias_l[yl], bias_l[yl]} : *(const f32x4*)(bias_l + xl);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const int xlog = (PERM && X_IS_M) ? (((p0 + r) & ~31) | inv_kperm32((p0 + r) & 31)) : p0 + r;      // (only V^T looks at the logical index: its pad keys)
-                            o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, xlog, acc[i][j][r], bx[r]); }
+                        for (int r = 0; r < 4; ++r) {
+                            o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
+                            if (X_IS_M) { int key = rb + (((xl + r) & ~31) | inv_kperm32((xl + r) & 31)); if (key >= a.Tpad) key -= a.Tpad; if (key >= a.n_ctx) o[r] = 0.0f; }   // V^T: pad keys stay zero (logical key of this memory position)
+                        }
                         const int ck = xl / CE;
                         char* dst = stg + ylp * ROWB + ((ck ^ (ylp & (CPR - 1))) << 4);
                         if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
-                        else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                        else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
                     }
                 }
                 __syncthreads();
@@ -259,9 +267,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         const int cid = tid + (c0 + u) * NW * 64, ylp = cid / CPR, pc = cid % CPR, ck = pc ^ (ylp & (CPR - 1));
                         const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
                         lofs[u] = ylp * ROWB + (pc << 4);
-                        off[u] = (y >= y_lim || px >= x_lim || (a.probe & 8)) ? -1 : epi_chunk_offset<EPI>(a, y, px);
+                        off[u] = (y >= y_lim || px >= x_lim || (a.probe & 8)) ? -1 : epi_chunk_offset<EPI>(a, y, px, pass * RP + ylp, ck * CE, qb, rb);
                         if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? *(const f32x4*)(a.res + (long)y * a.ldres + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (EPI == EPI_CONV2) opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)(y % a.n_ctx) * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_CONV2) { int i = rb + pass * RP + ylp; if (i >= a.n_ctx) i -= a.n_ctx; opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u) {
