@@ -324,8 +324,8 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // One workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries (two 16-query MFMA tiles).  K rows and V^T
 // rows arrive in 64-key blocks through a double-buffered LDS image shared by the four waves (register staged: one 16-byte chunk
 // per thread per operand half, swizzled on the store so the fragment reads are conflict-free), so each K / V byte leaves L2 once
-// per 128 queries instead of once per 16 as in the exact kernel.  Two passes over the keys: (1) S^T = K.Q^T for the exact row
-// maximum; (2) S^T again, p = exp2((s - max) * scale * log2 e), row sums, and O^T += V^T . P^T with P^T taken straight from the
+// per 128 queries instead of once per 16 as in the exact kernel.  One pass over the keys, flash-attention style: S^T = K.Q^T per
+// block, running row maximum, p = exp2((s - max) * scale * log2 e), row sums, and O^T += V^T . P^T with P^T taken straight from the
 // S^T accumulators (MFMA row rho of a 16-key tile holds key 4 * (rho & 3) + (rho >> 2), which is the order the kperm'ed V^T rows
 // store their keys in).  Normalisation by the row sum happens once, on O.
 #define A16_QB 128
@@ -385,31 +385,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         s0 = MFMA16X32(k0, qf[0][0], ((f32x4){0.f, 0.f, 0.f, 0.f})); s1 = MFMA16X32(k0, qf[1][0], ((f32x4){0.f, 0.f, 0.f, 0.f}));
         s0 = MFMA16X32(k1, qf[0][1], s0); s1 = MFMA16X32(k1, qf[1][1], s1);
     };
-    // ---- pass 1: exact row maxima
-    float mx0 = -INFINITY, mx1 = -INFINITY;
-    load_k(0); store_k(0); __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const char* kbase = &lds[kb & 1][0][0];
-        if (kb + 1 < nkb) load_k(kb + 1);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            f32x4 s0, s1; scores(kbase, kt, s0, s1);
-            if (kb == nkb - 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (kb * 64 + kt * 16 + 4 * r + g >= n_ctx) { s0[r] = -INFINITY; s1[r] = -INFINITY; }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { mx0 = fmaxf(mx0, s0[r]); mx1 = fmaxf(mx1, s1[r]); }
-        }
-        if (kb + 1 < nkb) store_k((kb + 1) & 1);
-        __syncthreads();
-    }
-    mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64)); mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
-    mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
-    // ---- pass 2: probabilities, row sums, O^T
+    // ---- one pass over the keys with a running row maximum (online softmax): per 64-key block the scores of both query tiles, their
+    // block maximum (lane-local over 16 scores, then across the four lanes of a query), and — only when some query's maximum grew, which
+    // stops happening after the first few blocks — a rescale of that tile's O^T accumulators and row sum by 2^((m_old - m_new) c).
     const float c1 = kq_scale * 1.44269504088896341f;
-    const float mc0 = mx0 * c1, mc1 = mx1 * c1;
-    float l0 = 0.0f, l1 = 0.0f;
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.0f, l1 = 0.0f;
     f32x4 oacc[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -419,19 +399,39 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     for (int kb = 0; kb < nkb; ++kb) {
         const char* kbase = &lds[kb & 1][0][0]; const char* vbase = &lds[kb & 1][1][0];
         if (kb + 1 < nkb) { load_k(kb + 1); load_v(kb + 1); }
-        f16x8 p0[2], p1[2];      // P^T fragments [32-key half of the block]: element 4 * (kt & 1) + r of lane (query, g) = key 16 kt + 4 r + g
+        f32x4 s0[4], s1[4];
+        float bm0 = -INFINITY, bm1 = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f32x4 s0, s1; scores(kbase, kt, s0, s1);
+            scores(kbase, kt, s0[kt], s1[kt]);
+            if (kb == nkb - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (kb * 64 + kt * 16 + 4 * r + g >= n_ctx) { s0[kt][r] = -INFINITY; s1[kt][r] = -INFINITY; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bm0 = fmaxf(bm0, s0[kt][r]); bm1 = fmaxf(bm1, s1[kt][r]); }
+        }
+        bm0 = fmaxf(bm0, __shfl_xor(bm0, 16, 64)); bm0 = fmaxf(bm0, __shfl_xor(bm0, 32, 64));
+        bm1 = fmaxf(bm1, __shfl_xor(bm1, 16, 64)); bm1 = fmaxf(bm1, __shfl_xor(bm1, 32, 64));
+        if (__builtin_amdgcn_ballot_w64(bm0 > m0 || bm1 > m1)) {                // wave-uniform
+            const float n0 = fmaxf(m0, bm0), n1 = fmaxf(m1, bm1);
+            const float a0 = __builtin_amdgcn_exp2f((m0 - n0) * c1), a1 = __builtin_amdgcn_exp2f((m1 - n1) * c1);   // first block: exp2(-inf) = 0 on empty accumulators
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { oacc[0][ct][r] *= a0; oacc[1][ct][r] *= a1; }
+            l0 *= a0; l1 *= a1; m0 = n0; m1 = n1;
+        }
+        const float mc0 = m0 * c1, mc1 = m1 * c1;
+        f16x8 p0[2], p1[2];      // P^T fragments [32-key half of the block]: element 4 * (kt & 1) + r of lane (query, g) = key 16 kt + 4 r + g
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c1, -mc0)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c1, -mc1));
-                if (kb == nkb - 1 && kb * 64 + kt * 16 + 4 * r + g >= n_ctx) { e0 = 0.0f; e1 = 0.0f; }
-                const half_t h0 = (half_t)e0, h1 = (half_t)e1;
-                l0 += (float)h0; l1 += (float)h1;                      // the sum of what P.V will actually use
-                p0[kt >> 1][(kt & 1) * 4 + r] = h0; p1[kt >> 1][(kt & 1) * 4 + r] = h1;
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[kt][r], c1, -mc0)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[kt][r], c1, -mc1));   // masked keys: exp2(-inf) = 0
+                l0 += e0; l1 += e1;
+                p0[kt >> 1][(kt & 1) * 4 + r] = (half_t)e0; p1[kt >> 1][(kt & 1) * 4 + r] = (half_t)e1;
             }
-        }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
