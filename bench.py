@@ -7,9 +7,10 @@ c -> rank c mod N (independent clips: no data-path collective), then one RCCL al
 `python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (fresh child processes; the parent never
 touches the GPU); under torchrun it is one of the ranks.  Rank 0 prints ONE JSON line.
 
-The headline runs the f16-MFMA precision (f16 operands on the f16 matrix cores, f32 accumulate; token ids / timestamps / texts
-checked identical to the exact mode on every clip of the batch and to the CPU oracle on a sample); the exact mode (f32-chain
-contractions, bit-identical to the oracle) is timed beside it and reported under "modes".
+The headline runs the f16-MFMA precision (f16 operands on the f16 matrix cores, f32 accumulate; its transcripts are compared
+with the exact mode's on every clip of the batch — they may differ only from a near-tie of the greedy argmax on, DESIGN.md §1 —
+and with the CPU oracle's on a sample); the exact mode (f32-chain contractions, bit-identical to the oracle) is timed beside
+it and reported under "modes".
 """
 import argparse
 import json
@@ -184,9 +185,19 @@ def main():
         t_o = ctx.timing()
         modes[other] = {"value": round(n_o * audio_per_step / dt_o, 2), "ms_per_step": round(1000.0 * dt_o / n_o, 3),
                         "encode_ms": round(t_o["encode_ms"], 3), "decode_ms": round(t_o["decode_ms"], 3), "mel_ms": round(t_o["mel_ms"], 3)}
-        identical = all([t[0] for t in a["tokens"]] == [t[0] for t in b["tokens"]] and
-                        [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]]
-                        for a, b in zip(res, res_o))
+        same = [[t[0] for t in a["tokens"]] == [t[0] for t in b["tokens"]] and
+                [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]] for a, b in zip(res, res_o)]
+        # a clip that differs must differ from a near-tie on: the exact mode's top1 - top2 logit margin at the first differing token
+        ex = res_o if other == "exact" else res
+        fa = res if other == "exact" else res_o
+        margins = []
+        for a, b, ok in zip(fa, ex, same):
+            if not ok:
+                ia, ib = [t[0] for t in a["tokens"]], [t[0] for t in b["tokens"]]
+                k = next((i for i, (x, y) in enumerate(zip(ia, ib)) if x != y), min(len(ia), len(ib)))
+                margins.append(min(b["tokens"][k][4] if k < len(ib) else float("inf"), b["min_margin"]))
+        identical = {"identical_clips": int(sum(same)), "of": len(same), "largest_exact_mode_margin_at_a_divergence": round(max(margins), 4) if margins else None,
+                     "note": "transcripts may differ only from a near-tie of the greedy argmax on (DESIGN.md section 1; tests/test_gpu_f16.py bounds the margin)"}
         ctx.set_precision(args.precision)
 
     fast = args.precision == "f16_mfma"
@@ -203,7 +214,7 @@ def main():
                    "last_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
                    "fallback_requested": int(sum(r["fallback_requested"] for r in res))},
         "modes": modes,
-        "tokens_identical_between_modes": identical,
+        "transcripts_f16_vs_exact": identical,
         "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
         "value_pcie_inclusive": round(pcie_value, 2),
     }
@@ -261,7 +272,8 @@ def main():
         t_roof = enc_fl / (mfma_peak * 1e12) + dec_bytes / (HBM_PEAK_GBS * 1e9) + fe_bytes / (HBM_PEAK_GBS * 1e9)
         ph["combined"] = {"roofline_ms": round(t_roof * 1e3, 3), "measured_ms": round(timing["total_ms"], 3), "frac": round(t_roof * 1e3 / timing["total_ms"], 4)}
         roof["phases"] = ph
-        roof["profiled_step_ms"] = {"encode": round(tprof["encode_ms"], 2), "decode_one_group": round(tprof["decode_ms"], 2)}
+        roof["profiled_step_ms"] = {"encode": round(tprof["encode_ms"], 2), "decode": round(tprof["decode_ms"], 2),
+                                    "note": "the step the per-kernel event pairs were taken in (eager launches, an event pair per kernel): its wall time is not the benchmark's"}
         out["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

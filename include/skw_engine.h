@@ -114,7 +114,7 @@ void skw_result_free(skw_result*);
 typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t n_windows, n_decode_steps, n_tokens; } skw_timing;
 void skw_ctx_last_timing(const skw_ctx*, skw_timing* out);
 /* per-kernel-class event timing (adds an event pair around every launch; use for roofline accounting, not for the timed run).
- * classes: 0 k_gemm, 1 k_gemm_smallm, 2 k_attn_encoder, 3 k_layernorm, 4 k_mel, 5 k_dec_attn, 6 k_dec_sample, 7 other */
+ * classes: 0 k_gemm, 1 k_gemm_smallm, 2 k_attn_encoder, 3 k_layernorm, 4 k_mel, 5 k_dec_self_attn, 6 k_dec_sample, 7 other, 8 k_dec_cross_attn */
 void skw_ctx_profile(skw_ctx*, int on);
 int  skw_ctx_profile_get(skw_ctx*, int cls, char* name, size_t name_len, long* count, double* ms, double* algorithmic_flops, double* algorithmic_bytes);
 /* the HIP stream the engine launches on (opaque hipStream_t) */

@@ -193,7 +193,7 @@ class Context:
 
     def profile_get(self):
         out = {}
-        for cls in range(8):
+        for cls in range(9):
             name = C.create_string_buffer(64); cnt = C.c_long(); ms = C.c_double(); fl = C.c_double(); by = C.c_double()
             if lib().skw_ctx_profile_get(self.h, cls, name, 64, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by)) == 0:
                 out[name.value.decode()] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
