@@ -1383,25 +1383,43 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
 // per chunk: idx starts at last_index, `while idx < end_idx { idx += t_ratio; out = (1-frac)*y[floor idx] + frac*y[floor idx + 1] }`,
 // last_index = idx - chunk.  The index recurrence is a sequential f64 accumulation whose roundings decide `frac`, across the whole
 // stream.  It is parallelised without giving that up:
-//   k_resample_starts  one lane proposes every chunk's start index, output count and output offset from the closed form
-//                      n = ceil((end - s) / t), s' = s + n t - chunk (O(1) per chunk; exact whenever every add of the walk is exact,
-//                      e.g. the 48 kHz -> 16 kHz case of an Opus source, t = 3);
+//   k_resample_starts  one lane proposes every chunk's start index, output count and output offset by stepping whole binades of the
+//                      f64 index at a time (exact integer arithmetic per binade, a real addition at each crossing);
 //   k_resample_walk    one lane PER CHUNK walks its chunk with the real f64 recurrence from the proposed start, writes
 //                      (sample index, frac) for its outputs and checks that it produced the proposed count and hands the next chunk
 //                      exactly the proposed start — by induction the proposal then IS the sequential walk, bit for bit;
-//   k_resample_scan    the original single-lane walk, which only runs when a check failed (ratios whose adds round, e.g. 44.1 kHz).
+//   k_resample_scan    the original single-lane walk, which only runs when a check failed or the proposal met a rounding tie.
 // The interpolation (k_resample_lerp) is data parallel.
+// The proposal must reproduce n dependent f64 additions exactly.  Inside one binade [2^e, 2^(e+1)) every x is a multiple of
+// ulp_e = 2^(e-52), so fl(x + t) = x + RN_e(t) with RN_e(t) = t rounded to that grid (no tie: then the rounding would depend on x's
+// parity and the proposal gives up — flag — for the sequential walk): a whole binade is one integer multiply-add.  A chunk crosses
+// ~10 binades (index -10 .. 950), each crossing is one real f64 addition; 1500 chunks cost one lane ~0.3 ms instead of ~30.
 __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, int n_chunks, double* start, int* count, int* offset, int* flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
-    double s = last_index; int off = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        int n = 0;
-        if (s < end_idx) { n = (int)ceil((end_idx - s) / t_ratio); if (n < 1) n = 1; while (n > 1 && s + (double)(n - 1) * t_ratio >= end_idx) --n; while (s + (double)n * t_ratio < end_idx) ++n; }
+    double s = last_index; int off = 0, bad = 0;
+    for (int c = 0; c < n_chunks && !bad; ++c) {
+        double x = s; int n = 0;
+        while (x < end_idx && x < 4.0) { x += t_ratio; n++; }               // negative / small indices: the few plain additions the walk makes too
+        while (x < end_idx) {
+            const long long bits = __double_as_longlong(x);
+            const int e = (int)((bits >> 52) & 0x7ff) - 1023;                 // x in [2^e, 2^(e+1)), e >= 2
+            long long xi = (bits & 0xfffffffffffffLL) | (1LL << 52);          // x / ulp_e
+            const double ts = ldexp(t_ratio, 52 - e);                         // t / ulp_e, exact
+            const double tr = rint(ts);
+            if (fabs(ts - floor(ts) - 0.5) == 0.0 || tr < 1.0 || e > 40) { bad = 1; break; }   // a tie (or a degenerate ratio): leave it to the sequential walk
+            const long long ti = (long long)tr, Bi = 1LL << 53, endi = (long long)ldexp(end_idx, 52 - e);
+            const long long in_binade = (Bi - xi + ti - 1) / ti - 1;          // additions whose result stays below 2^(e+1)
+            const long long to_end = xi < endi ? (endi - xi + ti - 1) / ti : 0;   // additions the loop condition still allows
+            const long long k = in_binade < to_end ? in_binade : to_end;
+            xi += k * ti; n += (int)k; x = ldexp((double)xi, e - 52);
+            if (k == to_end) break;
+            x = x + t_ratio; n++;                                             // the addition that crosses into the next binade: rounded by the hardware
+        }
         start[c] = s; count[c] = n; offset[c] = off; off += n;
-        s = (s + (double)n * t_ratio) - (double)chunk;
+        s = x - (double)chunk;
     }
-    start[n_chunks] = s; offset[n_chunks] = off; *flag = 0;
+    start[n_chunks] = s; offset[n_chunks] = off; *flag = bad;
 }
 __global__ void k_resample_walk(const double* start, const int* count, const int* offset, double t_ratio, int chunk, int n_chunks, int* pos, float* frac,
                                 int* n_out, double* last_index_out, int cap, int* flag) {
