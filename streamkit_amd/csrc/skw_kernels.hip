@@ -1391,14 +1391,23 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
 //   k_resample_scan    the original single-lane walk, which only runs when a check failed or the proposal met a rounding tie.
 // The interpolation (k_resample_lerp) is data parallel.
 // The proposal must reproduce n dependent f64 additions exactly.  Inside one binade [2^e, 2^(e+1)) every x is a multiple of
-// ulp_e = 2^(e-52), so fl(x + t) = x + RN_e(t) with RN_e(t) = t rounded to that grid (no tie: then the rounding would depend on x's
-// parity and the proposal gives up — flag — for the sequential walk): a whole binade is one integer multiply-add.  A chunk crosses
-// ~10 binades (index -10 .. 950), each crossing is one real f64 addition; 1500 chunks cost one lane ~0.3 ms instead of ~30.
+// ulp_e = 2^(e-52), so fl(x + t) = x + RN_e(t), t rounded to that grid: a whole binade is one integer multiply-add.  When t sits
+// exactly halfway between two grid points (44.1 kHz sources: t = 441/160 has one bit below the grid of [4, 8)) round-to-even picks
+// the step that makes the result even: from an odd x that is one real addition, after which x is even and the step is the even
+// neighbour for the rest of the binade.  A chunk crosses ~10 binades (index -10 .. 950), each crossing is one real f64 addition;
+// 1500 chunks cost one lane well under a millisecond instead of ~30 ms.  (tests/test_cpu_frontend.py checks the same stepping against the sequential walk for 11 source
+// rates x 3000 chunks on the CPU; on the device k_resample_walk checks every launch.)
+__device__ __forceinline__ long long ceil_div_pos(long long a, long long b) {      // a > 0, b > 0, a < 2^62: no 64-bit integer division (software, ~1 us for one lane)
+    long long q = (long long)((double)a / (double)b);
+    while (q * b < a) ++q;
+    while ((q - 1) * b >= a) --q;
+    return q;
+}
 __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, int n_chunks, double* start, int* count, int* offset, int* flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
-    double s = last_index; int off = 0, bad = 0;
-    for (int c = 0; c < n_chunks && !bad; ++c) {
+    double s = last_index; int off = 0;
+    for (int c = 0; c < n_chunks; ++c) {
         double x = s; int n = 0;
         while (x < end_idx && x < 4.0) { x += t_ratio; n++; }               // negative / small indices: the few plain additions the walk makes too
         while (x < end_idx) {
@@ -1406,11 +1415,16 @@ __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, 
             const int e = (int)((bits >> 52) & 0x7ff) - 1023;                 // x in [2^e, 2^(e+1)), e >= 2
             long long xi = (bits & 0xfffffffffffffLL) | (1LL << 52);          // x / ulp_e
             const double ts = ldexp(t_ratio, 52 - e);                         // t / ulp_e, exact
-            const double tr = rint(ts);
-            if (fabs(ts - floor(ts) - 0.5) == 0.0 || tr < 1.0 || e > 40) { bad = 1; break; }   // a tie (or a degenerate ratio): leave it to the sequential walk
-            const long long ti = (long long)tr, Bi = 1LL << 53, endi = (long long)ldexp(end_idx, 52 - e);
-            const long long in_binade = (Bi - xi + ti - 1) / ti - 1;          // additions whose result stays below 2^(e+1)
-            const long long to_end = xi < endi ? (endi - xi + ti - 1) / ti : 0;   // additions the loop condition still allows
+            const double fl = floor(ts), fr = ts - fl;
+            long long ti = (long long)fl;
+            if (fr == 0.5) {
+                if (xi & 1) { x = x + t_ratio; n++; continue; }               // odd x on a tie: the hardware rounds this one
+                ti += ti & 1;                                                 // the even neighbour
+            } else if (fr > 0.5) ti += 1;
+            if (ti < 1) { x = x + t_ratio; n++; continue; }                   // (degenerate ratios: plain additions)
+            const long long Bi = 1LL << 53, endi = (long long)ldexp(end_idx, 52 - e);
+            const long long in_binade = ceil_div_pos(Bi - xi, ti) - 1;        // additions whose result stays below 2^(e+1)
+            const long long to_end = xi < endi ? ceil_div_pos(endi - xi, ti) : 0;   // additions the loop condition still allows
             const long long k = in_binade < to_end ? in_binade : to_end;
             xi += k * ti; n += (int)k; x = ldexp((double)xi, e - 52);
             if (k == to_end) break;
@@ -1419,7 +1433,7 @@ __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, 
         start[c] = s; count[c] = n; offset[c] = off; off += n;
         s = x - (double)chunk;
     }
-    start[n_chunks] = s; offset[n_chunks] = off; *flag = bad;
+    start[n_chunks] = s; offset[n_chunks] = off; *flag = 0;
 }
 __global__ void k_resample_walk(const double* start, const int* count, const int* offset, double t_ratio, int chunk, int n_chunks, int* pos, float* frac,
                                 int* n_out, double* last_index_out, int cap, int* flag) {

@@ -107,3 +107,56 @@ def test_json_helpers_match_serde_shapes(built):
     assert float(L.mh_json_f32(np.float32(0.7))) == float(np.float32(0.7))
     assert L.mh_utf8_trim(" \t hello world 　".encode()).decode() == "hello world"
     assert L.mh_utf8_valid(b"ok \xe2\x99\xaa", 6) == 1 and L.mh_utf8_valid(b"\xe2\x99", 2) == 0
+
+
+def test_binade_stepping_equals_the_sequential_index_walk():
+    """The arithmetic k_resample_starts uses to propose every chunk's start index (whole binades of the f64 index per step, round-to-even
+    ties included) against rubato's sequential `idx += t_ratio` walk, restated here in Python floats (IEEE f64, same roundings): identical
+    output counts and carried indices for every chunk.  On the GPU k_resample_walk repeats this check for each launch."""
+    import math
+    import struct
+
+    def seq(s, t, chunk):
+        end = float(chunk - 9) - math.ceil(t); x = s; n = 0
+        while x < end:
+            x += t; n += 1
+        return n, x - chunk
+
+    def cdiv(a, b):
+        q = int(float(a) / float(b))
+        while q * b < a:
+            q += 1
+        while (q - 1) * b >= a:
+            q -= 1
+        return q
+
+    def prop(s, t, chunk):
+        end = float(chunk - 9) - math.ceil(t); x = s; n = 0
+        while x < end and x < 4.0:
+            x += t; n += 1
+        while x < end:
+            bits = struct.unpack("<q", struct.pack("<d", x))[0]
+            e = ((bits >> 52) & 0x7FF) - 1023
+            xi = (bits & 0xFFFFFFFFFFFFF) | (1 << 52)
+            ts = math.ldexp(t, 52 - e); a = math.floor(ts); fr = ts - a; ti = int(a)
+            if fr == 0.5:
+                if xi & 1:
+                    x = x + t; n += 1; continue
+                ti += ti & 1
+            elif fr > 0.5:
+                ti += 1
+            endi = int(math.ldexp(end, 52 - e))
+            k = min(cdiv((1 << 53) - xi, ti) - 1, cdiv(endi - xi, ti) if xi < endi else 0)
+            to_end = cdiv(endi - xi, ti) if xi < endi else 0
+            xi += k * ti; n += k; x = math.ldexp(float(xi), e - 52)
+            if k == to_end:
+                break
+            x = x + t; n += 1
+        return n, x - chunk
+
+    for rate in (44100, 22050, 11025, 48000, 8000, 32000, 96000, 24000, 37800):
+        t = 1.0 / (16000 / rate); s = -4.0
+        for c in range(800):
+            a = seq(s, t, 960)
+            assert prop(s, t, 960) == a, (rate, c)
+            s = a[1]
