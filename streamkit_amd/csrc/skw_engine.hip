@@ -351,9 +351,11 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     c->cur = c->stream;
     // decode groups: the step kernels are latency-bound chains that leave most CUs idle, so independent row groups run concurrently
-    { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : 1; }
-    { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : 2; if (c->n_groups < 1) c->n_groups = 1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
-    for (int g = 0; g < c->n_groups && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
+    // -1 = per precision (see skw_full_batch): the exact kernels (9 - 24 us each) run best as two row groups with captured step graphs,
+    // the f16 ones (5 us each) as one group launched eagerly a few steps ahead of the host's liveness check (profiles/r02a)
+    { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : -1; }
+    { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
+    for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
 #define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
     WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
@@ -739,7 +741,9 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
-        const int G = std::max(1, std::min(c->n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
+        const int n_groups = c->n_groups > 0 ? c->n_groups : (c->precision == SKW_PRECISION_F16_MFMA ? 1 : 2);
+        const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : c->precision != SKW_PRECISION_F16_MFMA;
+        const int G = std::max(1, std::min(n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
         for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; c->h_n_active[g] = g_n[g]; }
         HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
@@ -748,7 +752,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         // every step = decoder step (token and position from the device state) + k_dec_sample, which feeds the next prompt token
         // while a row is still inside its prompt and samples afterwards; rows have prompts of different lengths
         hipGraphExec_t gexec[skw_ctx::MAX_GROUPS] = {};
-        if (c->use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
+        if (use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
             { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g]); }
@@ -949,7 +953,7 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
 // ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
 struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
                  size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0;
-                 double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flag = 0; };
+                 double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flags[2] = {0, 0}; };
 extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
     int ndev = skw_device_count();
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: the resampler kernels require an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
@@ -981,13 +985,13 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
     if ((size_t)n_chunks + 1 > d->cap_chunks) {
         hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset); d->cap_chunks = ((size_t)n_chunks + 1) * 2;
         HIPCHK(hipMalloc((void**)&d->d_start, d->cap_chunks * sizeof(double))); HIPCHK(hipMalloc((void**)&d->d_count, d->cap_chunks * sizeof(int))); HIPCHK(hipMalloc((void**)&d->d_offset, d->cap_chunks * sizeof(int)));
-        if (!d->d_flag) HIPCHK(hipMalloc((void**)&d->d_flag, sizeof(int)));
+        if (!d->d_flag) HIPCHK(hipMalloc((void**)&d->d_flag, 2 * sizeof(int)));
     }
     skw_resample_linear_launch(d->d_in, ch, st->last_index, 1.0 / st->ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames,
                                d->d_start, d->d_count, d->d_offset, d->d_flag, d->stream);
     int n = 0; double li = 0;
     HIPCHK(hipMemcpyAsync(&n, d->d_n, sizeof(int), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipMemcpyAsync(&li, d->d_li, sizeof(double), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipMemcpyAsync(&d->last_flag, d->d_flag, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(d->last_flags, d->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     if (n > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity %d too small for %d frames", out_cap_frames, n); return -1; }
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n * ch, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
@@ -1036,7 +1040,7 @@ extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_fra
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n_out * channels, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     *out_frames = n_out; return 0;
 }
-extern "C" int skw_dsp_last_scan_fallback(const skw_dsp* d) { return d->last_flag; }
+extern "C" int skw_dsp_last_scan_fallback(const skw_dsp* d) { return d->last_flags[1] ? 2 : (d->last_flags[0] ? 1 : 0); }
 
 // streaming polyphase: the input tail the later outputs still need stays on the device; a push uploads only the new frames and
 // computes only the outputs whose filter support has arrived (all remaining ones when `final`).  Identical to the whole-buffer result.

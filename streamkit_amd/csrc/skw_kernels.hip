@@ -1383,8 +1383,9 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
 // per chunk: idx starts at last_index, `while idx < end_idx { idx += t_ratio; out = (1-frac)*y[floor idx] + frac*y[floor idx + 1] }`,
 // last_index = idx - chunk.  The index recurrence is a sequential f64 accumulation whose roundings decide `frac`, across the whole
 // stream.  It is parallelised without giving that up:
-//   k_resample_starts  one lane proposes every chunk's start index, output count and output offset by stepping whole binades of the
-//                      f64 index at a time (exact integer arithmetic per binade, a real addition at each crossing);
+//   k_resample_starts* one lane proposes every chunk's start index, output count and output offset: first by a closed form (one
+//                      division per chunk; right whenever every addition of the walk is exact), and if that fails its check by
+//                      stepping whole binades of the f64 index at a time (exact integer arithmetic per binade, ties included);
 //   k_resample_walk    one lane PER CHUNK walks its chunk with the real f64 recurrence from the proposed start, writes
 //                      (sample index, frac) for its outputs and checks that it produced the proposed count and hands the next chunk
 //                      exactly the proposed start — by induction the proposal then IS the sequential walk, bit for bit;
@@ -1403,8 +1404,24 @@ __device__ __forceinline__ long long ceil_div_pos(long long a, long long b) {   
     while ((q - 1) * b >= a) --q;
     return q;
 }
+// first proposal: the closed form n = ceil((end - s) / t), s' = (s + n t) - chunk — one division per chunk, exact whenever every
+// addition of the walk is exact (48 / 32 / 96 kHz -> 16 kHz: t is a small integer), which k_resample_walk then proves
+__global__ void k_resample_starts_simple(double last_index, double t_ratio, int chunk, int n_chunks, double* start, int* count, int* offset, int* flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
+    double s = last_index; int off = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        int n = 0;
+        if (s < end_idx) { n = (int)ceil((end_idx - s) / t_ratio); if (n < 1) n = 1; while (n > 1 && s + (double)(n - 1) * t_ratio >= end_idx) --n; while (s + (double)n * t_ratio < end_idx) ++n; }
+        start[c] = s; count[c] = n; offset[c] = off; off += n;
+        s = (s + (double)n * t_ratio) - (double)chunk;
+    }
+    start[n_chunks] = s; offset[n_chunks] = off; *flag = 0;
+}
+// second proposal (runs only when the first one failed its check: *flag != 0)
 __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, int n_chunks, double* start, int* count, int* offset, int* flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!*flag) return;
     const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
     double s = last_index; int off = 0;
     for (int c = 0; c < n_chunks; ++c) {
@@ -1433,12 +1450,13 @@ __global__ void k_resample_starts(double last_index, double t_ratio, int chunk, 
         start[c] = s; count[c] = n; offset[c] = off; off += n;
         s = x - (double)chunk;
     }
-    start[n_chunks] = s; offset[n_chunks] = off; *flag = 0;
+    start[n_chunks] = s; offset[n_chunks] = off; *flag = 2;        // 2: this proposal is the one to check
 }
 __global__ void k_resample_walk(const double* start, const int* count, const int* offset, double t_ratio, int chunk, int n_chunks, int* pos, float* frac,
-                                int* n_out, double* last_index_out, int cap, int* flag) {
+                                int* n_out, double* last_index_out, int cap, int* flag, int* fail, int level) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
+    if (level == 2 && *flag != 2) return;                                      // the first proposal was proven: nothing to redo
     const double end_idx = (double)(chunk - 9) - ceil(t_ratio);
     double idx = start[c]; int n = 0; const int o = offset[c];
     while (idx < end_idx) {
@@ -1448,7 +1466,7 @@ __global__ void k_resample_walk(const double* start, const int* count, const int
         n++;
     }
     idx = idx - (double)chunk;
-    if (n != count[c] || idx != start[c + 1]) atomicOr(flag, 1);      // the proposal is not the sequential walk: k_resample_scan redoes it
+    if (n != count[c] || idx != start[c + 1]) atomicOr(fail, 1);      // the proposal is not the sequential walk: the next level redoes it
     if (c == n_chunks - 1) { *n_out = o + n; *last_index_out = idx; }
 }
 __global__ void k_resample_scan(double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out, int cap, const int* flag) {
@@ -1481,9 +1499,14 @@ void skw_resample_linear_launch(const float* in, int channels, double last_index
     static const bool force_scan = getenv("SKW_RESAMPLE_SCAN") != nullptr;     // measurement switch: the single-lane walk only
     if (force_scan) hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
     else {
+        // flag[0]: 0 = first proposal stands, 1 = it failed, 2 = second proposal to be checked; flag[1]: the second one failed too
+        int* fail2 = flag + 1;
+        hipMemsetAsync(flag, 0, 2 * sizeof(int), s);
+        hipLaunchKernelGGL(k_resample_starts_simple, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
+        hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag, flag, 1);
         hipLaunchKernelGGL(k_resample_starts, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
-        hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag);
-        hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)flag);
+        hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag, fail2, 2);
+        hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)fail2);
     }
     hipLaunchKernelGGL(k_resample_lerp, dim3(256), dim3(256), 0, s, in, channels, pos, frac, n_out, out, cap);
 }

@@ -120,7 +120,7 @@ def test_parallel_index_walk_is_proven_or_falls_back(dsp, in_rate):
     x = _signal(chunk * n_chunks, 1, seed=7)
     st = dsp.linear_stream(16000 / in_rate, chunk, 1)
     got = dsp.resample_linear(st, x, n_chunks)
-    assert dsp.last_scan_fallback() == 0
+    assert dsp.last_scan_fallback() == (0 if in_rate in (48000, 32000, 96000, 8000) else 1)     # closed form proven / binade stepping proven; never the single-lane walk
     orc = oracle_lib.OracleResampler(16000 / in_rate, chunk, 1)
     ref = np.concatenate([orc.process(x[c * chunk:(c + 1) * chunk][None])[0] for c in range(n_chunks)])
     assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
