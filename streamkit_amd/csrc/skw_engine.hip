@@ -939,11 +939,14 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
       HIPCHK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice)); }
     HIPCHK(hipMemset(bias, 0, (size_t)std::max(M, N) * 4)); HIPCHK(hipMemset(res, 0, (size_t)M * N * 4));
     SkwGemmArgs a{}; a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = N; a.bias = bias; a.epi = epi; a.scale = 1.0f; a.probe = probe;
-    a.gelu_tab = c->m->gelu_tab; a.pe = res; a.n_ctx = c->m->hp.n_audio_ctx; a.H = N / 64; a.Tpad = c->Tpad; if (epi == EPI_F32) { a.res = res; a.ldres = N; }
+    a.gelu_tab = c->m->gelu_tab; a.pe = res; a.n_ctx = c->m->hp.n_audio_ctx; a.H = N / 64; a.Tpad = c->Tpad; if (epi == EPI_F32 && N < 8192) { a.res = res; a.ldres = N; }
+    if (N >= 8192) a.bias = nullptr;                               // the vocabulary projection: no bias, no residual
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) skw_gemm16(a, c->stream);
+    const bool small = M <= 64;                                      // the decode-step form: a chain of dependent launches, so the figure includes the kernel boundary
+    if (small && epi == EPI_DEC_QKV) { a.C2 = res; a.C3 = res; a.ldc2 = N; a.n_ctx = N / 3; a.ldc = N / 3; }
+    for (int i = 0; i < 3; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) skw_gemm16(a, c->stream);
+    for (int i = 0; i < iters; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_per_launch = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(C); hipFree(bias); hipFree(res);

@@ -504,23 +504,25 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
 // kernel's K/4 dependent f32 MFMAs), the partial tiles meet in LDS and wave t finishes row tile t.  As in k_gemm16 the weights
 // are the MFMA's first operand, so a lane ends up with four adjacent outputs of one row: 16-byte residual loads and stores.
 // Operands come straight from global memory (16-byte buffer loads with hardware range checks; a ring of RD k-blocks in flight).
-template <int EPI, int MT>
-__global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
+template <int EPI, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
     constexpr int RD = (MT == 4) ? 6 : 12;               // k-blocks in flight per wave
-    __shared__ f32x4 red[4][MT][64];
+    __shared__ f32x4 red[NW][MT][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16, my0 = blockIdx.y * (16 * MT);
     const int r16 = lane & 15, g = lane >> 4;
-    const int nkw = (a.K >> 5) >> 2, kb_lo = w * nkw;                 // k-blocks (of 32) per wave; host guarantees K % 128 == 0
+    const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;                  // k-blocks (of 32) per wave; host guarantees K % (32 NW) == 0
     int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
-    const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    // a.probe (tools/dec_gemm_probe.py only): 1 = no weight loads, 2 = no activation loads (out-of-range offsets: zeros without memory traffic),
+    // 4 = no partial-sum exchange and no epilogue, 8 = no stores
+    const unsigned wo = (wn < a.N && !(a.probe & 1)) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
     unsigned ao[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
+    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M && !(a.probe & 2)) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
     u32x4 fw[RD], fa[RD][MT];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (a.probe & 4) { if (acc[0][0] == 12345.678f) ((float*)a.C)[0] = 0.f; return; }
 #pragma unroll
     for (int t = 0; t < MT; ++t) red[w][t][lane] = acc[t];
     __syncthreads();
@@ -563,7 +566,8 @@ __global__ __launch_bounds__(256) void k_gemm16_small(SkwGemmArgs a) {
     const int t = w;                                   // wave t finishes row tile t
     f32x4 v = red[0][t][lane];
 #pragma unroll
-    for (int s = 1; s < 4; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
+    for (int s = 1; s < NW; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
+    if ((a.probe & 8) && v[0] != 12345.678f) return;
     gemm16_small_finish<EPI>(a, my0 + t * 16 + r16, n0 + 4 * g, v, pre_res, pre_po);
 }
 // ------------------------------------------------------------------ decode GEMM with the LayerNorm that feeds it folded in
@@ -680,18 +684,151 @@ bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
     }
 }
 
+// ------------------------------------------------------------------ vocabulary projection of the decode step (K10), f16 MFMA
+// N = n_vocab is ~52k columns: as 16-column strips of k_gemm16_small that is 3 242 workgroups, each re-reading its rows of A from
+// L2 (98 KB for 64 rows: four times the 25 KB of W the strip needs) — 72 us per step, of which 24 us is dispatching the workgroups.
+// Here A is stationary: one workgroup per CU copies its 16 MT rows of A into LDS once (row stride K + 8 halves: the sixteen lanes
+// of a 16-byte read phase then hit sixteen different bank groups) and walks a contiguous range of strips; a wave takes two adjacent
+// strips at a time (one A fragment from LDS feeds both), pairs w, w + 4, ..., with 2 RD k-blocks of W in flight, refilled as they
+// are consumed, across pair boundaries.  A lane's chain for one output runs over the whole K in ascending order (no split): every
+// row sees the same arithmetic whatever the batch.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));             // n_vocab is odd: a row of logits starts on any 4-byte boundary
+template <int MT, int RD>
+__global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_a[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nk = a.K >> 5, bps = nk / RD;                 // k-blocks of 32 per strip, ring refills per strip pair (host: nk % RD == 0)
+    const int rowb = a.K * 2 + 16;
+    const int my0 = blockIdx.y * (16 * MT);
+    const int n_strips = (a.N + 15) >> 4;
+    const int s_lo = blockIdx.x * strips_per_wg, s_hi = min((int)(blockIdx.x + 1) * strips_per_wg, n_strips);
+    const int n_pairs = (s_hi - s_lo + 1) >> 1;
+    const int np = w < n_pairs ? (n_pairs - w + 3) >> 2 : 0;        // this wave's pairs: w, w + 4, ...
+    const int nblk = np * bps;
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    const unsigned oob = 0x7fffff00u;
+    auto w_off = [&](int b, int h) -> unsigned {             // byte offset of this lane's 16 bytes of ring block b (strip h of the pair), k-block 0 of the block
+        if (b >= nblk || (a.probe & 1)) return oob;
+        const int strip = s_lo + 2 * (w + 4 * (b / bps)) + h, kb0 = (b % bps) * RD, wn = strip * 16 + r16;
+        return (strip < s_hi && wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb0 * 32 + g * 8) * 2) : oob;
+    };
+    u32x4 fw[2][RD];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned o = w_off(0, h);
+#pragma unroll
+        for (int j = 0; j < RD; ++j) fw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, o != oob ? o + j * 64 : oob, 0, 0);
+    }
+    // A -> LDS (16-byte chunks, coalesced, eight in flight per thread; rows past M read as zeros)
+    { const int cpr = a.K >> 3, total = 16 * MT * cpr;
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+      for (int q0 = threadIdx.x; q0 < total; q0 += 256 * 8) {
+          u32x4 v[8]; int dsto[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+              const int q = q0 + 256 * u, row = q / cpr, c = q - row * cpr, m = my0 + row;
+              dsto[u] = q < total ? row * rowb + c * 16 : -1;
+              v[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, (q < total && m < a.M && !(a.probe & 2)) ? (unsigned)(((long)m * a.lda + c * 8) * 2) : oob, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (dsto[u] >= 0) *(u32x4*)(lds_a + dsto[u]) = v[u];
+      } }
+    __syncthreads();
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[h][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* la = lds_a + r16 * rowb + g * 16;
+    f16x8 xa[2][MT];                                                             // A fragments of k-block j (slot j & 1): read one k-block ahead of their MFMAs
+    if (nblk > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xa[0][t] = __builtin_bit_cast(f16x8, *(const u32x4*)(la + t * 16 * rowb));
+    }
+    for (int b = 0; b < nblk; ++b) {
+        const unsigned on0 = w_off(b + 1, 0), on1 = w_off(b + 1, 1);
+        const int kb0 = (b % bps) * RD;
+        const int kb_next = ((b + 1) % bps) * RD;                                // (reads past the last block stay inside the image: k-block 0)
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+            const f16x8 xw0 = __builtin_bit_cast(f16x8, fw[0][j]), xw1 = __builtin_bit_cast(f16x8, fw[1][j]);
+            fw[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on0 != oob ? on0 + j * 64 : oob, 0, 0);
+            fw[1][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on1 != oob ? on1 + j * 64 : oob, 0, 0);
+            const int kbn = (j + 1 < RD) ? kb0 + j + 1 : kb_next;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xa[(j + 1) & 1][t] = __builtin_bit_cast(f16x8, *(const u32x4*)(la + t * 16 * rowb + kbn * 64));
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { acc[0][t] = MFMA16X32(xw0, xa[j & 1][t], acc[0][t]); acc[1][t] = MFMA16X32(xw1, xa[j & 1][t], acc[1][t]); }   // D[n = 4g + r][m = 16 t + r16]
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((b + 1) % bps == 0) {                                                // the pair is complete: out it goes
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int strip = s_lo + 2 * (w + 4 * (b / bps)) + h, p0 = strip * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int m = my0 + t * 16 + r16;
+                    if (m < a.M && strip < s_hi && (!(a.probe & 8) || acc[h][t][0] == 12345.678f)) {
+                        float* dst = (float*)a.C + (long)m * a.ldc + p0;
+                        f32x4 x = acc[h][t];
+                        if (p0 + 3 < a.N) {
+                            if (a.bias) { x[0] = x[0] + a.bias[p0]; x[1] = x[1] + a.bias[p0 + 1]; x[2] = x[2] + a.bias[p0 + 2]; x[3] = x[3] + a.bias[p0 + 3]; }
+                            *(f32x4_u*)dst = x;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) dst[r] = a.bias ? x[r] + a.bias[p0 + r] : x[r];
+                        }
+                    }
+                    acc[h][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+}
+template <int MT, int RD> static void launch_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
+    const int lds = 16 * MT * (a.K * 2 + 16);
+    static bool once = false;
+    if (!once) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+    const int n_strips = (a.N + 15) / 16, rows = (a.M + 16 * MT - 1) / (16 * MT);
+    const int slots = std::max(1, skw_cu_count() / rows);
+    const int spw = (n_strips + slots - 1) / slots;
+    hipLaunchKernelGGL((k_gemm16_vocab<MT, RD>), dim3((n_strips + spw - 1) / spw, rows), dim3(256), lds, s, a, spw);
+}
+// plain f32 output with optional bias, no residual; false when the geometry is outside what it handles
+static bool skw_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
+    static const int off = getenv("SKW_DEC_VOCAB_KERNEL") ? !atoi(getenv("SKW_DEC_VOCAB_KERNEL")) : 0;
+    if (off || a.epi != EPI_F32 || a.res || (a.K & 127) || a.K > 2048) return false;
+    const int nk = a.K >> 5;
+    const bool mt4 = 64 * (a.K * 2 + 16) <= 150 * 1024;                          // 64 rows of A in LDS (K <= 1024), else 32
+#define SKW_VOCAB_RD(RDV) do { if (mt4) launch_gemm16_vocab<4, RDV>(a, s); else launch_gemm16_vocab<2, RDV>(a, s); return true; } while (0)
+    if (nk == 24 || nk == 12) SKW_VOCAB_RD(12);                                  // small, tiny
+    if (nk == 32 || nk == 16) SKW_VOCAB_RD(16);                                  // medium, base
+    if (nk == 40) SKW_VOCAB_RD(20);                                              // large
+    SKW_VOCAB_RD(4);
+#undef SKW_VOCAB_RD
+}
+
 // Rows per workgroup: every workgroup re-reads its row block of A from L2 (the weights are the small operand here), and one CU
 // takes in only ~70 GB/s, so fewer rows per workgroup = more workgroups each loading less: 16-row blocks unless told otherwise.
 template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
-    static const int mt = getenv("SKW_DEC_MT") ? atoi(getenv("SKW_DEC_MT")) : 1;
-    if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL((k_gemm16_small<EPI, 2>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm16_small<EPI, 1>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
+    static const int mt_env = getenv("SKW_DEC_MT") ? atoi(getenv("SKW_DEC_MT")) : 1;
+    static const int mt_wide = getenv("SKW_DEC_MT_WIDE") ? atoi(getenv("SKW_DEC_MT_WIDE")) : 4;      // N in [2048, 8192): the QKV and fc1 products
+    static const int mt_vocab = getenv("SKW_DEC_MT_VOCAB") ? atoi(getenv("SKW_DEC_MT_VOCAB")) : 4;   // the logits product: thousands of strips, W read once
+    static const int nw_deep = getenv("SKW_DEC_NW_DEEP") ? atoi(getenv("SKW_DEC_NW_DEEP")) : 4;      // K >= 2048 (fc2); eight waves measured slower: a launch costs ~0.8 us per 1000 waves
+    static const int nw_env = getenv("SKW_DEC_NW") ? atoi(getenv("SKW_DEC_NW")) : 4;
+    const int mt = a.N >= 8192 ? mt_vocab : (a.N >= 2048 ? mt_wide : mt_env);
+    const int nw = (a.K >= 2048 ? nw_deep : nw_env) == 8 && !(a.K & 255) && mt == 1 ? 8 : 4;
+    if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemm16_small<EPI, 2, 4>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(256), 0, s, a);
+    else if (nw == 8) hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 8>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 4>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
 }
 // f16-MFMA form of skw_gemm_smallm; returns false when the geometry is outside what it handles (K % 128 != 0): the caller then
 // launches the exact kernel, which handles everything.
 bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
     if (a.K & 127) return false;
+    if (a.N >= 8192 && !(a.probe & 16) && skw_gemm16_vocab(a, s)) return true;
     switch (a.epi) {
         case EPI_F32: launch_gemm16_small<EPI_F32>(a, s); return true;
         case EPI_F16_PLAIN: launch_gemm16_small<EPI_F16_PLAIN>(a, s); return true;
