@@ -26,6 +26,53 @@ union H8 { uint4 u; half_t h[8]; };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 union H8v { u32x4 v; half_t h[8]; };
 
+// ------------------------------------------------------------------ LayerNorm of R rows by one wave (K3: ggml_norm + mul + add)
+// Lane l owns elements l, l + 64, ... of each row (d <= 1536).  Statistics as ggml_norm: f64 sums over the row, mean and variance
+// rounded to f32, then scale, gain, bias; the f16 image is written in kperm order.  k_layernorm, the embedding kernel and the
+// LayerNorm tail of the decode GEMMs all call this, so every one of them produces the same bits for the same row.
+__device__ __forceinline__ double skw_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int R>
+__device__ __forceinline__ void skw_ln_rows(float (&v)[R][24], const float (&wv)[24], const float (&bv)[24], int d, int lane, const bool (&live)[R], half_t* const (&out16)[R], float* const (&out32)[R]) {
+    double sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sum[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) sum[r] += (double)v[r][c];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = skw_wave_sum_f64(sum[r]);
+    double sum2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float mean = (float)(sum[r] / (double)d);
+        sum2[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; if (i < d) { const float t = v[r][c] - mean; v[r][c] = t; sum2[r] += (double)(t * t); } }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum2[r] = skw_wave_sum_f64(sum2[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float variance = (float)(sum2[r] / (double)d);
+        const float scale = 1.0f / sqrtf(variance + 1e-5f);
+        if (!live[r]) continue;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) {
+            const int i = lane + 64 * c;
+            if (i < d) {
+                float t = v[r][c] * scale; t = t * wv[c]; t = t + bv[c];
+                if (out16[r]) out16[r][skw_kperm(i)] = f2h(t);
+                if (out32[r]) out32[r][i] = t;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ epilogues
 template <int EPI>
 __device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, float v) {

@@ -316,7 +316,7 @@ struct skw_ctx {
     float* x = nullptr; half_t* y16 = nullptr; half_t *Qh = nullptr, *Kh = nullptr, *Vt = nullptr; half_t* hbuf = nullptr; float* enc_out32 = nullptr;
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
-    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; unsigned* ln_cnt = nullptr;   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
@@ -367,7 +367,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
-    WS(logits, float, (size_t)B * hp.n_vocab, false);
+    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     c->max_tok = hp.n_text_ctx / 2;
     WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
 #undef WS
@@ -467,7 +467,8 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
 
 // decode GEMM fed by a LayerNorm of x: one fused kernel in the f16 precision, LayerNorm kernel + GEMM otherwise
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical);
-static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s) {
+static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s, bool normalised = false) {
+    if (normalised) { GEMM_S(c, a, a.K); return; }                     // y16 already holds LayerNorm(x): the GEMM that wrote x did it (ln_tail)
     // measured (profiles/r02): the fused kernel costs 20 us at N = 2304 / 3072 and 10 us at N = 768 where LayerNorm (5 us) + plain GEMM
     // (5 - 6 us) cost 11: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
     static const bool fuse = getenv("SKW_DEC_LN_FUSE") != nullptr;
@@ -569,23 +570,34 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     c->cur = s;
     float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
     half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = c->st + r0;
-    skw_dec_embed(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
+    // The first layer's LayerNorm rides on the embedding kernel (same bits: skw_ln_rows).  The others could ride on the GEMM that completes x
+    // (SKW_DEC_LN_TAIL=1, f16_mfma: the last workgroup to arrive per 16-row block normalises it — 8 launches per layer instead of 11), but a
+    // launch boundary (3 us) is cheaper on this part than what the hand-over costs inside a kernel (write-through stores, two counter
+    // round trips and the read-back, each ~2 us across XCDs): 15.6 us for GEMM + tail against 5.1 + 5.0 for the two launches.  Off by default.
+    static const bool ln_tail_env = getenv("SKW_DEC_LN_TAIL") ? atoi(getenv("SKW_DEC_LN_TAIL")) != 0 : false;
+    const bool tail = ln_tail_env && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
+    const bool embed_ln = dt <= 1536;
+    auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
+    if (embed_ln) skw_dec_embed_ln(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, m->dec[0].attn_ln.w, m->dec[0].attn_ln.b, dy16, s);
+    else skw_dec_embed(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s); }
+          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
         { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s); }
-        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s, tail); }
+        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;
+          if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
+          GEMM_S(c, a, a.K); }
     }
     if (want_logits) {
-        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
+        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
         SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
     c->cur = c->stream;

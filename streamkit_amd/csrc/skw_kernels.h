@@ -28,6 +28,7 @@ enum SkwEpi : int {
     EPI_GELU_F16_KPERM_ROWPAD = 7, // conv1: like 2 but row index remapped m -> (m / T) * (T + 2) + (m % T) + 1 (one zero row of padding per clip side)
 };
 
+#define SKW_LN_CNT_STRIDE 1024
 struct SkwGemmArgs {
     const half_t* A; long lda;      // [M][K] f16, K axis kperm'ed, lda in elements (multiple of 8)
     int a_rows_per_batch; long a_batch_stride; // when a_rows_per_batch > 0: row m lives at A + (m / rpb) * a_batch_stride + (m % rpb) * lda
@@ -46,6 +47,8 @@ struct SkwGemmArgs {
     int epi;
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
+    half_t* ln_out; unsigned* ln_cnt;                          // skw_gemm16_small, EPI_F32 with N = ldc: the workgroup that completes a 16-row block of C also writes
+                                                               // ln_out [M][N] = f16 kperm LayerNorm(C rows; ln_w, ln_b); ln_cnt: SKW_LN_CNT_STRIDE zeroed words per row block (needs N <= 16 * 8 * 15)
 };
 
 // big-M GEMM (LDS-tiled 128x128 block, 4 waves)
@@ -78,6 +81,7 @@ void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, cons
 // ---------------- decoder ----------------
 // x[b][d] = f32(te[tok[b]][kperm(i)]) + pe[pos[b]][i]
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
+void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s);
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null

@@ -240,30 +240,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long)row * d;
-    float v[24], wv[24], bv[24];
-    double sum = 0.0;
+    float v[1][24], wv[24], bv[24];
     // the gain / bias loads go out together with the row (a 64-row decode launch is three dependent round trips otherwise)
 #pragma unroll
-    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; const bool in = i < d; v[c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
-#pragma unroll
-    for (int c = 0; c < 24; ++c) sum += (double)v[c];
-    sum = wave_sum_f64(sum);
-    const float mean = (float)(sum / (double)d);
-    double sum2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; if (i < d) { float t = v[c] - mean; v[c] = t; sum2 += (double)(t * t); } }
-    sum2 = wave_sum_f64(sum2);
-    const float variance = (float)(sum2 / (double)d);
-    const float scale = 1.0f / sqrtf(variance + 1e-5f);
-#pragma unroll
-    for (int c = 0; c < 24; ++c) {
-        int i = lane + 64 * c;
-        if (i < d) {
-            float t = v[c] * scale; t = t * wv[c]; t = t + bv[c];
-            if (out16) out16[(long)row * d + skw_kperm(i)] = f2h(t);
-            if (out32) out32[(long)row * d + i] = t;
-        }
-    }
+    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; const bool in = i < d; v[0][c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
+    const bool live[1] = {true}; half_t* const o16[1] = {out16 ? out16 + (long)row * d : nullptr}; float* const o32[1] = {out32 ? out32 + (long)row * d : nullptr};
+    skw_ln_rows<1>(v, wv, bv, d, lane, live, o16, o32);
 }
 void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s) {
     hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, d, w, b, out16, out32);
@@ -735,8 +717,26 @@ __global__ void k_dec_embed(const half_t* te, const float* pe, const int* tok, c
     const int b = blockIdx.x; const int tk = tok[b * (int)(sizeof(SkwSeqState) / 4)]; const int ps = pos[b * (int)(sizeof(SkwSeqState) / 4)];
     for (int i = threadIdx.x; i < d; i += blockDim.x) x[(long)b * d + i] = h2f(te[(long)tk * d + skw_kperm(i)]) + pe[(long)ps * d + i];
 }
+// the same with the first layer's LayerNorm attached: one wave per row, x written in passing (d <= 1536)
+__global__ __launch_bounds__(256) void k_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int tk = tok[row * (int)(sizeof(SkwSeqState) / 4)], ps = pos[row * (int)(sizeof(SkwSeqState) / 4)];
+    float v[1][24], wv[24], bv[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+        const int i = lane + 64 * c; const bool in = i < d;
+        v[0][c] = in ? h2f(te[(long)tk * d + skw_kperm(i)]) + pe[(long)ps * d + i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f;
+        if (in) x[(long)row * d + i] = v[0][c];
+    }
+    const bool live[1] = {true}; half_t* const o16[1] = {y16 + (long)row * d}; float* const o32[1] = {nullptr};
+    skw_ln_rows<1>(v, wv, bv, d, lane, live, o16, o32);
+}
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_embed, dim3(B), dim3(256), 0, s, te, pe, tok, pos, d, x);
+}
+void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_embed_ln, dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
 }
 
 __device__ __forceinline__ float block_max(float v, float* sh) {
@@ -769,8 +769,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
-    if (active && !active[b * active_stride]) return;      // a finished sequence keeps its slot in the batch but no longer reads its caches (its row is never sampled again)
-    const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
+    const int act = active ? active[b * active_stride] : 1;   // (tested after the prefetches below are on their way: one round trip for all of them)
     const half_t* K = kbase + (long)b * batch_stride + h * 64;
     const half_t* V = vbase + (long)b * batch_stride + h * 64;
     // V rows of the first NPRE keys are requested before anything else waits on memory (their addresses depend on nothing that is
@@ -792,6 +791,13 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 #pragma unroll
             for (int e = 0; e < 8; ++e) qv[c8 * 8 + e] = h2f(t.h[e]); }
     }
+    // the first 64 K rows likewise: requested before n_kv has arrived (every step needs them; rows past n_kv are masked below)
+    uint4 kk0[8];
+    { const uint4* kr = (const uint4*)(K + (long)min(lane, rows_cap - 1) * ldkv);
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) kk0[c8] = kr[c8]; }
+    const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
+    if (!act) return;                                        // a finished sequence keeps its slot in the batch; its row is never sampled again
     float sc[MAXT];
     float lmax = -INFINITY;
 #pragma unroll
@@ -799,10 +805,15 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
         sc[t] = -INFINITY;
         if (t * 64 < n_kv) {   // wave-uniform
             const int key = t * 64 + lane;
-            const uint4* kr = (const uint4*)(K + (long)min(key, n_kv - 1) * ldkv);
             uint4 kk[8];
+            if (t == 0) {
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) kk[c8] = kr[c8];
+                for (int c8 = 0; c8 < 8; ++c8) kk[c8] = kk0[c8];
+            } else {
+                const uint4* kr = (const uint4*)(K + (long)min(key, n_kv - 1) * ldkv);
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) kk[c8] = kr[c8];
+            }
             float a = 0.0f;
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) { H8 t8; t8.u = kk[c8];

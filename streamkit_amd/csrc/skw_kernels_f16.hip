@@ -477,7 +477,11 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
             if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
             if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
                          v[0] = v[0] + pre_res[0]; v[1] = v[1] + pre_res[1]; v[2] = v[2] + pre_res[2]; v[3] = v[3] + pre_res[3]; }
-            *(f32x4*)((float*)a.C + (long)m * a.ldc + p0) = v;
+            float* dst = (float*)a.C + (long)m * a.ldc + p0;
+            if (a.ln_cnt) {                              // the LayerNorm tail reads these from another XCD: written through (agent scope), no L2 write-back needed later
+#pragma unroll
+                for (int r = 0; r < 4; ++r) __hip_atomic_store(dst + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else *(f32x4*)dst = v;
         }
     } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
     else if (EPI == EPI_GELU_F16_KPERM) {
@@ -495,6 +499,55 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
             half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
             *(f16x4*)dst = o;
         }
+    }
+}
+
+// LayerNorm by the last arrival.  The decode GEMMs that write the residual stream x (C f32 [M][d], one workgroup per 16-column strip)
+// are each followed by a LayerNorm of x that feeds the next GEMM: a 5 us launch for 0.2 MB of work, 37 times per step.  Instead every
+// workgroup publishes its strip (agent-scope stores), counts itself in on its row block's counter, and the one that completes the
+// block — whichever it is: the result does not depend on it — re-reads the block's rows (agent-scope loads) and writes their f16 kperm
+// LayerNorm (skw_ln_rows: the bits k_layernorm would produce).  Nobody waits on anybody: a workgroup that is not last just exits.
+template <int MT, int NW>
+__device__ __forceinline__ void gemm16_small_ln_tail(const SkwGemmArgs& a, int my0, int w, int lane) {
+    __shared__ int s_last;
+    // C went out as agent-scope (write-through) stores: once they are acknowledged every XCD can read them, so the release is a wait,
+    // not an L2 write-back (buffer_wbl2 from 192 workgroups at once cost 20 us here)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // Two levels of counters, each on its own 256-byte line: same-address atomics from different XCDs retire one every ~60 ns, so 48
+        // strips on one counter (let alone four row blocks sharing a line) would cost more than the LayerNorm launch this replaces.
+        unsigned* base = a.ln_cnt + (size_t)blockIdx.y * SKW_LN_CNT_STRIDE;
+        const unsigned grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3, gsz = min(8u, gridDim.x - 8 * grp);
+        unsigned* sub = base + 64 * (1 + grp);
+        int last = 0;
+        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gsz) {
+            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       // re-armed for the next launch on this stream
+            if (__hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == ngrp) { __hip_atomic_store(base, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the block's rows are read back with agent-scope loads (they miss any stale line this XCD's L2 holds): no cache invalidate either
+    const int d = a.N;
+    constexpr int RPW = 16 * MT / NW;                              // rows per wave
+    static_assert(RPW >= 1 && RPW % 2 == 0 || RPW == 1, "rows per wave");
+    constexpr int R = RPW >= 4 ? 4 : RPW;
+    float wv[24], bv[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; const bool in = i < d; wv[c] = in ? a.ln_w[i] : 0.0f; bv[c] = in ? a.ln_b[i] : 0.0f; }
+    for (int r0 = 0; r0 < RPW; r0 += R) {
+        float v[R][24]; bool live[R]; half_t* o16[R]; float* o32[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = my0 + w * RPW + r0 + r; live[r] = row < a.M;
+            const float* xr = (const float*)a.C + (long)(live[r] ? row : 0) * a.ldc;
+            o16[r] = a.ln_out + (long)row * d; o32[r] = nullptr;
+#pragma unroll
+            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; v[r][c] = (i < d && live[r]) ? __hip_atomic_load(xr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
+        }
+        skw_ln_rows<R>(v, wv, bv, d, lane, live, o16, o32);
     }
 }
 
@@ -562,13 +615,16 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) red[w][t][lane] = acc[t];
     __syncthreads();
-    if (w >= MT) return;
-    const int t = w;                                   // wave t finishes row tile t
-    f32x4 v = red[0][t][lane];
+    const bool ln_tail = EPI == EPI_F32 && a.ln_cnt != nullptr;      // (uniform)
+    if (w >= MT && !ln_tail) return;
+    if (w < MT) {
+        const int t = w;                                   // wave t finishes row tile t
+        f32x4 v = red[0][t][lane];
 #pragma unroll
-    for (int s = 1; s < NW; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
-    if ((a.probe & 8) && v[0] != 12345.678f) return;
-    gemm16_small_finish<EPI>(a, my0 + t * 16 + r16, n0 + 4 * g, v, pre_res, pre_po);
+        for (int s = 1; s < NW; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
+        if (!((a.probe & 8) && v[0] != 12345.678f)) gemm16_small_finish<EPI>(a, my0 + t * 16 + r16, n0 + 4 * g, v, pre_res, pre_po);
+    }
+    if (EPI == EPI_F32) { if (ln_tail) gemm16_small_ln_tail<MT, NW>(a, my0, w, lane); }
 }
 // ------------------------------------------------------------------ decode GEMM with the LayerNorm that feeds it folded in
 // C = LN(x) . W^T for a 16-row block: the workgroup normalises its 16 rows itself (wave w takes rows 4w .. 4w+3 with exactly the
