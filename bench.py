@@ -227,7 +227,9 @@ def main():
         ctx.profile(False)
         tprof = ctx.timing()
         mfma_peak = F16_MFMA_PEAK_TFLOPS if fast else F32_MFMA_PEAK_TFLOPS
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        # the dominant KERNEL: k_gemm_smallm is a class of six differently shaped decode products (none of which comes near the
+        # cross-attention on its own), so it is listed under "kernels" but does not compete here
+        dom = max(((k, v) for k, v in prof.items() if k != "k_gemm_smallm"), key=lambda kv: kv[1]["ms"])
         name, p = dom
         traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json)
         try:
@@ -246,9 +248,9 @@ def main():
             if v["bytes"]:
                 e["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
             kern[k] = e
-        if name in ("k_gemm", "k_gemm_smallm", "k_attn_encoder"):
+        if name in ("k_gemm", "k_attn_encoder"):
             ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-            pk = mfma_peak if name != "k_gemm_smallm" or fast else F32_MFMA_PEAK_TFLOPS
+            pk = mfma_peak
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4)}
         else:
             ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
