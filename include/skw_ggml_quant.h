@@ -11,10 +11,26 @@
  *   q8_0  { f16 d;           i8 qs[32]; }  x =  qs           * d
  *   element j < 16 takes the low nibble of qs[j] (+ bit j of qh), element j + 16 the high nibble (+ bit j + 16 of qh).
  *
- * DEVIATION D4: ggml multiplies quantised weights by activations it first quantises to q8 blocks (integer dot
- * products, per-block scales).  Here the weights are dequantised once (f32: q*d exact, +m one rounding), rounded to f16 (RNE) and
- * run through the f16-weight path — the transcripts of a quantised file are therefore those of its dequantised f16 twin, within
- * the quantisation noise of ggml's own result, not bit-identical to it.  Engine and oracle share this header, so they agree bitwise.
+ * Two arithmetics for a quantised file:
+ *
+ *  (a) ggml's own — the default in the exact precision.  ggml_compute_forward_mul_mat converts each f32 activation row to the weight
+ *      type's vec_dot_type (q8_0 for q4_0 / q5_0 / q8_0, q8_1 for q4_1 / q5_1: quantize_row_q8_* below) and takes per-block integer dot
+ *      products with f32 scales.  Restated from ggml-quants.c (quantize_row_q8_0_ref / q8_1_ref, ggml_vec_dot_*_generic; third-party,
+ *      NOT in /root/reference: recalled, flagged in DESIGN.md):
+ *          q8 block of 32:  amax = max |x|;  d = amax / 127;  id = d ? 1/d : 0;  qs[j] = roundf(x[j] * id);  stored d = f16(d);
+ *                           q8_1 also stores s = f16(d * sum(qs))   (the UNROUNDED d; whisper.cpp >= 1.5.5: d and s are f16)
+ *          per block b (ascending), sumi = sum_j qw[j] * qs[j] in int32, then
+ *              q4_0:          sumf += ((float)sumi * dw) * dy                     qw = nibble - 8
+ *              q5_0, q8_0:    sumf += (dw * dy) * (float)sumi                     qw = 5-bit - 16 / int8
+ *              q4_1, q5_1:    sumf += ((dw * dy) * (float)sumi + mw * sy)         qw = nibble / 5-bit, unsigned
+ *      every product and sum rounded to f32 separately (no contraction).  What cannot be restated is the SIMD build's order of the
+ *      block sums (AVX2 keeps eight partial sums): like D3 this is a chain of our choosing, block-ascending.  get_rows on the
+ *      quantised token embedding dequantises (q * d, + m) to f32 without rounding to f16.
+ *
+ *  (b) the dequantised f16 twin — what the f16_mfma precision runs, and what SKW_QUANT_TWIN=1 / quant_mode 0 selects everywhere:
+ *      weights dequantised once (f32: q*d exact, +m one rounding), rounded to f16 (RNE) and run through the f16-weight path.
+ *      Transcripts are those of the file's f16 twin, within the quantisation noise of (a), not identical to it.
+ *  Engine and oracle share this header, so they agree bitwise in either arithmetic.
  */
 #ifndef SKW_GGML_QUANT_H
 #define SKW_GGML_QUANT_H
@@ -47,6 +63,42 @@ static inline void skw_ggml_dequant_block(int type, const uint8_t* b, float* y /
             default: { float p0 = (float)x0 * d, p1 = (float)x1 * d; y[j] = p0 + m; y[j + 16] = p1 + m; }   /* q4_1, q5_1 */
         }
     }
+}
+
+/* a block in the common form the integer dot uses: 32 signed bytes qw, scale d, offset m (0 for the symmetric types) */
+static inline void skw_ggml_unpack_block(int type, const uint8_t* b, int8_t* qw /* [32] */, float* d, float* m) {
+    uint16_t dh, mh = 0; uint32_t qh = 0; const uint8_t* qs;
+    memcpy(&dh, b, 2); b += 2;
+    if (type == SKW_GGML_Q4_1 || type == SKW_GGML_Q5_1) { memcpy(&mh, b, 2); b += 2; }
+    if (type == SKW_GGML_Q5_0 || type == SKW_GGML_Q5_1) { memcpy(&qh, b, 4); b += 4; }
+    qs = b; *d = skw_f16_to_f32(dh); *m = skw_f16_to_f32(mh);
+    if (type == SKW_GGML_Q8_0) { for (int j = 0; j < 32; ++j) qw[j] = (int8_t)qs[j]; return; }
+    for (int j = 0; j < 16; ++j) {
+        int x0 = qs[j] & 0x0F, x1 = qs[j] >> 4;
+        if (type == SKW_GGML_Q5_0 || type == SKW_GGML_Q5_1) { x0 |= (int)((qh >> j) & 1u) << 4; x1 |= (int)((qh >> (j + 16)) & 1u) << 4; }
+        if (type == SKW_GGML_Q4_0) { x0 -= 8; x1 -= 8; } else if (type == SKW_GGML_Q5_0) { x0 -= 16; x1 -= 16; }
+        qw[j] = (int8_t)x0; qw[j + 16] = (int8_t)x1;
+    }
+}
+/* which of the three per-block forms above a weight type uses: 1 = q4_0, 2 = q5_0 / q8_0, 3 = q4_1 / q5_1 (q8_1 activations) */
+static inline int skw_ggml_dot_form(int type) { return type == SKW_GGML_Q4_0 ? 1 : (type == SKW_GGML_Q4_1 || type == SKW_GGML_Q5_1) ? 3 : (type == SKW_GGML_Q5_0 || type == SKW_GGML_Q8_0) ? 2 : 0; }
+/* roundf (half away from zero) without libm: exact for |x| < 2^23, and q8 arguments are within [-127, 127] */
+static inline float skw_roundf(float x) { float t = (float)(int)x; float r = x - t; if (r >= 0.5f) t += 1.0f; else if (r <= -0.5f) t -= 1.0f; return t; }
+/* quantize_row_q8_0 / q8_1 of one 32-value block: qs, d (f16-rounded, as stored), s (f16-rounded d_unrounded * sum; q8_1 only) */
+static inline void skw_ggml_quantize_q8_block(const float* x, int8_t* qs, float* d_out, float* s_out) {
+    float amax = 0.0f;
+    for (int j = 0; j < 32; ++j) { const float v = x[j] < 0.0f ? -x[j] : x[j]; if (v > amax) amax = v; }
+    const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+    int sum = 0;
+    for (int j = 0; j < 32; ++j) { const float v = x[j] * id; const int q = (int)skw_roundf(v); qs[j] = (int8_t)q; sum += q; }
+    *d_out = skw_round_f16(d); *s_out = skw_round_f16((float)sum * d);
+}
+/* one block's contribution, added to the running sum */
+static inline float skw_ggml_block_dot(int form, float sumf, int sumi, float dw, float mw, float dy, float sy) {
+    if (form == 1) { float t = (float)sumi * dw; t = t * dy; return sumf + t; }
+    float dd = dw * dy; float t = dd * (float)sumi;
+    if (form == 3) { float u = mw * sy; t = t + u; }
+    return sumf + t;
 }
 
 /* n values (a multiple of 32) from blocks to f16 bit patterns (RNE of the f32 value) */

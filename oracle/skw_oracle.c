@@ -32,7 +32,9 @@
 #define N_LANG 99
 
 /* ------------------------------------------------------------------ model */
-typedef struct { float* wt; float* b; int n_in, n_out; } lin_t; /* wt: [n_in][n_out] (transposed), b may be NULL */
+typedef struct { float* wt; float* b; int n_in, n_out;
+                 int qtype; int8_t* qw; float* qd; float* qm; /* ggml q8 arithmetic (include/skw_ggml_quant.h (a)): qw [n_out][n_in], qd / qm [n_out][n_in / 32]; NULL for f16 weights */
+} lin_t; /* wt: [n_in][n_out] (transposed), b may be NULL */
 typedef struct { float *w, *b; } ln_t;
 typedef struct { ln_t attn_ln, mlp_ln; lin_t q, k, v, o, fc1, fc2; } enc_layer_t;
 typedef struct { ln_t attn_ln, cross_ln, mlp_ln; lin_t q, k, v, o, cq, ck, cv, co, fc1, fc2; } dec_layer_t;
@@ -47,11 +49,12 @@ struct skwo_model {
     float* e_pe; lin_t conv1, conv2; ln_t ln_post; enc_layer_t* enc;
     /* decoder */
     float* d_pe; float* d_te; /* [n_vocab][d] natural layout for embedding lookup */ lin_t d_te_lin; ln_t d_ln; dec_layer_t* dec;
+    int quant;   /* ggml type of the matmul weights when the file is uniformly block-quantised and ggml's q8 arithmetic is on; 0 = f16 arithmetic */
     uint16_t* gelu_tab; float sin_vals[WHISPER_N_FFT], cos_vals[WHISPER_N_FFT], hann[WHISPER_N_FFT];
 };
 
 /* raw tensor as read from file */
-typedef struct { char name[96]; int n_dims; int ne[4]; int type; size_t n; float* data; } raw_t;
+typedef struct { char name[96]; int n_dims; int ne[4]; int type; size_t n; float* data; uint8_t* qblk; int qtype; } raw_t;   /* qblk: the file's blocks of a quantised tensor */
 
 static float* xmalloc_f(size_t n) { float* p = (float*)aligned_alloc(64, ((n * 4 + 63) / 64) * 64); if (!p) { fprintf(stderr, "oracle: oom\n"); abort(); } return p; }
 
@@ -60,6 +63,13 @@ static const char* NST_LIST[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "
     "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
 #define N_NST_LIST ((int)(sizeof(NST_LIST) / sizeof(NST_LIST[0])))
 
+/* 1 (default): a uniformly quantised file runs ggml's q8 arithmetic; 0: its dequantised f16 twin (what the f16_mfma precision of the engine runs) */
+static int g_quant_mode = 1;
+void skwo_set_quant_mode(int mode) { g_quant_mode = mode; }
+static int is_matmul_weight(const raw_t* t) {
+    const size_t L = strlen(t->name);
+    return t->n_dims == 2 && L > 7 && !strcmp(t->name + L - 7, ".weight") && !strstr(t->name, "positional_embedding") && !strstr(t->name, "ln");
+}
 static raw_t* find_t(raw_t* ts, int n, const char* name) { for (int i = 0; i < n; ++i) if (!strcmp(ts[i].name, name)) return &ts[i]; return NULL; }
 
 static int take_lin(raw_t* ts, int nt, const char* wname, const char* bname, lin_t* L, char* err, int errlen) {
@@ -77,6 +87,12 @@ static int take_lin(raw_t* ts, int nt, const char* wname, const char* bname, lin
         int kw = w->ne[0], ic = w->ne[1];
         for (int o = 0; o < n_out; ++o) for (int c = 0; c < ic; ++c) for (int t = 0; t < kw; ++t)
             L->wt[(size_t)(t * ic + c) * n_out + o] = w->data[((size_t)o * ic + c) * kw + t];
+    }
+    L->qtype = 0; L->qw = NULL; L->qd = L->qm = NULL;
+    if (w->qblk && w->qtype) {   /* ggml q8 arithmetic: keep the blocks in the common integer form */
+        const int nb = n_in / 32; const size_t bb = skw_ggml_block_bytes(w->qtype);
+        L->qtype = w->qtype; L->qw = (int8_t*)malloc((size_t)n_out * n_in); L->qd = xmalloc_f((size_t)n_out * nb); L->qm = xmalloc_f((size_t)n_out * nb);
+        for (size_t i = 0; i < (size_t)n_out * nb; ++i) skw_ggml_unpack_block(w->qtype, w->qblk + i * bb, L->qw + i * 32, &L->qd[i], &L->qm[i]);
     }
     L->b = NULL;
     if (bname) { raw_t* b = find_t(ts, nt, bname); if (!b) { snprintf(err, errlen, "missing tensor %s", bname); return -1; } L->b = b->data; b->data = NULL; }
@@ -157,16 +173,23 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
         t->name[len] = 0; t->data = xmalloc_f(t->n);
         if (tt == 0) { if (fread(t->data, 4, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } }
         else if (tt == 1) { uint16_t* h = (uint16_t*)malloc(t->n * 2); if (fread(h, 2, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } for (size_t i = 0; i < t->n; ++i) t->data[i] = skw_f16_to_f32(h[i]); free(h); }
-        else if (skw_ggml_block_bytes(tt) && t->ne[0] % 32 == 0) {   /* block-quantised: decoded here, values rounded to f16 (DEVIATION D4, include/skw_ggml_quant.h) */
-            const size_t bb = skw_ggml_block_bytes(tt), nb = t->n / 32; uint8_t* blk = (uint8_t*)malloc(nb * bb);
-            if (fread(blk, bb, nb, f) != nb) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; }
-            for (size_t i = 0; i < nb; ++i) { skw_ggml_dequant_block(tt, blk + i * bb, t->data + i * 32); for (int j = 0; j < 32; ++j) t->data[i * 32 + j] = skw_round_f16(t->data[i * 32 + j]); }
-            free(blk); t->type = 1;
+        else if (skw_ggml_block_bytes(tt) && t->ne[0] % 32 == 0) {   /* block-quantised: blocks kept, decoded once the whole file has been seen */
+            const size_t bb = skw_ggml_block_bytes(tt), nb = t->n / 32; t->qblk = (uint8_t*)malloc(nb * bb); t->qtype = tt;
+            if (fread(t->qblk, bb, nb, f) != nb) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; }
         }
         else { snprintf(err, errlen, "tensor %s: unsupported ggml type %d (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)", t->name, tt); return NULL; }
         nt++;
     }
     fclose(f);
+    /* ggml's q8 arithmetic needs every matmul weight in one block type (what whisper.cpp's quantize writes); anything else runs as the f16 twin */
+    { int qt = 0, uniform = g_quant_mode != 0;
+      for (int i = 0; i < nt; ++i) if (is_matmul_weight(&ts[i])) { if (!ts[i].qblk) uniform = 0; else if (!qt) qt = ts[i].qtype; else if (qt != ts[i].qtype) uniform = 0; }
+      m->quant = (uniform && qt) ? qt : 0;
+      for (int i = 0; i < nt; ++i) if (ts[i].qblk) {
+          raw_t* t = &ts[i]; const size_t bb = skw_ggml_block_bytes(t->qtype), nb = t->n / 32;
+          for (size_t b = 0; b < nb; ++b) { skw_ggml_dequant_block(t->qtype, t->qblk + b * bb, t->data + b * 32); if (!m->quant) for (int j = 0; j < 32; ++j) t->data[b * 32 + j] = skw_round_f16(t->data[b * 32 + j]); }
+          t->type = 1; if (!m->quant || !is_matmul_weight(t)) { free(t->qblk); t->qblk = NULL; t->qtype = 0; }
+      } }
     int rc = 0; char nmw[128], nmb[128];
     raw_t* t;
     if (!(t = find_t(ts, nt, "encoder.positional_embedding"))) { snprintf(err, errlen, "missing encoder.positional_embedding"); return NULL; } m->e_pe = t->data; t->data = NULL;
@@ -217,7 +240,7 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
 #undef NB
     }
     if (rc) return NULL;
-    for (int i = 0; i < nt; ++i) free(ts[i].data);
+    for (int i = 0; i < nt; ++i) { free(ts[i].data); free(ts[i].qblk); }
     free(ts);
     /* ggml_table_gelu_f16 */
     m->gelu_tab = (uint16_t*)malloc(65536 * 2); for (int i = 0; i < 65536; ++i) m->gelu_tab[i] = skw_gelu_table_entry((uint16_t)i);
@@ -230,7 +253,7 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
     return m;
 }
 
-static void free_lin(lin_t* L) { free(L->wt); free(L->b); }
+static void free_lin(lin_t* L) { free(L->wt); free(L->b); free(L->qw); free(L->qd); free(L->qm); }
 static void free_ln(ln_t* L) { free(L->w); free(L->b); }
 void skwo_free(skwo_model* m) {
     if (!m) return;
@@ -242,6 +265,7 @@ void skwo_free(skwo_model* m) {
     free(m->enc); free(m->dec); free(m);
 }
 void skwo_get_hparams(const skwo_model* m, skwo_hparams* out) { *out = m->hp; }
+int skwo_model_quant(const skwo_model* m) { return m->quant; }
 const char* skwo_token_str(const skwo_model* m, int id, int* len) { if (id < 0 || id >= m->hp.n_vocab) { if (len) *len = 0; return ""; } if (len) *len = m->tok_len[id]; return m->tok_str[id]; }
 void skwo_free_buf(void* p) { free(p); }
 void skwo_default_params(skwo_params* p) {
@@ -422,8 +446,36 @@ static void layer_norm(const float* x, int rows, int d, const ln_t* ln, float* y
 }
 
 /* y = round16?( A16 . W + b ) helper: A (rows x n_in, f16-valued), result rows x n_out f32 with bias */
+/* ggml's quantised mul_mat (include/skw_ggml_quant.h (a)): rows of A (f32, NOT rounded to f16) -> q8 blocks, block-ascending chain of integer dots */
+static void linear_q8(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
+    const int K = L->n_in, nb = K / 32, N = L->n_out, form = skw_ggml_dot_form(L->qtype);
+    int8_t* qa = (int8_t*)malloc((size_t)rows * K); float* da = xmalloc_f((size_t)rows * nb); float* sa = xmalloc_f((size_t)rows * nb);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) for (int b = 0; b < nb; ++b) skw_ggml_quantize_q8_block(A + (long)r * lda + b * 32, qa + ((size_t)r * nb + b) * 32, &da[(size_t)r * nb + b], &sa[(size_t)r * nb + b]);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int r = 0; r < rows; ++r) for (int n = 0; n < N; ++n) {
+        const int8_t* x = qa + (size_t)r * K; const int8_t* w = L->qw + (size_t)n * K;
+        float sumf = 0.0f;
+        for (int b = 0; b < nb; ++b) {
+            int sumi = 0; for (int j = 0; j < 32; ++j) sumi += (int)w[b * 32 + j] * (int)x[b * 32 + j];
+            sumf = skw_ggml_block_dot(form, sumf, sumi, L->qd[(size_t)n * nb + b], L->qm[(size_t)n * nb + b], da[(size_t)r * nb + b], sa[(size_t)r * nb + b]);
+        }
+        out[(long)r * ldo + n] = sumf;
+    }
+    free(qa); free(da); free(sa);
+}
+/* test hook: out [rows][n_out] = ggml's quantised mul_mat of A [rows][n_in] f32 with n_out * n_in / 32 blocks of the given type */
+int skwo_debug_linear_q8(int type, const uint8_t* blocks, int n_out, int n_in, const float* A, int rows, float* out) {
+    const size_t bb = skw_ggml_block_bytes(type); if (!bb || n_in % 32) return -1;
+    lin_t L; memset(&L, 0, sizeof L); L.n_in = n_in; L.n_out = n_out; L.qtype = type; const int nb = n_in / 32;
+    L.qw = (int8_t*)malloc((size_t)n_out * n_in); L.qd = xmalloc_f((size_t)n_out * nb); L.qm = xmalloc_f((size_t)n_out * nb);
+    for (size_t i = 0; i < (size_t)n_out * nb; ++i) skw_ggml_unpack_block(type, blocks + i * bb, L.qw + i * 32, &L.qd[i], &L.qm[i]);
+    linear_q8(A, n_in, rows, &L, out, n_out);
+    free(L.qw); free(L.qd); free(L.qm); return 0;
+}
 static void linear(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
-    gemm_chain(A, lda, rows, L->wt, L->n_out, L->n_out, L->n_in, out, ldo);
+    if (L->qw) linear_q8(A, lda, rows, L, out, ldo);
+    else gemm_chain(A, lda, rows, L->wt, L->n_out, L->n_out, L->n_in, out, ldo);
     if (L->b) {
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < rows; ++r) { float* o = out + (long)r * ldo; for (int i = 0; i < L->n_out; ++i) o[i] = o[i] + L->b[i]; }
@@ -487,7 +539,7 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
     const float KQscale = 1.0f / sqrtf((float)dh);
     for (int l = 0; l < m->hp.n_audio_layer; ++l) {
         const enc_layer_t* L = &m->enc[l];
-        layer_norm(x, n_ctx, d, &L->attn_ln, y); round_f16_inplace(y, (size_t)n_ctx * d);
+        layer_norm(x, n_ctx, d, &L->attn_ln, y); if (!m->quant) round_f16_inplace(y, (size_t)n_ctx * d);   /* mul_mat's src1: -> f16 for f16 weights, -> q8 blocks (inside linear) for quantised ones */
         if (l == 0) tap("l0.ln1", y, (size_t)n_ctx * d);
         linear(y, d, n_ctx, &L->q, q, d); linear(y, d, n_ctx, &L->k, kk, d); linear(y, d, n_ctx, &L->v, v, d);
         round_f16_inplace(q, (size_t)n_ctx * d);   /* src1 of mul_mat(K,Q) -> f16 */
@@ -507,7 +559,7 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
             gemm_chain(S, n_ctx, n_ctx, vh, dh, dh, n_ctx, oh, dh);
             if (l == 0 && g_taps_on) { static float* a32 = NULL; if (h == 0) a32 = (float*)calloc((size_t)n_ctx * d, 4); for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) a32[(size_t)i * d + h * dh + c] = oh[(size_t)i * dh + c]; if (h == nh - 1) { tap("l0.att32", a32, (size_t)n_ctx * d); free(a32); } }
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) att[(size_t)i * d + h * dh + c] = skw_round_f16(oh[(size_t)i * dh + c]);
+            for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) att[(size_t)i * d + h * dh + c] = m->quant ? oh[(size_t)i * dh + c] : skw_round_f16(oh[(size_t)i * dh + c]);
         }
         if (l == 0) tap("l0.att", att, (size_t)n_ctx * d);
         if (g_dbg_max) { tap("l0.rmax", g_dbg_max, (size_t)nh * n_ctx); tap("l0.rinv", g_dbg_inv, (size_t)nh * n_ctx); free(g_dbg_max); free(g_dbg_inv); g_dbg_max = g_dbg_inv = NULL; }
@@ -515,11 +567,11 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < (size_t)n_ctx * d; ++i) x[i] = y[i] + x[i];
         if (l == 0) tap("l0.x1", x, (size_t)n_ctx * d);
-        layer_norm(x, n_ctx, d, &L->mlp_ln, y); round_f16_inplace(y, (size_t)n_ctx * d);
+        layer_norm(x, n_ctx, d, &L->mlp_ln, y); if (!m->quant) round_f16_inplace(y, (size_t)n_ctx * d);
         if (l == 0) tap("l0.ln2", y, (size_t)n_ctx * d);
         linear(y, d, n_ctx, &L->fc1, hbuf, 4 * d);
 #pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < (size_t)n_ctx * 4 * d; ++i) hbuf[i] = skw_round_f16(skw_gelu_lookup(hbuf[i], m->gelu_tab));
+        for (size_t i = 0; i < (size_t)n_ctx * 4 * d; ++i) { const float g = skw_gelu_lookup(hbuf[i], m->gelu_tab); hbuf[i] = m->quant ? g : skw_round_f16(g); }
         if (l == 0) tap("l0.h", hbuf, (size_t)n_ctx * 4 * d);
         linear(hbuf, 4 * d, n_ctx, &L->fc2, y, d);
 #pragma omp parallel for schedule(static)
@@ -529,7 +581,7 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
     layer_norm(x, n_ctx, d, &m->ln_post, enc_out);
     if (cross_k && cross_v) { /* whisper_build_graph_cross */
         const int dtxt = m->hp.n_text_state; const float Kscale = (float)pow((double)((float)dtxt / m->hp.n_text_head), -0.25);
-        memcpy(y, enc_out, sizeof(float) * (size_t)n_ctx * d); round_f16_inplace(y, (size_t)n_ctx * d);
+        memcpy(y, enc_out, sizeof(float) * (size_t)n_ctx * d); if (!m->quant) round_f16_inplace(y, (size_t)n_ctx * d);
         for (int l = 0; l < m->hp.n_text_layer; ++l) {
             float* ck = cross_k + (size_t)l * n_ctx * dtxt; float* cv = cross_v + (size_t)l * n_ctx * dtxt;
             linear(y, d, n_ctx, &m->dec[l].ck, ck, dtxt); linear(y, d, n_ctx, &m->dec[l].cv, cv, dtxt);
@@ -570,7 +622,7 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
         const dec_layer_t* L = &m->dec[l];
         float* Kc = s->self_k + (size_t)l * ntc * d; float* Vc = s->self_v + (size_t)l * ntc * d;
         /* self-attention */
-        layer_norm(x, 1, d, &L->attn_ln, y); for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
+        layer_norm(x, 1, d, &L->attn_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
         linear(y, d, 1, &L->q, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
         linear(y, d, 1, &L->k, kv, d); for (int i = 0; i < d; ++i) Kc[(size_t)pos * d + i] = skw_round_f16(kv[i] * KQscale);
         linear(y, d, 1, &L->v, kv, d); for (int i = 0; i < d; ++i) Vc[(size_t)pos * d + i] = skw_round_f16(kv[i]);
@@ -579,11 +631,11 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
             for (int j = 0; j < n_kv; ++j) { float a = 0.0f; const float* kr = Kc + (size_t)j * d + h * dh; for (int c = 0; c < dh; ++c) a = fmaf(q[h * dh + c], kr[c], a); sc[j] = a; }
             softmax_row(sc, n_kv, 1.0f);
             for (int j = 0; j < n_kv; ++j) sc[j] = skw_round_f16(sc[j]);
-            for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < n_kv; ++j) a = fmaf(sc[j], Vc[(size_t)j * d + h * dh + c], a); att[h * dh + c] = skw_round_f16(a); }
+            for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < n_kv; ++j) a = fmaf(sc[j], Vc[(size_t)j * d + h * dh + c], a); att[h * dh + c] = m->quant ? a : skw_round_f16(a); }
         }
         linear(att, d, 1, &L->o, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
         /* cross-attention */
-        layer_norm(x, 1, d, &L->cross_ln, y); for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
+        layer_norm(x, 1, d, &L->cross_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
         linear(y, d, 1, &L->cq, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
         const float* Vx = s->cross_v + (size_t)l * nc * d;
         for (int h = 0; h < nh; ++h) {
@@ -592,17 +644,18 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
             gemm_chain(q + h * dh, d, 1, kt, nc, nc, dh, scl, nc);
             softmax_row(scl, nc, 1.0f);
             for (int j = 0; j < nc; ++j) scl[j] = skw_round_f16(scl[j]);
-            for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < nc; ++j) a = fmaf(scl[j], Vx[(size_t)j * d + h * dh + c], a); att[h * dh + c] = skw_round_f16(a); }
+            for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < nc; ++j) a = fmaf(scl[j], Vx[(size_t)j * d + h * dh + c], a); att[h * dh + c] = m->quant ? a : skw_round_f16(a); }
         }
         linear(att, d, 1, &L->co, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
         /* mlp */
-        layer_norm(x, 1, d, &L->mlp_ln, y); for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        linear(y, d, 1, &L->fc1, hb, 4 * d); for (int i = 0; i < 4 * d; ++i) hb[i] = skw_round_f16(skw_gelu_lookup(hb[i], m->gelu_tab));
+        layer_norm(x, 1, d, &L->mlp_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
+        linear(y, d, 1, &L->fc1, hb, 4 * d); for (int i = 0; i < 4 * d; ++i) { const float g = skw_gelu_lookup(hb[i], m->gelu_tab); hb[i] = m->quant ? g : skw_round_f16(g); }
         linear(hb, 4 * d, 1, &L->fc2, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
     }
     if (logits) {
-        layer_norm(x, 1, d, &m->d_ln, y); for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        gemm_chain(y, d, 1, m->d_te_lin.wt, m->d_te_lin.n_out, m->hp.n_vocab, d, logits, m->hp.n_vocab);
+        layer_norm(x, 1, d, &m->d_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
+        if (m->d_te_lin.qw) linear_q8(y, d, 1, &m->d_te_lin, logits, m->hp.n_vocab);
+        else gemm_chain(y, d, 1, m->d_te_lin.wt, m->d_te_lin.n_out, m->hp.n_vocab, d, logits, m->hp.n_vocab);
     }
 }
 int skwo_dec_step(skwo_dec* s, const int32_t* tokens, int n_tokens, int n_past, int n_threads, float* logits) {

@@ -76,7 +76,12 @@ typedef struct {
     int32_t lang_id;             /* language decoded with (detected when params.lang_id < 0) */
 } skwo_result;
 
+/* how a uniformly block-quantised file (q4_0 / q4_1 / q5_0 / q5_1 / q8_0 matmul weights) is multiplied; set BEFORE skwo_load:
+ *   1 (default) ggml's arithmetic: activations to q8 blocks, integer block dots (include/skw_ggml_quant.h (a));  0: the dequantised f16 twin */
+void skwo_set_quant_mode(int mode);
 skwo_model* skwo_load(const char* path, char* err, int errlen);
+int skwo_model_quant(const skwo_model* m);
+int skwo_debug_linear_q8(int type, const uint8_t* blocks, int n_out, int n_in, const float* A, int rows, float* out);   /* test hook: one quantised mul_mat */   /* ggml type running in q8 arithmetic, 0 if none */
 void skwo_free(skwo_model*);
 void skwo_get_hparams(const skwo_model*, skwo_hparams* out);
 const char* skwo_token_str(const skwo_model*, int id, int* len);

@@ -46,6 +46,9 @@ def lib():
         L.skwo_load.restype = C.c_void_p
         L.skwo_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.skwo_free.argtypes = [C.c_void_p]
+        L.skwo_set_quant_mode.argtypes = [C.c_int]
+        L.skwo_model_quant.argtypes = [C.c_void_p]
+        L.skwo_debug_linear_q8.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.skwo_get_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
         L.skwo_token_str.restype = C.c_void_p
         L.skwo_token_str.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -75,10 +78,14 @@ def lib():
 
 
 class OracleModel:
-    def __init__(self, path):
+    def __init__(self, path, quant_mode=1):
+        """quant_mode: 1 = ggml's q8 arithmetic for a uniformly quantised file (the exact precision of the engine), 0 = its dequantised f16 twin"""
         L = lib()
         err = C.create_string_buffer(256)
+        L.skwo_set_quant_mode(int(quant_mode))
         self.h = L.skwo_load(path.encode(), err, 256)
+        L.skwo_set_quant_mode(1)
+        self.quant = L.skwo_model_quant(self.h) if self.h else 0
         if not self.h:
             raise RuntimeError("oracle load failed: " + err.value.decode())
         self.hp = HParams()

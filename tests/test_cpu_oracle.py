@@ -3,6 +3,7 @@ committed golden vectors, and for internal consistency.  (No reference output ex
 see oracle/skw_oracle.h.)"""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -217,9 +218,101 @@ def test_quantised_ggml_is_read_as_its_dequantised_f16_twin(kind, tmp_path):
     twin = str(tmp_path / "twin.bin")
     assert dequantize_file_to_f16(qpath, twin) > 10
     pcm = synth.clip(5, 16000 * 11)
-    a = oracle_lib.OracleModel(qpath).full(pcm)
+    a = oracle_lib.OracleModel(qpath, quant_mode=0).full(pcm)
     b = oracle_lib.OracleModel(twin).full(pcm)
     assert a["tokens"] == b["tokens"] and a["segments"] == b["segments"] and len(a["tokens"]) > 0
+
+
+def _np_q8_mul_mat(kind, blocks, n_out, n_in, A):
+    """ggml's quantised mul_mat restated step by step in numpy float32 scalars (include/skw_ggml_quant.h (a)), independent of the C code."""
+    import struct
+    f1 = np.float32
+    bb = {"q4_0": 18, "q4_1": 20, "q5_0": 22, "q5_1": 24, "q8_0": 34}[kind]
+    nb = n_in // 32
+    raw = np.frombuffer(blocks, np.uint8).reshape(n_out * nb, bb)
+    qw = np.zeros((n_out * nb, 32), np.int32); dw = np.zeros(n_out * nb, np.float32); mw = np.zeros(n_out * nb, np.float32)
+    for i, b in enumerate(raw):
+        o = 0
+        dw[i] = np.frombuffer(b[o:o + 2].tobytes(), np.float16)[0]; o += 2
+        if kind in ("q4_1", "q5_1"):
+            mw[i] = np.frombuffer(b[o:o + 2].tobytes(), np.float16)[0]; o += 2
+        qh = 0
+        if kind in ("q5_0", "q5_1"):
+            qh = struct.unpack("<I", b[o:o + 4].tobytes())[0]; o += 4
+        qs = b[o:]
+        if kind == "q8_0":
+            qw[i] = qs.view(np.int8)
+            continue
+        for j in range(16):
+            x0, x1 = int(qs[j]) & 15, int(qs[j]) >> 4
+            if kind in ("q5_0", "q5_1"):
+                x0 |= ((qh >> j) & 1) << 4; x1 |= ((qh >> (j + 16)) & 1) << 4
+            off = 8 if kind == "q4_0" else 16 if kind == "q5_0" else 0
+            qw[i, j], qw[i, j + 16] = x0 - off, x1 - off
+    rows = A.shape[0]
+    out = np.zeros((rows, n_out), np.float32)
+    for r in range(rows):
+        qa = np.zeros((nb, 32), np.int32); da = np.zeros(nb, np.float32); sa = np.zeros(nb, np.float32)
+        for b in range(nb):
+            x = A[r, b * 32:(b + 1) * 32]
+            amax = f1(np.abs(x).max()); d = f1(amax / f1(127)); idv = f1(f1(1) / d) if d != 0 else f1(0)
+            v = (x * idv).astype(np.float32).astype(np.float64)
+            q = (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int32)          # roundf: half away from zero (exact in f64)
+            qa[b] = q; da[b] = f1(np.float16(d)); sa[b] = f1(np.float16(f1(f1(int(q.sum())) * d)))
+        for n in range(n_out):
+            sumf = f1(0)
+            for b in range(nb):
+                i = n * nb + b; sumi = int((qw[i] * qa[b]).sum())
+                if kind == "q4_0":
+                    t = f1(f1(f1(sumi) * dw[i]) * da[b])
+                else:
+                    t = f1(f1(dw[i] * da[b]) * f1(sumi))
+                    if kind in ("q4_1", "q5_1"):
+                        t = f1(t + f1(mw[i] * sa[b]))
+                sumf = f1(sumf + t)
+            out[r, n] = sumf
+    return out
+
+
+@pytest.mark.parametrize("kind", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_ggml_q8_mul_mat_matches_numpy_restatement(kind):
+    """The oracle's quantised mul_mat (activation rows -> q8_0 / q8_1 blocks, integer block dots, f32 scales, block-ascending sum)
+    against a numpy restatement written from the same description: bit-identical, including rows with zero blocks and ties in roundf."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(oracle_lib.ROOT, "tools"))
+    from quantize_ggml import quantize_blocks, TYPES
+    rng = np.random.default_rng(7)
+    n_out, n_in, rows = 6, 96, 4
+    W = (rng.standard_normal((n_out, n_in)) * 0.3).astype(np.float32)
+    blocks = quantize_blocks(W.reshape(-1, 32), kind)
+    A = (rng.standard_normal((rows, n_in)) * 2.0).astype(np.float32)
+    A[1, 32:64] = 0.0                                              # a block of zeros: d = 0, id = 0
+    A[2, :32] = np.linspace(-127, 127, 32, dtype=np.float32) * 0.5   # amax = 63.5 -> id = 2: values land on .5 (roundf ties, away from zero)
+    out = np.zeros((rows, n_out), np.float32)
+    buf = (C.c_uint8 * len(blocks)).from_buffer_copy(blocks)
+    assert oracle_lib.lib().skwo_debug_linear_q8(TYPES[kind], buf, n_out, n_in, A.ctypes.data, rows, out.ctypes.data) == 0
+    want = _np_q8_mul_mat(kind, blocks, n_out, n_in, A)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    ref = A @ W.T                                                  # and it is a sensible approximation of the real product
+    assert np.abs(out - ref).max() < 0.12 * np.abs(ref).max() + 0.5
+
+
+@pytest.mark.parametrize("kind", ["q5_1", "q8_0"])
+def test_quantised_file_runs_ggml_q8_arithmetic_by_default(kind):
+    """A uniformly quantised file is multiplied the way ggml does it (q8 activation blocks) unless the f16 twin is asked for; the two
+    arithmetics are different computations (logits differ) of nearly the same function."""
+    from conftest import quantized_model
+    qpath = quantized_model("micro", kind)
+    q8 = oracle_lib.OracleModel(qpath)
+    tw = oracle_lib.OracleModel(qpath, quant_mode=0)
+    assert q8.quant == {"q5_1": 7, "q8_0": 8}[kind] and tw.quant == 0
+    pcm = synth.clip(5, 16000 * 11)
+    a, b = q8.full(pcm), tw.full(pcm)
+    assert len(a["tokens"]) > 0 and len(b["tokens"]) > 0
+    la = q8.decode_logits(pcm, [q8.sot()]) if hasattr(q8, "decode_logits") else None
+    if la is not None:
+        lb = tw.decode_logits(pcm, [tw.sot()])
+        assert not np.array_equal(la, lb) and np.abs(la - lb).max() < 0.25 * np.abs(lb).max()
 
 
 def test_language_auto_detect_is_consistent_in_oracle(micro_model_path):
