@@ -95,6 +95,9 @@ __device__ __forceinline__ void epi_store(const SkwGemmArgs& a, int m, int n, fl
         if (a.bias) v = v + a.bias[n];
         float g = gelu_dev(v, a.gelu_tab);
         ((float*)a.C)[(long)m * a.ldc + n] = a.pe[(long)(m % a.n_ctx) * a.N + n] + g;
+    } else if (EPI == EPI_GELU_F32) {
+        if (a.bias) v = v + a.bias[n];
+        ((float*)a.C)[(long)m * a.ldc + n] = gelu_dev(v, a.gelu_tab);
     } else if (EPI == EPI_HEADS_F16) {
         if (a.bias) v = v + a.bias[n];
         if (a.has_scale) v = v * a.scale;

@@ -25,6 +25,7 @@ enum SkwEpi : int {
     EPI_VT_F16 = 5,     // swapped call (m = feature, n = token): C f16 [(b*H+h)*64 + c][kperm(key)] (row stride Tpad); f16(acc + bias[m])
     EPI_F16_PLAIN = 6,  // C f16 [m][n] = f16((acc + bias[n]) * scale)   (decoder K/V caches, cross K/V)
     EPI_DEC_QKV = 8,    // fused decoder q|k|v: see epilogue (C = q plain, C2/C3 = K/V cache rows, n_ctx = d)
+    EPI_GELU_F32 = 9,   // C f32 [m][n] = gelu(acc + bias[n]), not rounded (feeds ggml's q8 activation quantiser: skw_kernels_q8.hip)
     EPI_GELU_F16_KPERM_ROWPAD = 7, // conv1: like 2 but row index remapped m -> (m / T) * (T + 2) + (m % T) + 1 (one zero row of padding per clip side)
 };
 
@@ -81,6 +82,12 @@ void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, cons
 // ---------------- decoder ----------------
 // x[b][d] = f32(te[tok[b]][kperm(i)]) + pe[pos[b]][i]
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
+// ggml's arithmetic for block-quantised files (skw_kernels_q8.hip)
+struct SkwQ8Args { const int8_t* qa; const float* dyT; const float* syT;        // activations: int8 [M][K], scales [K/32][M]
+                   const int8_t* qw; const float* dwT; const float* mwT; int n_pad; int form; };   // weights: int8 [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
+void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s);
+bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s);
+void skw_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
 void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s);
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]

@@ -1,0 +1,130 @@
+// skw_kernels_q8.hip — ggml's arithmetic for block-quantised model files (q4_0 / q4_1 / q5_0 / q5_1 / q8_0), exact precision.
+//
+// whisper.cpp multiplies a quantised weight matrix by f32 activations the way ggml_compute_forward_mul_mat does it: every activation
+// row is quantised to q8_0 / q8_1 blocks of 32 (vec_dot_type of the weight type), and each output is a block-ascending sum of
+// integer block dots times f32 scales (include/skw_ggml_quant.h (a) states the operations; oracle/skw_oracle.c linear_q8 is the CPU
+// restatement these kernels are bit-identical to).  The reference's DEFAULT model is a q5_1 file
+// (/root/reference/plugins/native/whisper/src/lib.rs:114-116), so this is the arithmetic its default configuration runs.
+//
+//   k_q8_quantize   f32 rows -> int8 values [M][K] + per-block d (f16-rounded) and s = f16(d_unrounded * sum q), stored [K/32][M]
+//   k_gemm_q8<EPI>  64 x 64 output tile per workgroup, four waves of 32 x 32; per 32-block one v_mfma_i32_16x16x32_i8 per 16 x 16
+//                   sub-tile gives the sixteen-by-sixteen integer dots, the block's scales come in as 16-byte loads from the
+//                   transposed scale tables, and the f32 update of skw_ggml_block_dot runs on the VALU (the path is VALU-bound: ~10
+//                   f32 operations per integer dot of 32, which is why it is ~3x the f16 MFMA path and still 2x faster than the f32 chains)
+// The weights are the MFMA's first operand as everywhere else: a lane ends with four adjacent features of one row.
+#include <hip/hip_runtime.h>
+#include "skw_dev_common.h"
+#include "../../include/skw_ggml_quant.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// one thread per block of 32 (operation for operation skw_ggml_quantize_q8_block)
+__global__ __launch_bounds__(256) void k_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT) {
+    const int nb = K >> 5;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)M * nb) return;
+    const int m = (int)(id / nb), b = (int)(id % nb);
+    const f32x4* xp = (const f32x4*)(x + (long)m * ldx + b * 32);
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const f32x4 t = xp[j]; v[4 * j] = t[0]; v[4 * j + 1] = t[1]; v[4 * j + 2] = t[2]; v[4 * j + 3] = t[3]; }
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const float a = v[j] < 0.0f ? -v[j] : v[j]; if (a > amax) amax = a; }
+    const float d = amax / 127.0f, idv = d != 0.0f ? 1.0f / d : 0.0f;
+    int sum = 0; union { int8_t b[32]; u32x4 w[2]; } o;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const float t = v[j] * idv; const int qi = (int)skw_roundf(t); o.b[j] = (int8_t)qi; sum += qi; }
+    u32x4* qp = (u32x4*)(q + (long)m * K + b * 32); qp[0] = o.w[0]; qp[1] = o.w[1];
+    dT[(long)b * M + m] = skw_round_f16(d);
+    sT[(long)b * M + m] = skw_round_f16((float)sum * d);
+}
+void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s) {
+    const long n = (long)M * (K >> 5);
+    hipLaunchKernelGGL(k_q8_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, M, K, q, dT, sT);
+}
+
+template <int EPI>
+__device__ __forceinline__ void q8_store(const SkwGemmArgs& a, int m, int n, float v) {
+    if (EPI == EPI_VT_F16) epi_store<EPI_VT_F16>(a, n, m, v);          // (that epilogue names the feature first: it was written for the operand-swapped call)
+    else epi_store<EPI>(a, m, n, v);
+}
+
+// C = epilogue(A_q8 . W_q^T): A int8 [M][K] with dyT / syT [K/32][M]; W int8 [N][K] with dwT / mwT [K/32][n_pad] (n_pad = N rounded up to 64)
+template <int EPI, int FORM>
+__global__ __launch_bounds__(256) void k_gemm_q8(SkwGemmArgs a, SkwQ8Args qa) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 64 + (w >> 1) * 32, n0 = blockIdx.x * 64 + (w & 1) * 32;
+    const int nb = a.K >> 5;
+    // operand rows (clamped: rows past the edge compute on a copy and are never stored)
+    const int8_t* wp[2]; const int8_t* ap[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        wp[t] = qa.qw + (long)min(n0 + t * 16 + r16, a.N - 1) * a.K + g * 8;
+        ap[t] = qa.qa + (long)min(m0 + t * 16 + r16, a.M - 1) * a.K + g * 8;
+    }
+    const int mrow[2] = {min(m0 + r16, a.M - 1), min(m0 + 16 + r16, a.M - 1)};
+    float sumf[2][2][4];                                  // [n tile][m tile][feature 4g + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sumf[i][j][r] = 0.0f;
+    for (int b = 0; b < nb; ++b) {
+        long fw[2], fa[2]; f32x4 dw[2], mw[2]; float dy[2], sy[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fw[t] = *(const long*)(wp[t] + b * 32); fa[t] = *(const long*)(ap[t] + b * 32);
+            dw[t] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + n0 + t * 16 + 4 * g);
+            if (FORM == 3) mw[t] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + n0 + t * 16 + 4 * g);
+            dy[t] = qa.dyT[(long)b * a.M + mrow[t]];
+            if (FORM == 3) sy[t] = qa.syT[(long)b * a.M + mrow[t]];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[i], fa[j], (i32x4){0, 0, 0, 0}, 0, 0, 0);     // D[n = 4g + r][m = r16]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sumf[i][j][r] = skw_ggml_block_dot(FORM, sumf[i][j][r], si[r], dw[i][r], FORM == 3 ? mw[i][r] : 0.0f, dy[j], FORM == 3 ? sy[j] : 0.0f);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + j * 16 + r16;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int n = n0 + i * 16 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[i][j][r]); }
+        }
+}
+template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
+    const dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+    if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1>), grid, dim3(256), 0, s, a, qa);
+    else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2>), grid, dim3(256), 0, s, a, qa);
+    else hipLaunchKernelGGL((k_gemm_q8<EPI, 3>), grid, dim3(256), 0, s, a, qa);
+}
+bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
+    if ((a.K & 31) || qa.form < 1 || qa.form > 3) return false;
+    switch (a.epi) {
+        case EPI_F32: launch_gemm_q8<EPI_F32>(a, qa, s); return true;
+        case EPI_GELU_F32: launch_gemm_q8<EPI_GELU_F32>(a, qa, s); return true;
+        case EPI_HEADS_F16: launch_gemm_q8<EPI_HEADS_F16>(a, qa, s); return true;
+        case EPI_VT_F16: launch_gemm_q8<EPI_VT_F16>(a, qa, s); return true;
+        case EPI_F16_PLAIN: launch_gemm_q8<EPI_F16_PLAIN>(a, qa, s); return true;
+        case EPI_DEC_QKV: launch_gemm_q8<EPI_DEC_QKV>(a, qa, s); return true;
+        default: return false;
+    }
+}
+
+// token + position embedding from the dequantised (f32, not f16-rounded) token embedding: ggml_get_rows on a quantised tensor
+__global__ void k_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int d, float* x) {
+    const int b = blockIdx.x; const int tk = tok[b * (int)(sizeof(SkwSeqState) / 4)]; const int ps = pos[b * (int)(sizeof(SkwSeqState) / 4)];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(long)b * d + i] = te32[(long)tk * d + i] + pe[(long)ps * d + i];
+}
+void skw_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_embed_f32, dim3(B), dim3(256), 0, s, te32, pe, tok, pos, d, x);
+}
