@@ -80,6 +80,15 @@ typedef struct {
 /* ---- lifetime ---- */
 int  skw_device_count(void);
 skw_model* skw_model_load(const char* ggml_path, int device, char* err, size_t errlen);
+/* Block-quantised files (q4_0 / q4_1 / q5_0 / q5_1 / q8_0; the reference's default model is a q5_1 file, lib.rs:114-116):
+ *   SKW_QUANT_GGML (default)  a context in the exact precision multiplies the way ggml does — activation rows to q8_0 / q8_1 blocks,
+ *                             integer block dots, f32 scales (include/skw_ggml_quant.h (a)); a context in the f16_mfma precision runs the
+ *                             file's dequantised f16 twin (both representations are resident)
+ *   SKW_QUANT_F16_TWIN        the twin in both precisions (round-1 behaviour; also forced by the environment variable SKW_QUANT_TWIN)
+ * skw_model_quant_type: the ggml tensor type running in ggml's arithmetic (2, 3, 6, 7, 8), or 0. */
+enum { SKW_QUANT_F16_TWIN = 0, SKW_QUANT_GGML = 1 };
+skw_model* skw_model_load_ex(const char* ggml_path, int device, int quant_mode, char* err, size_t errlen);
+int skw_model_quant_type(const skw_model* m);
 void skw_model_free(skw_model*);
 void skw_model_get_hparams(const skw_model*, skw_hparams* out);
 const char* skw_model_token_text(const skw_model*, int id, int* len);

@@ -81,11 +81,11 @@ static inline void skw_ggml_unpack_block(int type, const uint8_t* b, int8_t* qw 
     }
 }
 /* which of the three per-block forms above a weight type uses: 1 = q4_0, 2 = q5_0 / q8_0, 3 = q4_1 / q5_1 (q8_1 activations) */
-static inline int skw_ggml_dot_form(int type) { return type == SKW_GGML_Q4_0 ? 1 : (type == SKW_GGML_Q4_1 || type == SKW_GGML_Q5_1) ? 3 : (type == SKW_GGML_Q5_0 || type == SKW_GGML_Q8_0) ? 2 : 0; }
+SKW_HD int skw_ggml_dot_form(int type) { return type == SKW_GGML_Q4_0 ? 1 : (type == SKW_GGML_Q4_1 || type == SKW_GGML_Q5_1) ? 3 : (type == SKW_GGML_Q5_0 || type == SKW_GGML_Q8_0) ? 2 : 0; }
 /* roundf (half away from zero) without libm: exact for |x| < 2^23, and q8 arguments are within [-127, 127] */
-static inline float skw_roundf(float x) { float t = (float)(int)x; float r = x - t; if (r >= 0.5f) t += 1.0f; else if (r <= -0.5f) t -= 1.0f; return t; }
+SKW_HD float skw_roundf(float x) { float t = (float)(int)x; float r = x - t; if (r >= 0.5f) t += 1.0f; else if (r <= -0.5f) t -= 1.0f; return t; }
 /* quantize_row_q8_0 / q8_1 of one 32-value block: qs, d (f16-rounded, as stored), s (f16-rounded d_unrounded * sum; q8_1 only) */
-static inline void skw_ggml_quantize_q8_block(const float* x, int8_t* qs, float* d_out, float* s_out) {
+SKW_HD void skw_ggml_quantize_q8_block(const float* x, int8_t* qs, float* d_out, float* s_out) {
     float amax = 0.0f;
     for (int j = 0; j < 32; ++j) { const float v = x[j] < 0.0f ? -x[j] : x[j]; if (v > amax) amax = v; }
     const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
@@ -94,7 +94,7 @@ static inline void skw_ggml_quantize_q8_block(const float* x, int8_t* qs, float*
     *d_out = skw_round_f16(d); *s_out = skw_round_f16((float)sum * d);
 }
 /* one block's contribution, added to the running sum */
-static inline float skw_ggml_block_dot(int form, float sumf, int sumi, float dw, float mw, float dy, float sy) {
+SKW_HD float skw_ggml_block_dot(int form, float sumf, int sumi, float dw, float mw, float dy, float sy) {
     if (form == 1) { float t = (float)sumi * dw; t = t * dy; return sumf + t; }
     float dd = dw * dy; float t = dd * (float)sumi;
     if (form == 3) { float u = mw * sy; t = t + u; }

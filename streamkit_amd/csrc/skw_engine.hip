@@ -49,12 +49,15 @@ static void set_err(char* err, size_t n, const char* fmt, ...) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(errbuf, 512, "HIP error '%s' at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
-struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0; };
+struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0;
+                // ggml's arithmetic for a block-quantised weight (skw_kernels_q8.hip): int8 [n_out][n_in], scales / offsets [n_in / 32][n_pad]; null for f16 weights
+                int8_t* qw = nullptr; float* dwT = nullptr; float* mwT = nullptr; int n_pad = 0, qform = 0; };
+struct HostQ { std::vector<int8_t> q; std::vector<float> d, m; int n_out = 0, K = 0; };      // a quantised weight in the common integer form, host side
 struct DevLN { float* w = nullptr; float* b = nullptr; };
 struct EncLayer { DevLN attn_ln, mlp_ln; DevLin q, k, v, o, fc1, fc2; };
 struct DecLayer { DevLN attn_ln, cross_ln, mlp_ln; DevLin q, k, v, o, cq, ck, cv, co, fc1, fc2; DevLin qkv; /* q|k|v rows concatenated for the fused decode projection */ };
 
-struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; };
+struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; std::vector<uint8_t> qblk; int qtype = 0; };   // qblk: the file's blocks of a quantised tensor (data: its f16 twin)
 
 struct skw_model {
     skw_hparams hp{};
@@ -67,6 +70,8 @@ struct skw_model {
     uint16_t* gelu_tab = nullptr;
     float* e_pe = nullptr; DevLin conv1, conv2; DevLN ln_post; std::vector<EncLayer> enc;
     float* d_pe = nullptr; DevLin te; DevLN d_ln; std::vector<DecLayer> dec;
+    int quant = 0;             // ggml type of the matmul weights when the file is uniformly block-quantised and ggml's q8 arithmetic is available (exact precision runs it)
+    float* te32 = nullptr;     // quant: the token embedding dequantised to f32 [n_vocab][d] (get_rows does not round to f16)
     std::vector<void*> allocs;
 };
 
@@ -79,6 +84,24 @@ static RawT* find_t(std::vector<RawT>& ts, const std::string& name) { for (auto&
 static const float* as_f32(RawT* t, std::vector<float>& tmp) {
     if (t->type == 0) return (const float*)t->data.data();
     tmp.resize(t->n); const uint16_t* h = (const uint16_t*)t->data.data(); for (size_t i = 0; i < t->n; ++i) tmp[i] = skw_f16_to_f32(h[i]); return tmp.data();
+}
+static bool is_matmul_weight(const RawT& t) {
+    const std::string& n = t.name;
+    return t.n_dims == 2 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0 && n.find("positional_embedding") == std::string::npos && n.find("ln") == std::string::npos;
+}
+static void host_q(const RawT& w, HostQ* h) {
+    const int K = w.ne[0], n_out = w.ne[1], nb = K / 32; const size_t bb = skw_ggml_block_bytes(w.qtype);
+    h->n_out = n_out; h->K = K; h->q.resize((size_t)n_out * K); h->d.resize((size_t)n_out * nb); h->m.resize((size_t)n_out * nb);
+    for (size_t i = 0; i < (size_t)n_out * nb; ++i) skw_ggml_unpack_block(w.qtype, w.qblk.data() + i * bb, h->q.data() + i * 32, &h->d[i], &h->m[i]);
+}
+// int8 rows as they are; scales and offsets transposed to [block][n_pad] so that a lane's four adjacent features are one 16-byte load
+static bool up_q(skw_model* m, const HostQ& h, int qtype, DevLin* L) {
+    const int nb = h.K / 32, n_pad = (h.n_out + 63) & ~63;
+    std::vector<float> dT((size_t)nb * n_pad, 0.0f), mT((size_t)nb * n_pad, 0.0f);
+    for (int n = 0; n < h.n_out; ++n) for (int b = 0; b < nb; ++b) { dT[(size_t)b * n_pad + n] = h.d[(size_t)n * nb + b]; mT[(size_t)b * n_pad + n] = h.m[(size_t)n * nb + b]; }
+    L->qw = dev_upload(m, h.q.data(), h.q.size()); L->dwT = dev_upload(m, dT.data(), dT.size()); L->mwT = dev_upload(m, mT.data(), mT.size());
+    L->n_pad = n_pad; L->qform = skw_ggml_dot_form(qtype);
+    return L->qw && L->dwT && L->mwT;
 }
 // f16 weight [n_out][n_in] (or conv [oc][ic][kw]) -> device [n_out][k_pad] with the contraction axis in kperm order
 static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname, const char* bname, DevLin* L, char* err, size_t errlen) {
@@ -100,6 +123,7 @@ static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname
     L->n_in = n_in; L->n_out = n_out; L->k_pad = k_pad;
     L->w = (half_t*)dev_upload(m, h.data(), h.size());
     if (!L->w) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; }
+    if (m->quant && !w->qblk.empty()) { HostQ h; host_q(*w, &h); if (!up_q(m, h, w->qtype, L)) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
     L->b = nullptr;
     if (bname) {
         RawT* b = find_t(ts, bname);
@@ -122,12 +146,14 @@ extern "C" int skw_model_lang_id(const char* lang) {
     return -1;
 }
 
-static skw_model* model_load_impl(const char* path, int device, char* err, size_t errlen);
-extern "C" skw_model* skw_model_load(const char* path, int device, char* err, size_t errlen) {
-    try { return model_load_impl(path, device, err, errlen); }
+static skw_model* model_load_impl(const char* path, int device, int quant_mode, char* err, size_t errlen);
+extern "C" skw_model* skw_model_load_ex(const char* path, int device, int quant_mode, char* err, size_t errlen) {
+    try { return model_load_impl(path, device, quant_mode, err, errlen); }
     catch (const std::exception& e) { set_err(err, errlen, "Failed to load Whisper model from '%s': %s", path ? path : "", e.what()); return nullptr; }   // nothing may unwind across the C ABI
 }
-static skw_model* model_load_impl(const char* path, int device, char* err, size_t errlen) {
+extern "C" skw_model* skw_model_load(const char* path, int device, char* err, size_t errlen) { return skw_model_load_ex(path, device, SKW_QUANT_GGML, err, errlen); }
+extern "C" int skw_model_quant_type(const skw_model* m) { return m->quant; }
+static skw_model* model_load_impl(const char* path, int device, int quant_mode, char* err, size_t errlen) {
     int ndev = skw_device_count();
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: libskw_engine requires an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", device, ndev); return nullptr; }
@@ -204,13 +230,18 @@ static skw_model* model_load_impl(const char* path, int device, char* err, size_
             const size_t bb = skw_ggml_block_bytes(tt);
             if (!bb || t.ne[0] % 32) { std::string msg = "tensor " + t.name + ": unsupported ggml type " + std::to_string(tt) + " (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)"; return fail(msg.c_str()); }
             std::vector<uint8_t> blocks(t.n / 32 * bb); if (fread(blocks.data(), 1, blocks.size(), f) != blocks.size()) return fail("short tensor data");
-            t.data.resize(t.n * 2); skw_ggml_dequant_to_f16(tt, blocks.data(), t.n, (uint16_t*)t.data.data()); t.type = 1;
+            t.data.resize(t.n * 2); skw_ggml_dequant_to_f16(tt, blocks.data(), t.n, (uint16_t*)t.data.data()); t.type = 1; t.qtype = tt; t.qblk = std::move(blocks);
             ts.push_back(std::move(t)); continue;
         }
         t.data.resize(t.n * esz); if (fread(t.data.data(), 1, t.data.size(), f) != t.data.size()) return fail("short tensor data");
         ts.push_back(std::move(t));
     }
     fclose(f); f = nullptr;
+    {   // ggml's q8 arithmetic needs every matmul weight in one block type (what whisper.cpp's quantize writes); anything else runs as the f16 twin
+        int qt = 0; bool uniform = quant_mode != 0 && !getenv("SKW_QUANT_TWIN");
+        for (auto& t : ts) if (is_matmul_weight(t)) { if (t.qblk.empty()) uniform = false; else if (!qt) qt = t.qtype; else if (qt != t.qtype) uniform = false; }
+        m->quant = (uniform && qt) ? qt : 0;
+    }
     auto fail2 = [&]() -> skw_model* { skw_model_free(m); return nullptr; };
     // tables
     m->filters = dev_upload(m, filt.data(), filt.size());
@@ -249,6 +280,11 @@ static skw_model* model_load_impl(const char* path, int device, char* err, size_
         ok = ok && up_lin(m, ts, p + "mlp.2.weight", (p + "mlp.2.bias").c_str(), &L.fc2, err, errlen);
     }
     ok = ok && up_lin(m, ts, "decoder.token_embedding.weight", nullptr, &m->te, err, errlen);
+    if (ok && m->quant) {   // get_rows on the quantised token embedding: q * d (+ m) in f32, not rounded to f16
+        RawT* te = find_t(ts, "decoder.token_embedding.weight"); const size_t bb = skw_ggml_block_bytes(te->qtype); std::vector<float> e32(te->n);
+        for (size_t i = 0; i < te->n / 32; ++i) skw_ggml_dequant_block(te->qtype, te->qblk.data() + i * bb, e32.data() + i * 32);
+        m->te32 = dev_upload(m, e32.data(), e32.size()); ok = m->te32 != nullptr;
+    }
     ok = ok && up_ln(m, ts, "decoder.ln.weight", "decoder.ln.bias", &m->d_ln, err, errlen);
     m->dec.resize(m->hp.n_text_layer);
     for (int l = 0; l < m->hp.n_text_layer && ok; ++l) {
@@ -275,6 +311,12 @@ static skw_model* model_load_impl(const char* path, int device, char* err, size_
                 hipMemcpy(w, L.q.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)d * kp, L.k.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)2 * d * kp, L.v.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
                 hipMemset(b, 0, (size_t)3 * d * 4); hipMemcpy(b, L.q.b, (size_t)d * 4, hipMemcpyDeviceToDevice); hipMemcpy(b + 2 * d, L.v.b, (size_t)d * 4, hipMemcpyDeviceToDevice);
                 L.qkv.w = w; L.qkv.b = b;
+            }
+            if (ok && m->quant) {   // the same concatenation in the integer form
+                HostQ hq, hk, hv, all; host_q(*find_t(ts, p + "attn.query.weight"), &hq); host_q(*find_t(ts, p + "attn.key.weight"), &hk); host_q(*find_t(ts, p + "attn.value.weight"), &hv);
+                all.n_out = 3 * d; all.K = hq.K;
+                for (const HostQ* h : {&hq, &hk, &hv}) { all.q.insert(all.q.end(), h->q.begin(), h->q.end()); all.d.insert(all.d.end(), h->d.begin(), h->d.end()); all.m.insert(all.m.end(), h->m.begin(), h->m.end()); }
+                ok = up_q(m, all, m->quant, &L.qkv);
             }
         }
     }
@@ -316,7 +358,8 @@ struct skw_ctx {
     float* x = nullptr; half_t* y16 = nullptr; half_t *Qh = nullptr, *Kh = nullptr, *Vt = nullptr; half_t* hbuf = nullptr; float* enc_out32 = nullptr;
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
-    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; unsigned* ln_cnt = nullptr;   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
+    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr; int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;   // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
+    unsigned* ln_cnt = nullptr;   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
@@ -368,6 +411,12 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
+    if (m->quant) {
+        const int kmax = 4 * std::max(d, dt); const size_t rows = (size_t)B * nc; c->q8_kmax = kmax;
+        WS(y32, float, rows * d, false); WS(h32, float, rows * 4 * d, false); WS(encq32, float, rows * d, false);
+        WS(dy32, float, (size_t)B * dt, false); WS(datt32, float, (size_t)B * dt, false); WS(dh32, float, (size_t)B * 4 * dt, false);
+        WS(q8_a, int8_t, rows * kmax, false); WS(q8_d, float, rows * (kmax / 32), false); WS(q8_s, float, rows * (kmax / 32), false);
+    }
     c->max_tok = hp.n_text_ctx / 2;
     WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
 #undef WS
@@ -483,6 +532,20 @@ static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, 
     GEMM_S(c, a, a.K);
 }
 
+// ---- ggml's arithmetic for quantised files (skw_kernels_q8.hip): quantise the f32 rows once, then any number of products with them
+static bool use_q8(const skw_ctx* c) { return c->m->quant != 0 && c->precision == SKW_PRECISION_EXACT; }
+static void Q8_ROWS(skw_ctx* c, const float* act32, long lda, int M, int K, int r0) {
+    ProfScope p(c, PC_LAYERNORM, 0, 5.0 * M * K);
+    skw_q8_quantize(act32, lda, M, K, c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), c->cur);
+}
+static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0) {
+    a.K = L.n_in; a.N = L.n_out; a.bias = L.b;
+    SkwQ8Args qa{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), L.qw, L.dwT, L.mwT, L.n_pad, L.qform};
+    ProfScope p(c, a.M <= 64 ? PC_GEMM_SMALL : PC_GEMM, 2.0 * a.M * a.N * a.K, 1.0 * a.M * a.K + 1.0 * a.N * a.K + 4.0 * a.M * a.N);
+    skw_gemm_q8(a, qa, c->cur);
+}
+static SkwGemmArgs q8_args(int M, void* C, long ldc, int epi) { SkwGemmArgs a{}; a.M = M; a.C = C; a.ldc = ldc; a.epi = epi; a.scale = 1.0f; return a; }
+
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
     SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
 }
@@ -506,6 +569,42 @@ static void run_conv(skw_ctx* c, int Bw) {
 // encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
 static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, M = Bw * nc;
+    if (use_q8(c)) {
+        // Quantised file, exact precision: every weight product is ggml's (rows -> q8 blocks, integer block dots), so what feeds a
+        // projection stays f32 and unrounded — LayerNorm, attention and GELU write f32 here — and only the attention operands
+        // (Q, K, V^T: ggml casts those to f16 itself) are f16 as before.  The conv stem's kernels are 3-D tensors: never quantised.
+        for (int l = 0; l < hp.n_audio_layer; ++l) {
+            const EncLayer& L = m->enc[l];
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, nullptr, c->y32, c->stream); }
+            Q8_ROWS(c, c->y32, d, M, d, 0);
+            { SkwGemmArgs a = q8_args(M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.q, 0); }
+            { SkwGemmArgs a = q8_args(M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.k, 0); }
+            { SkwGemmArgs a = q8_args(M, c->Vt, 0, EPI_VT_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.v, 0); }
+            { ProfScope p_(c, PC_ATTN_ENC, 4.0 * Bw * H * (double)nc * nc * 64, 2.0 * 4 * M * d);
+              skw_attn_encoder(c->Qh, c->Kh, c->Vt, (half_t*)c->y32, d, Bw, H, nc, c->Tpad, c->stream, nullptr, nullptr, 1); }
+            Q8_ROWS(c, c->y32, d, M, d, 0);
+            { SkwGemmArgs a = q8_args(M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; Q8_GEMM(c, a, L.o, 0); }
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.mlp_ln.w, L.mlp_ln.b, nullptr, c->y32, c->stream); }
+            Q8_ROWS(c, c->y32, d, M, d, 0);
+            { SkwGemmArgs a = q8_args(M, c->h32, 4L * d, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, 0); }
+            Q8_ROWS(c, c->h32, 4L * d, M, 4 * d, 0);
+            { SkwGemmArgs a = q8_args(M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; Q8_GEMM(c, a, L.fc2, 0); }
+        }
+        skw_layernorm(c->x, M, d, m->ln_post.w, m->ln_post.b, nullptr, c->encq32, c->stream);
+        if (want_f32_out) hipMemcpyAsync(c->enc_out32, c->encq32, sizeof(float) * (size_t)nc * d, hipMemcpyDeviceToDevice, c->stream);
+        if (cross) {
+            const int dt = hp.n_text_state; const float Kscale = (float)pow((double)((float)dt / hp.n_text_head), -0.25);
+            Q8_ROWS(c, c->encq32, d, M, d, 0);
+            for (int l = 0; l < hp.n_text_layer; ++l) {
+                const DecLayer& L = m->dec[l];
+                half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad;
+                { SkwGemmArgs a = q8_args(M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; Q8_GEMM(c, a, L.ck, 0); }
+                { SkwGemmArgs a = q8_args(M, cv, 0, EPI_VT_F16); a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.cv, 0); }
+            }
+        }
+        c->last_enc_B = Bw;
+        return;
+    }
     for (int l = 0; l < hp.n_audio_layer; ++l) {
         const EncLayer& L = m->enc[l];
         { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, c->y16, nullptr, c->stream); }
@@ -570,6 +669,39 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     c->cur = s;
     float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
     half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = c->st + r0;
+    if (use_q8(c)) {   // quantised file, exact precision: ggml's arithmetic (see run_encoder); the row group's q8 scratch starts at its first row
+        float* dy32 = c->dy32 + (size_t)r0 * dt; float* datt32 = c->datt32 + (size_t)r0 * dt; float* dh32 = c->dh32 + (size_t)r0 * 4 * dt;
+        skw_dec_embed_f32(m->te32, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
+        for (int l = 0; l < hp.n_text_layer; ++l) {
+            const DecLayer& L = m->dec[l];
+            half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
+            half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, nullptr, dy32, s); }
+            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0); }
+            { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, (half_t*)datt32, &st[0].active, s, 1); }
+            Q8_ROWS(c, datt32, dt, Bw, dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0); }
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, nullptr, dy32, s); }
+            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
+            Q8_ROWS(c, datt32, dt, Bw, dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0); }
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, nullptr, dy32, s); }
+            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dh32, 4L * dt, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, r0); }
+            Q8_ROWS(c, dh32, 4L * dt, Bw, 4 * dt, r0);
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.fc2, r0); }
+        }
+        if (want_logits) {
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, nullptr, dy32, s); }
+            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            SkwGemmArgs a = q8_args(Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); Q8_GEMM(c, a, m->te, r0);
+        }
+        c->cur = c->stream;
+        return;
+    }
     // The first layer's LayerNorm rides on the embedding kernel (same bits: skw_ln_rows).  The others could ride on the GEMM that completes x
     // (SKW_DEC_LN_TAIL=1, f16_mfma: the last workgroup to arrive per 16-row block normalises it — 8 launches per layer instead of 11), but a
     // launch boundary (3 us) is cheaper on this part than what the hand-over costs inside a kernel (write-through stores, two counter

@@ -67,7 +67,7 @@ void skw_layernorm(const float* x, int rows, int d, const float* w, const float*
 
 // Encoder self-attention, exact three-pass softmax. Qh/Kh: [(b*H+h)*Tpad + i][64 kperm], Vt: [(b*H+h)*64 + c][Tpad kperm],
 // out: f16 [b*n_ctx + i][kperm(h*64 + c)] with row stride ld_out
-void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg = nullptr, float* dbg2 = nullptr);
+void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg = nullptr, float* dbg2 = nullptr, int f32_out = 0);   // f32_out: `out` is a float [B*n_ctx][ld_out] buffer, natural order, unrounded
 
 // log-mel front end
 struct SkwMelTables { const float* hann; const float* sin_t; const float* cos_t; const float* filters; int n_mel; int n_fft_bins;
@@ -92,11 +92,11 @@ void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const i
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s);
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0);
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s);
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0);
 
 // per-sequence decoding state kept on the device (whisper_decoder + the bits of whisper_full_with_state's loop that depend on it)
 struct SkwSeqState {

@@ -229,6 +229,11 @@ void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
     }
 }
 
+// attention outputs: f16 in kperm order for the f16-weight path; f32 in natural order (the same buffer pointer, viewed as float) when the
+// projection that follows multiplies by block-quantised weights and ggml quantises the UNROUNDED f32 row (skw_kernels_q8.hip)
+__device__ __forceinline__ void att_store(half_t* out, long row_off, int col, float v, int f32_out) {
+    if (f32_out) ((float*)out)[row_off + col] = v; else out[row_off + skw_kperm(col)] = f2h(v);
+}
 // ------------------------------------------------------------------ LayerNorm
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -255,7 +260,7 @@ void skw_layernorm(const float* x, int rows, int d, const float* w, const float*
 #define AT_KROW 72   // halves per K row in LDS (64 + 8 pad = 144 B)
 #define AT_VROW 40   // halves per V^T row in LDS (32 + 8 pad = 80 B)
 __global__ __launch_bounds__(256, 2) void k_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                         int H, int n_ctx, int Tpad, float kq_scale, float* dbg, float* dbg2) {
+                                                         int H, int n_ctx, int Tpad, float kq_scale, float* dbg, float* dbg2, int f32_out) {
     __shared__ __attribute__((aligned(16))) half_t ldsK[2][32 * AT_KROW];
     __shared__ __attribute__((aligned(16))) half_t ldsV[2][64 * AT_VROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder(const half_t* Qh, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int qi = q0 + qt * 16 + g * 4 + r; int c = ct * 16 + r16;
-                if (qi < n_ctx) out[((long)b * n_ctx + qi) * ld_out + skw_kperm(h * 64 + c)] = f2h(oacc[qt][ct][r]);
+                if (qi < n_ctx) att_store(out, ((long)b * n_ctx + qi) * ld_out, h * 64 + c, oacc[qt][ct][r], f32_out);
                 if (dbg && qi < n_ctx && b == 0) { dbg[(long)qi * (H * 64) + h * 64 + c] = oacc[qt][ct][r]; if (ct == 0 && r == 0 && g == 0 && q0 + qt * 16 + r16 < n_ctx) { dbg[(long)n_ctx * H * 64 + (long)h * n_ctx + q0 + qt * 16 + r16] = rmax[qt]; dbg[(long)n_ctx * H * 64 + (long)(H + h) * n_ctx + q0 + qt * 16 + r16] = rinv[qt]; } }
             }
 }
@@ -446,7 +451,7 @@ __device__ __forceinline__ f32x2 expf_nonpos_x2_softmax(f32x2 x) {
 }
 template <int NT, int RT>
 __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                            int H, int n_ctx, int Tpad, float kq_scale, int qtiles) {
+                                                            int H, int n_ctx, int Tpad, float kq_scale, int qtiles, int f32_out) {
     constexpr int LT = NT - RT, NB = NT / 2, KD = 3;
     static_assert(NT % 2 == 0 && RT % 2 == 0 && RT <= NT, "tiles come in 32-key blocks");
     extern __shared__ __attribute__((aligned(16))) char smem_att[];
@@ -577,19 +582,19 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int qi = q0 + g * 4 + r; int c = ct * 16 + r16;
-            if (qi < n_ctx) out[((long)b * n_ctx + qi) * ld_out + skw_kperm(h * 64 + c)] = f2h(oacc[ct][r]);
+            if (qi < n_ctx) att_store(out, ((long)b * n_ctx + qi) * ld_out, h * 64 + c, oacc[ct][r], f32_out);
         }
 }
 
-void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2) {
+void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2, int f32_out) {
     if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg && !getenv("SKW_ATTN_V1")) {     // Whisper's 1500-frame context
         const int qtiles = (n_ctx + 63) / 64;
         constexpr int RT3 = 72;
-        hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles);
+        hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles, f32_out);
         return;
     }
     dim3 grid((n_ctx + 127) / 128, H, B);
-    hipLaunchKernelGGL(k_attn_encoder, grid, dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), dbg, dbg2);
+    hipLaunchKernelGGL(k_attn_encoder, grid, dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), dbg, dbg2, f32_out);
 }
 
 // ------------------------------------------------------------------ log-mel front end (K1)
@@ -765,7 +770,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // A block is 4 waves = 4 heads of one sequence.
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
-                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride) {
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
             for (; jj < nj; ++jj) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, jj)), h2f(vt[(long)jj * ldkv]), acc);
         }
     }
-    out[(long)b * ldo + skw_kperm(h * 64 + lane)] = f2h(acc);
+    att_store(out, (long)b * ldo, h * 64 + lane, acc, f32_out);
 }
 // ------------------------------------------------------------------ decoder cross-attention (K9), bandwidth form
 // Two waves per (sequence, head), three heads per workgroup (12 heads x 64 sequences = 256 workgroups of 6 waves: every CU, 1.5 waves/SIMD).
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
 template <int MAXT, int WPH, int HPW>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
-                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride) {
+                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out) {
     if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
@@ -995,27 +1000,27 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long)b * ldo + skw_kperm(h * 64 + (half * CT + ct) * 16 + 4 * g + r)] = f2h(oacc[ct][r]);
+            for (int r = 0; r < 4; ++r) att_store(out, (long)b * ldo, h * 64 + (half * CT + ct) * 16 + 4 * g + r, oacc[ct][r], f32_out);
     }
 }
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s) {
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     // heads per workgroup: 3 (256 workgroups of 12 waves at 64 rows x 12 heads: every CU)
     static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
-    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
-    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as);
+    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
+    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out) {
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4));
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out);
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0);
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

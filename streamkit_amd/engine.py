@@ -59,6 +59,9 @@ def lib():
         L.skw_device_count.restype = C.c_int
         L.skw_model_load.restype = C.c_void_p
         L.skw_model_load.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.skw_model_load_ex.restype = C.c_void_p
+        L.skw_model_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.skw_model_quant_type.argtypes = [C.c_void_p]
         L.skw_model_free.argtypes = [C.c_void_p]
         L.skw_model_get_hparams.argtypes = [C.c_void_p, C.POINTER(HParams)]
         L.skw_model_token_text.restype = C.c_void_p
@@ -115,12 +118,14 @@ def _result_to_dict(r):
 
 
 class Model:
-    def __init__(self, path, device=0):
+    def __init__(self, path, device=0, quant_mode=1):
+        """quant_mode (block-quantised files): 1 = ggml's q8 arithmetic in the exact precision (SKW_QUANT_GGML), 0 = the dequantised f16 twin everywhere"""
         L = lib()
         err = C.create_string_buffer(512)
-        self.h = L.skw_model_load(path.encode(), device, err, 512)
+        self.h = L.skw_model_load_ex(path.encode(), device, int(quant_mode), err, 512)
         if not self.h:
             raise RuntimeError(err.value.decode())
+        self.quant = L.skw_model_quant_type(self.h)
         self.hp = HParams()
         L.skw_model_get_hparams(self.h, C.byref(self.hp))
 

@@ -210,13 +210,33 @@ def test_fallback_only_for_the_clips_that_need_it(tiny):
     assert 0 < n_fb < len(clips)
 
 
-@pytest.mark.parametrize("kind", ["q5_1", "q8_0", "q4_0"])
-def test_quantised_model_file_matches_oracle(eng, kind):
-    """Block-quantised GGML files (the reference's default is a q5_1 file) load through the same dequantise-to-f16 step in the
-    engine and in the oracle: tokens, segments and log-probs identical."""
+@pytest.mark.parametrize("kind", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_quantised_model_file_runs_ggml_arithmetic_like_the_oracle(eng, kind):
+    """Block-quantised GGML files (the reference's default is a q5_1 file, lib.rs:114-116).  Exact precision: ggml's own arithmetic —
+    activation rows to q8_0 / q8_1 blocks, integer block dots on v_mfma_i32_16x16x32_i8, f32 scales (skw_kernels_q8.hip) — tokens,
+    segments and log-probs identical to the oracle's restatement of it; encoder output and cross K/V bit-identical too."""
     from conftest import quantized_model
     path = quantized_model("micro", kind)
     m = eng.Model(path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path)
+    assert m.quant == {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}[kind] == om.quant
+    pcms = [synth.clip(c, n) for c, n in [(2, 16000 * 30), (8, 16000 * 7)]]
+    for pcm, rg in zip(pcms, ctx.full_batch(pcms)):
+        assert _same(rg, om.full(pcm)) and len(rg["tokens"]) > 0
+    enc_g, ck_g, cv_g = ctx.encode(pcms[0])
+    mel_o, _ = om.log_mel(pcms[0])
+    enc_o, ck_o, cv_o = om.encode(mel_o)
+    for name, a, b in (("enc_out", enc_g, enc_o), ("cross_k", ck_g, ck_o), ("cross_v", cv_g, cv_o)):
+        assert bits_equal(a, b), name
+
+
+@pytest.mark.parametrize("kind", ["q5_1", "q4_0"])
+def test_quantised_model_file_as_f16_twin_matches_oracle(eng, kind):
+    """SKW_QUANT_F16_TWIN: the file's weights dequantised once and rounded to f16, run through the f16-weight kernels (what the f16_mfma
+    precision always does with a quantised file) — identical to the oracle in the same mode."""
+    from conftest import quantized_model
+    path = quantized_model("micro", kind)
+    m = eng.Model(path, quant_mode=0); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path, quant_mode=0)
+    assert m.quant == 0 and om.quant == 0
     pcms = [synth.clip(c, n) for c, n in [(2, 16000 * 30), (8, 16000 * 7)]]
     for pcm, rg in zip(pcms, ctx.full_batch(pcms)):
         assert _same(rg, om.full(pcm)) and len(rg["tokens"]) > 0
