@@ -127,6 +127,19 @@ def test_tokens_identical_to_oracle_ragged_batch(tiny16, suppress_nst):
     assert n_same >= len(CLIPS) - 2, n_same
 
 
+def test_quantised_file_in_f16_mfma_runs_its_f16_twin(eng):
+    """A block-quantised file in the f16_mfma precision: the matrix cores take the file's dequantised f16 twin (ggml's q8 arithmetic
+    is what the exact precision runs: tests/test_gpu_parity.py); the checker is the oracle in the same twin mode."""
+    from conftest import quantized_model
+    path = quantized_model("micro", "q5_1")
+    m = eng.Model(path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path, quant_mode=0)
+    assert m.quant == 7
+    ctx.set_precision("f16_mfma")
+    for c, n in [(2, 16000 * 30), (8, 16000 * 7)]:
+        pcm = synth.clip(c, n)
+        same_or_near_tie(ctx.full_batch([pcm])[0], om.full(pcm), "q5_1 micro clip %d" % c)
+
+
 def test_multi_window_and_language_detection_identical(eng, tiny_model_path):
     m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 80); om = OracleModel(tiny_model_path)
     ctx.set_precision("f16_mfma")
