@@ -101,7 +101,51 @@ __global__ __launch_bounds__(256) void k_gemm_q8(SkwGemmArgs a, SkwQ8Args qa) {
             for (int r = 0; r < 4; ++r) { const int n = n0 + i * 16 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[i][j][r]); }
         }
 }
+// the decode step's shape (M <= 64 rows): a 64 x 64 tile per workgroup would put N / 64 = 12 workgroups on the chip.  Here a workgroup is one
+// 16-feature strip, wave w takes rows 16w .. 16w + 15 with the whole block-ascending chain (the order is part of the result: no split over K).
+template <int EPI, int FORM>
+__global__ __launch_bounds__(256) void k_gemm_q8_small(SkwGemmArgs a, SkwQ8Args qa) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 64 + w * 16, n0 = blockIdx.x * 16;
+    if (m0 >= a.M) return;
+    const int nb = a.K >> 5, mrow = min(m0 + r16, a.M - 1);
+    const int8_t* wp = qa.qw + (long)min(n0 + r16, a.N - 1) * a.K + g * 8;
+    const int8_t* ap = qa.qa + (long)mrow * a.K + g * 8;
+    float sumf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int U = 4;                                           // blocks whose operands are requested together
+    for (int b0 = 0; b0 < nb; b0 += U) {
+        long fw[U], fa[U]; f32x4 dw[U], mw[U]; float dy[U], sy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = min(b0 + u, nb - 1);
+            fw[u] = *(const long*)(wp + b * 32); fa[u] = *(const long*)(ap + b * 32);
+            dw[u] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + n0 + 4 * g);
+            if (FORM == 3) mw[u] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + n0 + 4 * g);
+            dy[u] = qa.dyT[(long)b * a.M + mrow];
+            if (FORM == 3) sy[u] = qa.syT[(long)b * a.M + mrow];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + u >= nb) break;
+            const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[u], fa[u], (i32x4){0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sumf[r] = skw_ggml_block_dot(FORM, sumf[r], si[r], dw[u][r], FORM == 3 ? mw[u][r] : 0.0f, dy[u], FORM == 3 ? sy[u] : 0.0f);
+        }
+    }
+    const int m = m0 + r16;
+    if (m >= a.M) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int n = n0 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[r]); }
+}
 template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
+    if (a.M <= 128) {
+        const dim3 gs((a.N + 15) / 16, (a.M + 63) / 64);
+        if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8_small<EPI, 1>), gs, dim3(256), 0, s, a, qa);
+        else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8_small<EPI, 2>), gs, dim3(256), 0, s, a, qa);
+        else hipLaunchKernelGGL((k_gemm_q8_small<EPI, 3>), gs, dim3(256), 0, s, a, qa);
+        return;
+    }
     const dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
     if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1>), grid, dim3(256), 0, s, a, qa);
     else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2>), grid, dim3(256), 0, s, a, qa);
