@@ -305,7 +305,7 @@ const char* const kSchema =
     "\"suppress_non_speech_tokens\":{\"type\":\"boolean\",\"description\":\"Suppress non-speech tokens like [BLANK_AUDIO], [MUSIC], [APPLAUSE], etc.\",\"default\":true},"
     "\"emit_vad_events\":{\"type\":\"boolean\",\"description\":\"Emit VAD speech start/end out-of-band to the telemetry bus (does not flow through graph pins).\",\"default\":false},"
     "\"vad_mode\":{\"type\":\"string\",\"description\":\"(additive) auto (Silero when vad_model_path exists, else an energy gate) | silero | energy | always\",\"default\":\"auto\"},"
-    "\"precision\":{\"type\":\"string\",\"description\":\"(additive) exact (f32-chain contractions, bit-reproducible) | f16_mfma (f16 matrix cores)\",\"default\":\"exact\"},"
+    "\"precision\":{\"type\":\"string\",\"description\":\"(additive) exact (f32-chain contractions, bit-reproducible; block-quantised model files run ggml's q8 arithmetic) | f16_mfma (f16 matrix cores; quantised files as their f16 twin)\",\"default\":\"exact\"},"
     "\"batch_window_ms\":{\"type\":\"integer\",\"description\":\"(additive) how long the per-GPU scheduler waits for concurrent instances before launching a batch\",\"default\":2},"
     "\"max_batch\":{\"type\":\"integer\",\"description\":\"(additive) largest number of segments transcribed in one GPU batch\",\"default\":64},"
     "\"flush_tail\":{\"type\":\"boolean\",\"description\":\"(additive) transcribe buffered speech when the input stream ends (the reference drops it)\",\"default\":false}"
