@@ -359,7 +359,8 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr; int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;   // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
-    unsigned* ln_cnt = nullptr;   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
+    unsigned* ln_cnt = nullptr;
+    half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;   // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
@@ -436,6 +437,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
     c->step_graphs.clear();
     for (int g = 0; g < skw_ctx::MAX_GROUPS; ++g) { if (c->gstream[g]) { hipStreamSynchronize(c->gstream[g]); hipStreamDestroy(c->gstream[g]); } if (c->gev[g]) hipEventDestroy(c->gev[g]); }
     for (void* p : c->allocs) hipFree(p);
+    hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map);
     if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_n_active) hipHostFree(c->h_n_active);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -558,17 +560,20 @@ static void run_mel(skw_ctx* c, int n) {
     skw_mel_normalize(c->mel, c->n_len, n, c->n_len_max, m->hp.n_mels, c->clip_max, c->stream);
 }
 // conv stem for Bw window slots (clip_idx/seek on device) -> c->x [Bw*nc][d]
-static void run_conv(skw_ctx* c, int Bw) {
-    skw_model* m = c->m; const int nc = m->hp.n_audio_ctx, T = 2 * nc, d = m->hp.n_audio_state;
-    skw_mel_im2col(c->mel, c->clip_idx, c->seek, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
+// row0: the first window slot to compute (slots before it keep what they hold: temperature retries, see skw_full_batch); the stem's
+// buffers are scratch, so the Bw - row0 computed windows sit at their start
+static void run_conv(skw_ctx* c, int Bw_all, int row0 = 0) {
+    skw_model* m = c->m; const int nc = m->hp.n_audio_ctx, T = 2 * nc, d = m->hp.n_audio_state; const int Bw = Bw_all - row0;
+    skw_mel_im2col(c->mel, c->clip_idx + row0, c->seek + row0, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
     SkwGemmArgs a = gemm_args(c->im2col, 256, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
     GEMM(c, a, m->conv1.n_in);
     SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d; b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;
     GEMM(c, b, m->conv2.n_in);
 }
 // encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
-static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
-    skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, M = Bw * nc;
+static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, int row0 = 0) {
+    skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head; const int Bw = Bw_all - row0, M = Bw * nc;
+    const size_t xk0 = (size_t)row0 * nc * hp.n_text_state, xv0 = (size_t)row0 * hp.n_text_head * 64 * c->Tpad;      // cross K / V of the computed windows land in slots row0 ..
     if (use_q8(c)) {
         // Quantised file, exact precision: every weight product is ggml's (rows -> q8 blocks, integer block dots), so what feeds a
         // projection stays f32 and unrounded — LayerNorm, attention and GELU write f32 here — and only the attention operands
@@ -597,12 +602,12 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
             Q8_ROWS(c, c->encq32, d, M, d, 0);
             for (int l = 0; l < hp.n_text_layer; ++l) {
                 const DecLayer& L = m->dec[l];
-                half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad;
+                half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
                 { SkwGemmArgs a = q8_args(M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; Q8_GEMM(c, a, L.ck, 0); }
                 { SkwGemmArgs a = q8_args(M, cv, 0, EPI_VT_F16); a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.cv, 0); }
             }
         }
-        c->last_enc_B = Bw;
+        c->last_enc_B = Bw_all;
         return;
     }
     for (int l = 0; l < hp.n_audio_layer; ++l) {
@@ -641,7 +646,7 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
         const int dt = hp.n_text_state; const float Kscale = (float)pow((double)((float)dt / hp.n_text_head), -0.25);
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
-            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad;
+            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
             { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; GEMM(c, a, d); }
             { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
                 SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv; a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
@@ -650,7 +655,7 @@ static void run_encoder(skw_ctx* c, int Bw, bool want_f32_out, bool cross) {
             }
         }
     }
-    c->last_enc_B = Bw;
+    c->last_enc_B = Bw_all;
 }
 
 // one decoder step for Bw sequences: token/pos taken from the device state; logits computed when want_logits
@@ -800,6 +805,38 @@ static int load_clips(skw_ctx* c, const float* const* pcm, const int32_t* n_samp
     return 0;
 }
 
+// cross K/V of window slots src_slot[r] -> dst_slot[r], every layer, 16 bytes per thread (temperature retries keep their encoder pass)
+__global__ void k_slot_copy(const half_t* src, long src_layer_stride, half_t* dst, long dst_layer_stride, const int* src_slot, const int* dst_slot, long slot_elems) {
+    const int r = blockIdx.y, l = blockIdx.z;
+    const uint4* s4 = (const uint4*)(src + (long)l * src_layer_stride + (long)src_slot[r] * slot_elems);
+    uint4* d4 = (uint4*)(dst + (long)l * dst_layer_stride + (long)dst_slot[r] * slot_elems);
+    const long n16 = slot_elems >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) d4[i] = s4[i];
+}
+// The windows in `old_slots` (ascending new slot order 0 .. R-1) are decoded again at the next temperature: their cross K/V move to slots
+// 0 .. R-1 through a staging copy (a direct move could overwrite another retry's source), instead of running the encoder on them again.
+static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
+    char* errbuf = c->errbuf; const skw_hparams& hp = c->m->hp; const int R = (int)old_slots.size(), L = hp.n_text_layer;
+    bool same = true; for (int k = 0; k < R; ++k) same = same && old_slots[k] == k;
+    if (same) return 0;
+    const long ke = (long)hp.n_audio_ctx * hp.n_text_state, ve = (long)hp.n_text_head * 64 * c->Tpad;
+    if (!c->stageK) {
+        HIPCHK(hipMalloc((void**)&c->stageK, (size_t)L * c->max_batch * ke * 2)); HIPCHK(hipMalloc((void**)&c->stageV, (size_t)L * c->max_batch * ve * 2));
+        HIPCHK(hipMalloc((void**)&c->slot_map, sizeof(int) * 2 * c->max_batch));
+    }
+    std::vector<int> h(2 * (size_t)c->max_batch, 0);
+    for (int k = 0; k < R; ++k) { h[k] = old_slots[k]; h[c->max_batch + k] = k; }
+    HIPCHK(hipMemcpyAsync(c->slot_map, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                                   // (h is a local; retries are rare)
+    const int* olds = c->slot_map; const int* news = c->slot_map + c->max_batch;
+    const dim3 grid(64, R, L);
+    hipLaunchKernelGGL(k_slot_copy, grid, dim3(256), 0, c->stream, c->crossK, (long)c->max_batch * ke, c->stageK, (long)c->max_batch * ke, olds, news, ke);
+    hipLaunchKernelGGL(k_slot_copy, grid, dim3(256), 0, c->stream, c->crossV, (long)c->max_batch * ve, c->stageV, (long)c->max_batch * ve, olds, news, ve);
+    hipLaunchKernelGGL(k_slot_copy, grid, dim3(256), 0, c->stream, c->stageK, (long)c->max_batch * ke, c->crossK, (long)c->max_batch * ke, news, news, ke);
+    hipLaunchKernelGGL(k_slot_copy, grid, dim3(256), 0, c->stream, c->stageV, (long)c->max_batch * ve, c->crossV, (long)c->max_batch * ve, news, news, ve);
+    return 0;
+}
+
 extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
     char* errbuf = c->errbuf; errbuf[0] = 0;
     if (n_clips < 1 || n_clips > c->max_batch) { snprintf(errbuf, 512, "n_clips %d outside [1, %d]", n_clips, c->max_batch); return -1; }
@@ -818,7 +855,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     // temperature ladder (whisper_full_with_state): per clip, the index of the temperature its current window is decoded at
     std::vector<float> temps; temps.push_back(p->temperature);
     if (p->temperature_inc > 0.0f) for (float t = p->temperature + p->temperature_inc; t < 1.0f + 1e-6f && temps.size() < 16; t += p->temperature_inc) temps.push_back(t);
-    std::vector<int> tidx(n_clips, 0);
+    std::vector<int> tidx(n_clips, 0), retry_slot(n_clips, -1);   // retry_slot: the window slot whose cross K/V a retrying clip left behind (-1: not retrying)
     // prompt_past (whisper_full_with_state): text already produced in this call conditions the next window of the same clip
     std::vector<std::vector<int>> prompt_past(n_clips); std::vector<int> last_take(n_clips, 0);
     skw_rng_seed(c->rng, n_clips, 0u, c->stream);   // DEVIATION D2': seeded per call (whisper.cpp: per state, running on across calls)
@@ -853,9 +890,16 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
 
     while (true) {
         // clips that still have audio to decode ("if only 100ms left, then stop"; "input is too short": delta_min = 10 frames, whisper.cpp #2065)
-        std::vector<int> act; for (int i = 0; i < n_clips; ++i) if (n_len_org[i] >= SKW_DELTA_MIN && seek[i] + SKW_DELTA_MIN < n_len_org[i]) act.push_back(i);
+        // Windows that are decoded again at the next temperature come first: their cross K/V are still in HBM (at last round's slot) and move
+        // to slots 0 .. R-1; the encoder then runs only on the new windows, slots R .. Bw-1.
+        std::vector<int> act, retry_old;
+        for (int i = 0; i < n_clips; ++i) if (retry_slot[i] >= 0) { act.push_back(i); retry_old.push_back(retry_slot[i]); }
+        const int R = (int)act.size();
+        for (int i = 0; i < n_clips; ++i) if (retry_slot[i] < 0 && n_len_org[i] >= SKW_DELTA_MIN && seek[i] + SKW_DELTA_MIN < n_len_org[i]) act.push_back(i);
         if (act.empty()) break;
         const int Bw = (int)act.size();
+        if (R > 0 && move_retry_slots(c, retry_old)) return -1;
+        for (int j = 0; j < Bw; ++j) retry_slot[act[j]] = -1;
         std::vector<int> sk(Bw); for (int j = 0; j < Bw; ++j) sk[j] = seek[act[j]];
         HIPCHK(hipMemcpyAsync(c->clip_idx, act.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->seek, sk.data(), sizeof(int) * Bw, hipMemcpyHostToDevice, c->stream));
@@ -873,8 +917,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         }
         HIPCHK(hipMemcpyAsync(c->prompt_buf, pbuf.data(), sizeof(int) * pbuf.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
-        run_conv(c, Bw);
-        run_encoder(c, Bw, false, true);
+        if (R < Bw) { run_conv(c, Bw, R); run_encoder(c, Bw, false, true, R); }
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
         // decoder state
         for (int j = 0; j < Bw; ++j) {
@@ -940,7 +983,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             if (s.min_margin < R.min_margin) R.min_margin = s.min_margin;
             if (failed || (avg_logprobs < p->logprob_thold && s.no_speech_prob < p->no_speech_thold)) {
                 R.fallback_requested++;
-                if (tidx[ci] + 1 < (int)temps.size()) { tidx[ci]++; continue; }   // this window again, at the next temperature (the batch re-encodes it)
+                if (tidx[ci] + 1 < (int)temps.size()) { tidx[ci]++; retry_slot[ci] = j; continue; }   // this window again, at the next temperature, on the cross K/V it already has (slot j)
             }
             tidx[ci] = 0;
             int seek_delta = s.seek_delta;

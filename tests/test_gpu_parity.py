@@ -210,6 +210,28 @@ def test_fallback_only_for_the_clips_that_need_it(tiny):
     assert 0 < n_fb < len(clips)
 
 
+def test_retry_windows_keep_their_cross_kv_while_batch_mates_advance(eng, tiny_model_path):
+    """A window that is decoded again at the next temperature is not encoded again: its cross K/V move to the front slots of the next
+    round while the other clips' new windows are encoded behind them (skw_full_batch, move_retry_slots).  Multi-window clips with a
+    log-prob threshold between the clips' averages: retries and fresh windows share rounds, slots shift as clips finish."""
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=6, max_samples=16000 * 80); om = OracleModel(tiny_model_path)
+    clips = [(11, 16000 * 75), (3, 16000 * 30), (13, 16000 * 47 + 123), (5, 16000 * 12), (12, 16000 * 61), (6, 16000 * 30)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    base = [om.full(x) for x in pcms]
+    avg = sorted(float(np.mean([t[3] for t in r["tokens"]])) for r in base)
+    thold = 0.5 * (avg[2] + avg[3])
+    p = ctx.default_params(); p.logprob_thold = thold; p.no_speech_thold = 2.0
+    po = om.default_params(); po.logprob_thold = thold; po.no_speech_thold = 2.0
+    res = ctx.full_batch(pcms, p)
+    n_fb = n_multi_fb = 0
+    for (c, n), pcm, rg in zip(clips, pcms, res):
+        ro = om.full(pcm, po)
+        assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"], (c, n)
+        n_fb += ro["fallback_requested"] > 0
+        n_multi_fb += ro["fallback_requested"] > 0 and ro["n_windows"] > 1
+    assert 0 < n_fb < len(clips) and n_multi_fb > 0
+
+
 @pytest.mark.parametrize("kind", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
 def test_quantised_model_file_runs_ggml_arithmetic_like_the_oracle(eng, kind):
     """Block-quantised GGML files (the reference's default is a q5_1 file, lib.rs:114-116).  Exact precision: ggml's own arithmetic —
