@@ -4,6 +4,7 @@
 #pragma once
 #include "skw_kernels.h"
 #include "../../include/skw_math.h"
+#include "../../include/skw_ggml_quant.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,11 +67,28 @@ __device__ __forceinline__ void skw_ln_rows(float (&v)[R][24], const float (&wv)
             const int i = lane + 64 * c;
             if (i < d) {
                 float t = v[r][c] * scale; t = t * wv[c]; t = t + bv[c];
+                v[r][c] = t;                                    // (left in place for callers that go on with the normalised row: k_layernorm_q8)
                 if (out16[r]) out16[r][skw_kperm(i)] = f2h(t);
                 if (out32[r]) out32[r][i] = t;
             }
         }
     }
+}
+
+// One 32-block held one value per lane by 32 consecutive lanes (lanes 0-31 or 32-63 of a wave): quantize_row_q8_* with the maximum and
+// the sum taken across the half wave (max and integer sum are order-free, so the bits are k_q8_quantize's).  Every lane returns q; d and s
+// are valid in all 32 lanes.
+__device__ __forceinline__ int q8_half_wave_block(float x, float* d_out, float* s_out) {
+    float amax = x < 0.0f ? -x : x;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float d = amax / 127.0f, idv = d != 0.0f ? 1.0f / d : 0.0f;
+    const int q = (int)skw_roundf(x * idv);
+    int sum = q;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    *d_out = skw_round_f16(d); *s_out = skw_round_f16((float)sum * d);
+    return q;
 }
 
 // ------------------------------------------------------------------ epilogues

@@ -540,6 +540,12 @@ static void Q8_ROWS(skw_ctx* c, const float* act32, long lda, int M, int K, int 
     ProfScope p(c, PC_LAYERNORM, 0, 5.0 * M * K);
     skw_q8_quantize(act32, lda, M, K, c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), c->cur);
 }
+// LayerNorm -> f32 rows -> q8 blocks (a LayerNorm kernel that quantises its own rows, one wave per row with half-wave reductions per block,
+// was measured slower than the two launches: 372 vs 356 ms of decode per batch, 189 vs 184 ms of encode)
+static void Q8_LN(skw_ctx* c, const float* x, int M, int d, const DevLN& ln, int r0, float* y32) {
+    { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(x, M, d, ln.w, ln.b, nullptr, y32, c->cur); }
+    Q8_ROWS(c, y32, d, M, d, r0);
+}
 static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0) {
     a.K = L.n_in; a.N = L.n_out; a.bias = L.b;
     SkwQ8Args qa{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), L.qw, L.dwT, L.mwT, L.n_pad, L.qform};
@@ -580,8 +586,7 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
         // (Q, K, V^T: ggml casts those to f16 itself) are f16 as before.  The conv stem's kernels are 3-D tensors: never quantised.
         for (int l = 0; l < hp.n_audio_layer; ++l) {
             const EncLayer& L = m->enc[l];
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.attn_ln.w, L.attn_ln.b, nullptr, c->y32, c->stream); }
-            Q8_ROWS(c, c->y32, d, M, d, 0);
+            Q8_LN(c, c->x, M, d, L.attn_ln, 0, c->y32);
             { SkwGemmArgs a = q8_args(M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.q, 0); }
             { SkwGemmArgs a = q8_args(M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.k, 0); }
             { SkwGemmArgs a = q8_args(M, c->Vt, 0, EPI_VT_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.v, 0); }
@@ -589,8 +594,7 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
               skw_attn_encoder(c->Qh, c->Kh, c->Vt, (half_t*)c->y32, d, Bw, H, nc, c->Tpad, c->stream, nullptr, nullptr, 1); }
             Q8_ROWS(c, c->y32, d, M, d, 0);
             { SkwGemmArgs a = q8_args(M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; Q8_GEMM(c, a, L.o, 0); }
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(c->x, M, d, L.mlp_ln.w, L.mlp_ln.b, nullptr, c->y32, c->stream); }
-            Q8_ROWS(c, c->y32, d, M, d, 0);
+            Q8_LN(c, c->x, M, d, L.mlp_ln, 0, c->y32);
             { SkwGemmArgs a = q8_args(M, c->h32, 4L * d, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, 0); }
             Q8_ROWS(c, c->h32, 4L * d, M, 4 * d, 0);
             { SkwGemmArgs a = q8_args(M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; Q8_GEMM(c, a, L.fc2, 0); }
@@ -681,27 +685,24 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             const DecLayer& L = m->dec[l];
             half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
             half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.attn_ln.w, L.attn_ln.b, nullptr, dy32, s); }
-            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0); }
-            { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, (half_t*)datt32, &st[0].active, s, 1); }
-            Q8_ROWS(c, datt32, dt, Bw, dt, r0);
+            { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt);
+              SkwQ8Out qo{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), Bw};
+              skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo); }
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0); }
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.cross_ln.w, L.cross_ln.b, nullptr, dy32, s); }
-            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            Q8_LN(c, dx, Bw, dt, L.cross_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0); }
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
             Q8_ROWS(c, datt32, dt, Bw, dt, r0);
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0); }
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, L.mlp_ln.w, L.mlp_ln.b, nullptr, dy32, s); }
-            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            Q8_LN(c, dx, Bw, dt, L.mlp_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dh32, 4L * dt, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, r0); }
             Q8_ROWS(c, dh32, 4L * dt, Bw, 4 * dt, r0);
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.fc2, r0); }
         }
         if (want_logits) {
-            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, nullptr, dy32, s); }
-            Q8_ROWS(c, dy32, dt, Bw, dt, r0);
+            Q8_LN(c, dx, Bw, dt, m->d_ln, r0, dy32);
             SkwGemmArgs a = q8_args(Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); Q8_GEMM(c, a, m->te, r0);
         }
         c->cur = c->stream;

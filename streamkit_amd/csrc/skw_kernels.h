@@ -83,6 +83,7 @@ void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, cons
 // x[b][d] = f32(te[tok[b]][kperm(i)]) + pe[pos[b]][i]
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
 // ggml's arithmetic for block-quantised files (skw_kernels_q8.hip)
+struct SkwQ8Out { int8_t* q; float* dT; float* sT; int M; };   // where a producer leaves its rows as q8 blocks (q == nullptr: it does not)
 struct SkwQ8Args { const int8_t* qa; const float* dyT; const float* syT;        // activations: int8 [M][K], scales [K/32][M]
                    const int8_t* qw; const float* dwT; const float* mwT; int n_pad; int form; };   // weights: int8 [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
 void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s);
@@ -92,7 +93,7 @@ void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const i
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0);
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0});
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]

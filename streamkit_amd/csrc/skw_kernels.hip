@@ -770,7 +770,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // A block is 4 waves = 4 heads of one sequence.
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
-                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out) {
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwQ8Out q8) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
@@ -866,6 +866,13 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
             }
             for (; jj < nj; ++jj) acc = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(pbits, jj)), h2f(vt[(long)jj * ldkv]), acc);
         }
+    }
+    if (q8.q) {   // the projection that follows multiplies by block-quantised weights: the row leaves as ggml's q8 blocks (a head's 64 channels = two blocks)
+        float dd, ss; const int qi = q8_half_wave_block(acc, &dd, &ss);
+        const int i = h * 64 + lane, blk = i >> 5;
+        q8.q[(long)b * ldo + i] = (int8_t)qi;
+        if ((lane & 31) == 0) { q8.dT[(long)blk * q8.M + b] = dd; q8.sT[(long)blk * q8.M + b] = ss; }
+        return;
     }
     att_store(out, (long)b * ldo, h * 64 + lane, acc, f32_out);
 }
@@ -1014,13 +1021,13 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8) {
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out);
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8);
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0);
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0});
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

@@ -532,7 +532,7 @@ __device__ __forceinline__ void gemm16_small_ln_tail(const SkwGemmArgs& a, int m
     // the block's rows are read back with agent-scope loads (they miss any stale line this XCD's L2 holds): no cache invalidate either
     const int d = a.N;
     constexpr int RPW = 16 * MT / NW;                              // rows per wave
-    static_assert(RPW >= 1 && RPW % 2 == 0 || RPW == 1, "rows per wave");
+    static_assert((RPW >= 1 && RPW % 2 == 0) || RPW == 1, "rows per wave");
     constexpr int R = RPW >= 4 ? 4 : RPW;
     float wv[24], bv[24];
 #pragma unroll

@@ -44,57 +44,78 @@ void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* d
     hipLaunchKernelGGL(k_q8_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, M, K, q, dT, sT);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// skw_ggml_block_dot for a lane's four adjacent features at once, two per packed-f32 instruction (v_pk_mul_f32 / v_pk_add_f32 round each
+// element exactly as the scalar forms do; nothing is contracted): the kernels below are VALU-bound on this update
+template <int FORM>
+__device__ __forceinline__ void q8_update4(float (&sumf)[4], const i32x4 si, const f32x4 dw, const f32x4 mw, float dy, float sy) {
+    const f32x2 s01 = {(float)si[0], (float)si[1]}, s23 = {(float)si[2], (float)si[3]};
+    const f32x2 d01 = {dw[0], dw[1]}, d23 = {dw[2], dw[3]}, y2 = {dy, dy};
+    f32x2 t01, t23;
+    if (FORM == 1) { t01 = (s01 * d01) * y2; t23 = (s23 * d23) * y2; }
+    else {
+        t01 = (d01 * y2) * s01; t23 = (d23 * y2) * s23;
+        if (FORM == 3) { const f32x2 m01 = {mw[0], mw[1]}, m23 = {mw[2], mw[3]}, z2 = {sy, sy}; t01 = t01 + m01 * z2; t23 = t23 + m23 * z2; }
+    }
+    const f32x2 a01 = (f32x2){sumf[0], sumf[1]} + t01, a23 = (f32x2){sumf[2], sumf[3]} + t23;
+    sumf[0] = a01[0]; sumf[1] = a01[1]; sumf[2] = a23[0]; sumf[3] = a23[1];
+}
+
 template <int EPI>
 __device__ __forceinline__ void q8_store(const SkwGemmArgs& a, int m, int n, float v) {
     if (EPI == EPI_VT_F16) epi_store<EPI_VT_F16>(a, n, m, v);          // (that epilogue names the feature first: it was written for the operand-swapped call)
     else epi_store<EPI>(a, m, n, v);
 }
 
-// C = epilogue(A_q8 . W_q^T): A int8 [M][K] with dyT / syT [K/32][M]; W int8 [N][K] with dwT / mwT [K/32][n_pad] (n_pad = N rounded up to 64)
-template <int EPI, int FORM>
+// C = epilogue(A_q8 . W_q^T): A int8 [M][K] with dyT / syT [K/32][M]; W int8 [N][K] with dwT / mwT [K/32][n_pad] (n_pad = N rounded up to 64).
+// Workgroup tile (32 TW) x (32 TW): four waves of (16 TW) x (16 TW), each TW x TW MFMA tiles.  TW = 4 (128 x 128) is the encoder's shape: a
+// wave then makes 24 loads per 32-block for 16 integer dots of 16 x 16 (TW = 2: 12 loads for 4), which is what the kernel is bound by — the
+// operands come straight from global memory / L2, two waves of a workgroup sharing each row panel through L1.
+template <int EPI, int FORM, int TW>
 __global__ __launch_bounds__(256) void k_gemm_q8(SkwGemmArgs a, SkwQ8Args qa) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 64 + (w >> 1) * 32, n0 = blockIdx.x * 64 + (w & 1) * 32;
+    const int m0 = blockIdx.y * (32 * TW) + (w >> 1) * (16 * TW), n0 = blockIdx.x * (32 * TW) + (w & 1) * (16 * TW);
     const int nb = a.K >> 5;
     // operand rows (clamped: rows past the edge compute on a copy and are never stored)
-    const int8_t* wp[2]; const int8_t* ap[2];
+    const int8_t* wp[TW]; const int8_t* ap[TW]; int mrow[TW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TW; ++t) {
         wp[t] = qa.qw + (long)min(n0 + t * 16 + r16, a.N - 1) * a.K + g * 8;
-        ap[t] = qa.qa + (long)min(m0 + t * 16 + r16, a.M - 1) * a.K + g * 8;
+        mrow[t] = min(m0 + t * 16 + r16, a.M - 1);
+        ap[t] = qa.qa + (long)mrow[t] * a.K + g * 8;
     }
-    const int mrow[2] = {min(m0 + r16, a.M - 1), min(m0 + 16 + r16, a.M - 1)};
-    float sumf[2][2][4];                                  // [n tile][m tile][feature 4g + r]
+    float sumf[TW][TW][4];                                // [n tile][m tile][feature 4g + r]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TW; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sumf[i][j][r] = 0.0f;
+    // (requesting block b + 1's operands before block b is computed was measured slower: the second register set costs the second wave per SIMD)
     for (int b = 0; b < nb; ++b) {
-        long fw[2], fa[2]; f32x4 dw[2], mw[2]; float dy[2], sy[2];
+        long fw[TW], fa[TW]; f32x4 dw[TW], mw[TW]; float dy[TW], sy[TW];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TW; ++t) {
             fw[t] = *(const long*)(wp[t] + b * 32); fa[t] = *(const long*)(ap[t] + b * 32);
-            dw[t] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + n0 + t * 16 + 4 * g);
-            if (FORM == 3) mw[t] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + n0 + t * 16 + 4 * g);
+            const int nq = min(n0 + t * 16 + 4 * g, qa.n_pad - 4);
+            dw[t] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + nq);
+            if (FORM == 3) mw[t] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + nq);
             dy[t] = qa.dyT[(long)b * a.M + mrow[t]];
             if (FORM == 3) sy[t] = qa.syT[(long)b * a.M + mrow[t]];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TW; ++j) {
                 const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[i], fa[j], (i32x4){0, 0, 0, 0}, 0, 0, 0);     // D[n = 4g + r][m = r16]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sumf[i][j][r] = skw_ggml_block_dot(FORM, sumf[i][j][r], si[r], dw[i][r], FORM == 3 ? mw[i][r] : 0.0f, dy[j], FORM == 3 ? sy[j] : 0.0f);
+                q8_update4<FORM>(sumf[i][j], si, dw[i], FORM == 3 ? mw[i] : (f32x4){0.f, 0.f, 0.f, 0.f}, dy[j], FORM == 3 ? sy[j] : 0.0f);
             }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TW; ++j) {
             const int m = m0 + j * 16 + r16;
             if (m >= a.M) continue;
 #pragma unroll
@@ -129,8 +150,7 @@ __global__ __launch_bounds__(256) void k_gemm_q8_small(SkwGemmArgs a, SkwQ8Args 
         for (int u = 0; u < U; ++u) {
             if (b0 + u >= nb) break;
             const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[u], fa[u], (i32x4){0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sumf[r] = skw_ggml_block_dot(FORM, sumf[r], si[r], dw[u][r], FORM == 3 ? mw[u][r] : 0.0f, dy[u], FORM == 3 ? sy[u] : 0.0f);
+            q8_update4<FORM>(sumf, si, dw[u], FORM == 3 ? mw[u] : (f32x4){0.f, 0.f, 0.f, 0.f}, dy[u], FORM == 3 ? sy[u] : 0.0f);
         }
     }
     const int m = m0 + r16;
@@ -146,10 +166,18 @@ template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8A
         else hipLaunchKernelGGL((k_gemm_q8_small<EPI, 3>), gs, dim3(256), 0, s, a, qa);
         return;
     }
+    static const int tw_env = getenv("SKW_Q8_TW") ? atoi(getenv("SKW_Q8_TW")) : 4;
+    if (tw_env == 4 && a.M >= 1024) {
+        const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
+        if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1, 4>), grid, dim3(256), 0, s, a, qa);
+        else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2, 4>), grid, dim3(256), 0, s, a, qa);
+        else hipLaunchKernelGGL((k_gemm_q8<EPI, 3, 4>), grid, dim3(256), 0, s, a, qa);
+        return;
+    }
     const dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-    if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1>), grid, dim3(256), 0, s, a, qa);
-    else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2>), grid, dim3(256), 0, s, a, qa);
-    else hipLaunchKernelGGL((k_gemm_q8<EPI, 3>), grid, dim3(256), 0, s, a, qa);
+    if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1, 2>), grid, dim3(256), 0, s, a, qa);
+    else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2, 2>), grid, dim3(256), 0, s, a, qa);
+    else hipLaunchKernelGGL((k_gemm_q8<EPI, 3, 2>), grid, dim3(256), 0, s, a, qa);
 }
 bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
     if ((a.K & 31) || qa.form < 1 || qa.form > 3) return false;

@@ -251,6 +251,18 @@ def test_quantised_model_file_runs_ggml_arithmetic_like_the_oracle(eng, kind):
         assert bits_equal(a, b), name
 
 
+def test_quantised_tiny_model_ggml_arithmetic_full_context(eng):
+    """The same at Whisper-tiny geometry (1500-frame context: the 128 x 128-tile form of k_gemm_q8 and the 1500-key attention kernels with
+    f32 outputs), one 30 s clip and a short one."""
+    from conftest import quantized_model
+    path = quantized_model("tiny", "q5_1")
+    m = eng.Model(path); ctx = eng.Context(m, max_batch=2, max_samples=16000 * 32); om = OracleModel(path)
+    assert m.quant == 7 == om.quant
+    pcms = [synth.clip(3, 16000 * 30), synth.clip(9, 16000 * 5)]
+    for pcm, rg in zip(pcms, ctx.full_batch(pcms)):
+        assert _same(rg, om.full(pcm)) and len(rg["tokens"]) > 0
+
+
 @pytest.mark.parametrize("kind", ["q5_1", "q4_0"])
 def test_quantised_model_file_as_f16_twin_matches_oracle(eng, kind):
     """SKW_QUANT_F16_TWIN: the file's weights dequantised once and rounded to f16, run through the f16-weight kernels (what the f16_mfma
