@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=64); ap.add_argument("--size", default="small"); ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--batch-window-ms", type=float, default=40.0); ap.add_argument("--packet", type=int, default=960)
+    ap.add_argument("--precision", default="f16_mfma", choices=["exact", "f16_mfma"])
     a = ap.parse_args()
     import torch  # noqa: F401  (libamdhip64 first, as bench.py does)
     import minihost
@@ -28,7 +29,7 @@ def main():
     path = synth_model(a.size)
     plug = minihost.Plugin()
     pcms = [synth.clip(c) for c in range(a.clips)]
-    params = {"model_path": path, "vad_mode": "always", "flush_tail": True, "max_batch": a.clips, "batch_window_ms": a.batch_window_ms}
+    params = {"model_path": path, "vad_mode": "always", "flush_tail": True, "max_batch": a.clips, "batch_window_ms": a.batch_window_ms, "precision": a.precision}
     best = None
     for rep in range(a.reps + 1):
         nodes = [plug.create_node(params) for _ in range(a.clips)]              # model load is cached per path (first create pays it; excluded, as in the reference)
@@ -40,7 +41,7 @@ def main():
     audio_s = sum(p.size for p in pcms) / 16000.0
     n_seg = sum(len(json.loads(o[0][2].decode())["segments"]) for o in outs)
     print(json.dumps({"what": "plugin-level Oneshot batch (host PCM -> Transcription JSON), %d instances" % a.clips, "value": round(audio_s / (best * 1e-3), 1), "unit": "x real-time",
-                      "wall_ms": round(best, 2), "packet_samples": a.packet, "batch_window_ms": a.batch_window_ms, "segments": n_seg, "model": a.size}))
+                      "wall_ms": round(best, 2), "packet_samples": a.packet, "batch_window_ms": a.batch_window_ms, "segments": n_seg, "model": a.size, "precision": a.precision}))
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8); ap.add_argument("--seconds", type=float, default=24.0); ap.add_argument("--size", default="small")
     ap.add_argument("--utterance-s", type=float, default=4.0); ap.add_argument("--gap-s", type=float, default=1.0); ap.add_argument("--batch-window-ms", type=float, default=2.0)
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="offset between the streams' utterance boundaries (0 = all streams end segments together)")
+    ap.add_argument("--precision", default="f16_mfma", choices=["exact", "f16_mfma"])
     a = ap.parse_args()
     import torch  # noqa: F401
     import minihost
@@ -36,7 +37,7 @@ def main():
         while pos + ut + gap <= n_total:
             x[pos:pos + ut] = synth.clip(100 * i + k, ut); pos += ut + gap; k += 1
         pcms.append(x)
-    params = {"model_path": path, "vad_mode": "energy", "min_silence_duration_ms": 500, "batch_window_ms": a.batch_window_ms, "max_batch": max(8, a.streams)}
+    params = {"model_path": path, "vad_mode": "energy", "min_silence_duration_ms": 500, "batch_window_ms": a.batch_window_ms, "max_batch": max(8, a.streams), "precision": a.precision}
     warm = plug.create_node(params); warm.process_audio(pcms[0][:ut + gap]); warm.destroy()          # model load + first-use costs outside the measurement
     nodes = [plug.create_node(params) for _ in range(a.streams)]
     n = a.streams; max_lat = 64
