@@ -22,6 +22,8 @@
  *     exactly what gfx950's v_mfma_f32_*_f32 computes (MI355X guide,
  *     "FP32-input MFMA": bit-for-bit a k-ordered fmaf chain), and what a plain
  *     scalar C loop computes;
+ *     In the one-token decoder graph the K axis is cut into four contiguous
+ *     segments, each such a chain from zero, added ((s0+s1)+s2)+s3 (D3');
  *   - long sums that ggml accumulates in `ggml_float` (double): accumulated in
  *     double here too (LayerNorm statistics, softmax denominators), which makes
  *     them insensitive to the reduction order a GPU uses.

@@ -446,6 +446,19 @@ static void layer_norm(const float* x, int rows, int d, const ln_t* ln, float* y
 }
 
 /* y = round16?( A16 . W + b ) helper: A (rows x n_in, f16-valued), result rows x n_out f32 with bias */
+/* Decode-step contraction (D3'): the K axis in four contiguous segments, each a k-ascending fma chain from zero, the four partial
+ * sums added in ascending segment order: ((s0 + s1) + s2) + s3.  Every mul_mat of the one-token decoder graph is defined this way
+ * (K % 128 == 0 in every Whisper geometry; otherwise the single chain) — four waves share a contraction on the GPU instead of one. */
+static void gemm_chain_seg4(const float* A, long lda, int M, const float* Wt, long ldw, int N, int K, float* C, long ldc) {
+    if (K % 128) { gemm_chain(A, lda, M, Wt, ldw, N, K, C, ldc); return; }
+    const int Kq = K / 4; float* t = xmalloc_f((size_t)4 * M * N);
+    for (int s = 0; s < 4; ++s) gemm_chain(A + (long)s * Kq, lda, M, Wt + (long)s * Kq * ldw, ldw, N, Kq, t + (size_t)s * M * N, N);
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+        const size_t i = (size_t)m * N + n; float v = t[i] + t[(size_t)M * N + i]; v = v + t[(size_t)2 * M * N + i]; v = v + t[(size_t)3 * M * N + i];
+        C[(long)m * ldc + n] = v;
+    }
+    free(t);
+}
 /* ggml's quantised mul_mat (include/skw_ggml_quant.h (a)): rows of A (f32, NOT rounded to f16) -> q8 blocks, block-ascending chain of integer dots */
 static void linear_q8(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
     const int K = L->n_in, nb = K / 32, N = L->n_out, form = skw_ggml_dot_form(L->qtype);
@@ -480,6 +493,13 @@ static void linear(const float* A, long lda, int rows, const lin_t* L, float* ou
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < rows; ++r) { float* o = out + (long)r * ldo; for (int i = 0; i < L->n_out; ++i) o[i] = o[i] + L->b[i]; }
     }
+}
+
+/* the decoder's projections: segmented contraction (f16 weights) or ggml's q8 arithmetic (quantised files), then the bias */
+static void linear_dec(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
+    if (L->qw) { linear(A, lda, rows, L, out, ldo); return; }
+    gemm_chain_seg4(A, lda, rows, L->wt, L->n_out, L->n_out, L->n_in, out, ldo);
+    if (L->b) for (int r = 0; r < rows; ++r) { float* o = out + (long)r * ldo; for (int i = 0; i < L->n_out; ++i) o[i] = o[i] + L->b[i]; }
 }
 
 /* ggml_soft_max_ext row: wp = s*scale; max; p = expf(wp-max); sum (double); p *= (float)(1/sum) */
@@ -623,9 +643,9 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
         float* Kc = s->self_k + (size_t)l * ntc * d; float* Vc = s->self_v + (size_t)l * ntc * d;
         /* self-attention */
         layer_norm(x, 1, d, &L->attn_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        linear(y, d, 1, &L->q, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
-        linear(y, d, 1, &L->k, kv, d); for (int i = 0; i < d; ++i) Kc[(size_t)pos * d + i] = skw_round_f16(kv[i] * KQscale);
-        linear(y, d, 1, &L->v, kv, d); for (int i = 0; i < d; ++i) Vc[(size_t)pos * d + i] = skw_round_f16(kv[i]);
+        linear_dec(y, d, 1, &L->q, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
+        linear_dec(y, d, 1, &L->k, kv, d); for (int i = 0; i < d; ++i) Kc[(size_t)pos * d + i] = skw_round_f16(kv[i] * KQscale);
+        linear_dec(y, d, 1, &L->v, kv, d); for (int i = 0; i < d; ++i) Vc[(size_t)pos * d + i] = skw_round_f16(kv[i]);
         const int n_kv = pos + 1;
         for (int h = 0; h < nh; ++h) {
             for (int j = 0; j < n_kv; ++j) { float a = 0.0f; const float* kr = Kc + (size_t)j * d + h * dh; for (int c = 0; c < dh; ++c) a = fmaf(q[h * dh + c], kr[c], a); sc[j] = a; }
@@ -633,10 +653,10 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
             for (int j = 0; j < n_kv; ++j) sc[j] = skw_round_f16(sc[j]);
             for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < n_kv; ++j) a = fmaf(sc[j], Vc[(size_t)j * d + h * dh + c], a); att[h * dh + c] = m->quant ? a : skw_round_f16(a); }
         }
-        linear(att, d, 1, &L->o, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
+        linear_dec(att, d, 1, &L->o, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
         /* cross-attention */
         layer_norm(x, 1, d, &L->cross_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        linear(y, d, 1, &L->cq, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
+        linear_dec(y, d, 1, &L->cq, q, d); for (int i = 0; i < d; ++i) q[i] = skw_round_f16(q[i] * KQscale);
         const float* Vx = s->cross_v + (size_t)l * nc * d;
         for (int h = 0; h < nh; ++h) {
             float scl[1536];
@@ -646,16 +666,16 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
             for (int j = 0; j < nc; ++j) scl[j] = skw_round_f16(scl[j]);
             for (int c = 0; c < dh; ++c) { float a = 0.0f; for (int j = 0; j < nc; ++j) a = fmaf(scl[j], Vx[(size_t)j * d + h * dh + c], a); att[h * dh + c] = m->quant ? a : skw_round_f16(a); }
         }
-        linear(att, d, 1, &L->co, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
+        linear_dec(att, d, 1, &L->co, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
         /* mlp */
         layer_norm(x, 1, d, &L->mlp_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        linear(y, d, 1, &L->fc1, hb, 4 * d); for (int i = 0; i < 4 * d; ++i) { const float g = skw_gelu_lookup(hb[i], m->gelu_tab); hb[i] = m->quant ? g : skw_round_f16(g); }
-        linear(hb, 4 * d, 1, &L->fc2, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
+        linear_dec(y, d, 1, &L->fc1, hb, 4 * d); for (int i = 0; i < 4 * d; ++i) { const float g = skw_gelu_lookup(hb[i], m->gelu_tab); hb[i] = m->quant ? g : skw_round_f16(g); }
+        linear_dec(hb, 4 * d, 1, &L->fc2, y, d); for (int i = 0; i < d; ++i) x[i] = y[i] + x[i];
     }
     if (logits) {
         layer_norm(x, 1, d, &m->d_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
         if (m->d_te_lin.qw) linear_q8(y, d, 1, &m->d_te_lin, logits, m->hp.n_vocab);
-        else gemm_chain(y, d, 1, m->d_te_lin.wt, m->d_te_lin.n_out, m->hp.n_vocab, d, logits, m->hp.n_vocab);
+        else gemm_chain_seg4(y, d, 1, m->d_te_lin.wt, m->d_te_lin.n_out, m->hp.n_vocab, d, logits, m->hp.n_vocab);
     }
 }
 int skwo_dec_step(skwo_dec* s, const int32_t* tokens, int n_tokens, int n_past, int n_threads, float* logits) {

@@ -195,6 +195,95 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
     }
 }
 
+// The same with the contraction in FOUR contiguous K segments (D3'): a workgroup is one 16-column strip x one 16-row tile, wave s
+// chains segment s (k-blocks [s nk/4, (s+1) nk/4), k-ascending from zero), the partial tiles meet in LDS and wave 0 adds them in ascending
+// segment order, ((s0 + s1) + s2) + s3 — oracle/skw_oracle.c gemm_chain_seg4, bit for bit.  A quarter of the dependent-MFMA chain per wave.
+template <int EPI, int SM_DEPTH>
+__global__ __launch_bounds__(256) void k_gemm_smallm_seg(SkwGemmArgs a) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16, mt = blockIdx.y;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int gn = n0 + r16, gm = mt * 16 + r16;
+    const unsigned wbytes = (unsigned)((long)a.N * a.ldw * 2), abytes = (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, abytes, 0x00020000);
+    const unsigned oob = 0x7fffff00u;
+    const int nkq = (a.K >> 5) >> 2, kb_lo = wave * nkq;                 // host guarantees K % 128 == 0
+    const unsigned wo = (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kb_lo * 32 + kq * 8) * 2) : oob;
+    const unsigned ao = (gm < a.M) ? (unsigned)(((long)gm * a.lda + kb_lo * 32 + kq * 8) * 2) : oob;
+    H8v fw[SM_DEPTH], fa[SM_DEPTH];
+#pragma unroll
+    for (int j = 0; j < SM_DEPTH; ++j) {
+        fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nkq) ? oob : wo + j * 64, 0, 0);
+        fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nkq) ? oob : ao + j * 64, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int en = n0 + r16; const bool en_ok = en < a.N && wave == 0;
+    float pre_bias = 0.0f, pre_res[4] = {0.f, 0.f, 0.f, 0.f}; long pre_po[4] = {0, 0, 0, 0};
+    if (EPI != EPI_VT_F16 && a.bias && en_ok) pre_bias = a.bias[en];
+    if (EPI == EPI_F32 && a.res && en_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_res[r] = a.res[(long)m * a.ldres + en]; }
+    }
+    if (EPI == EPI_DEC_QKV && a.pos_ptr && wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_po[r] = (long)a.pos_ptr[(long)m * a.pos_stride] * a.n_ctx; }
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb0 = 0; kb0 < nkq; kb0 += SM_DEPTH) {
+#pragma unroll
+        for (int j = 0; j < SM_DEPTH; ++j) {
+            float xa[8], xw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xa[e] = h2f(fa[j].h[e]); xw[e] = h2f(fw[j].h[e]); }
+            __builtin_amdgcn_sched_barrier(0);
+            const int nb = kb0 + j + SM_DEPTH;
+            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nkq) ? oob : wo + nb * 64, 0, 0);
+            fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nkq) ? oob : ao + nb * 64, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb0 + j < nkq) {                                         // (uniform) blocks past the segment are skipped, not multiplied by zeros
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = MFMA16(xa[e], xw[e], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    {
+        const f32x4 s1 = red[1][lane], s2 = red[2][lane], s3 = red[3][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float v = acc[r] + s1[r]; v = v + s2[r]; v = v + s3[r]; acc[r] = v; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int m = mt * 16 + kq * 4 + r, n = n0 + r16;
+        if (!(m < a.M && n < a.N)) continue;
+        float v = acc[r];
+        if (EPI == EPI_F32) {
+            if (a.bias) v = v + pre_bias;
+            if (a.res) v = v + pre_res[r];
+            ((float*)a.C)[(long)m * a.ldc + n] = v;
+        } else if (EPI == EPI_F16_PLAIN) {
+            if (a.bias) v = v + pre_bias;
+            if (a.has_scale) v = v * a.scale;
+            ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+        } else if (EPI == EPI_GELU_F16_KPERM) {
+            if (a.bias) v = v + pre_bias;
+            ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
+        } else if (EPI == EPI_DEC_QKV) {
+            const int d = a.n_ctx;
+            if (a.bias) v = v + pre_bias;
+            if (n < 2 * d) v = v * a.scale;
+            if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
+            else if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + pre_po[r] + (n - d)] = f2h(v);
+            else ((half_t*)a.C3)[(long)m * a.ldc2 + pre_po[r] + (n - 2 * d)] = f2h(v);
+        } else epi_store<EPI>(a, m, n, acc[r]);
+    }
+}
+
 template <int EPI> static void launch_gemm(const SkwGemmArgs& a, hipStream_t s) {
     int nbn = (a.N + G_BN - 1) / G_BN, nbm = (a.M + G_BM - 1) / G_BM;
     hipLaunchKernelGGL(k_gemm<EPI>, dim3(nbn * nbm), dim3(256), 0, s, a);
@@ -212,8 +301,15 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s) {
     }
 }
 template <int EPI> static void launch_gemm_small(const SkwGemmArgs& a, hipStream_t s) {
-    dim3 grid((a.N + 15) / 16, (a.M + 63) / 64);
     const int nk = a.K >> 5;
+    if (!(a.K & 127)) {      // the decoder's contractions: four segments (D3'); every Whisper geometry takes this branch
+        const dim3 gs((a.N + 15) / 16, (a.M + 15) / 16); const int nkq = nk >> 2;
+        if (nkq % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 24>), gs, dim3(256), 0, s, a);
+        else if (nkq <= 6) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 6>), gs, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 8>), gs, dim3(256), 0, s, a);
+        return;
+    }
+    dim3 grid((a.N + 15) / 16, (a.M + 63) / 64);
     // K = 768-class contractions keep the whole operand strip in flight (24 blocks = 192 VGPRs); others use an 8-deep ring
     if (nk % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm<EPI, 24>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gemm_smallm<EPI, 8>), grid, dim3(256), 0, s, a);
