@@ -395,8 +395,8 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     c->cur = c->stream;
     // decode groups: the step kernels are latency-bound chains that leave most CUs idle, so independent row groups run concurrently
-    // -1 = per precision (see skw_full_batch): the exact kernels (9 - 24 us each) run best as two row groups, the f16 ones (5 us each) as one
-    // (dependent chains on two streams do not overlap on this part: tools/probe/probe_stream_overlap.hip); captured step graphs in both
+    // -1 = default (see skw_full_batch): one row group as a captured step graph in both precisions (dependent chains on two streams do
+    // not overlap on this part: tools/probe/probe_stream_overlap.hip)
     { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : -1; }
     { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
     for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
@@ -929,7 +929,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
-        const int n_groups = c->n_groups > 0 ? c->n_groups : (c->precision == SKW_PRECISION_F16_MFMA ? 1 : 2);
+        const int n_groups = c->n_groups > 0 ? c->n_groups : 1;   // one row group in both precisions (exact: 194 ms against 213 with two, since the segmented decode GEMMs; f16_mfma: 178 against 204)
         const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;   // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
         const int G = std::max(1, std::min(n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
