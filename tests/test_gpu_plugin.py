@@ -202,6 +202,21 @@ def test_vad_modes_and_failure_strings(plugin, tiny_model_path, tmp_path):
     node.destroy()
 
 
+def test_default_configuration_with_a_q5_1_model_file(plugin):
+    """The reference's default model is a q5_1 file (lib.rs:114-116): with default params (precision exact) the drop-in multiplies it the way
+    ggml does (q8 activation blocks, integer block dots) and the Transcription packet equals what the oracle's restatement of that arithmetic gives."""
+    from conftest import quantized_model
+    path = quantized_model("tiny", "q5_1")
+    om = OracleModel(path)
+    assert om.quant == 7
+    node = plugin.create_node({"model_path": path, "vad_mode": "always", "flush_tail": True})
+    pcm = synth.clip(6, 16000 * 14)
+    _feed(node, pcm); assert node.flush() == 0
+    outs = node.outputs()
+    assert len(outs) == 1 and json.loads(outs[0][2].decode()) == _expected_transcription(om, pcm, 0)
+    node.destroy()
+
+
 def test_precision_param_f16_mfma(plugin, tiny_model_path):
     """(additive) precision: "f16_mfma" runs the f16 matrix-core kernels behind the same ABI; the transcript equals the exact
     instance's unless the exact argmax was a near-tie (tests/test_gpu_f16.py holds the detailed bar)."""
