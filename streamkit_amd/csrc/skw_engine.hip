@@ -520,8 +520,8 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical);
 static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s, bool normalised = false) {
     if (normalised) { GEMM_S(c, a, a.K); return; }                     // y16 already holds LayerNorm(x): the GEMM that wrote x did it (ln_tail)
-    // measured (profiles/r02): the fused kernel costs 20 us at N = 2304 / 3072 and 10 us at N = 768 where LayerNorm (5 us) + plain GEMM
-    // (5 - 6 us) cost 11: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
+    // measured (profiles/r02c): the fused kernel costs 17 - 18 us at N = 2304 / 3072 and 9.6 us at N = 768 where LayerNorm (5 us)
+    // + plain GEMM (5 - 8.6 us) cost 10 - 13.6: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
     static const bool fuse = getenv("SKW_DEC_LN_FUSE") != nullptr;
     if (c->precision == SKW_PRECISION_F16_MFMA && fuse) {
         a.ln_x = x; a.ln_w = ln.w; a.ln_b = ln.b;

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
     constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
     constexpr int RD = 12;                                      // K = d <= 1536: a wave's whole K quarter of W is in flight at once
     __shared__ __attribute__((aligned(16))) half_t ya[16 * 1536];
+    __shared__ f32x4 gb[2 * 384];                               // LayerNorm gain | bias
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16, my0 = blockIdx.y * 16;
@@ -659,52 +660,48 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
     if (EPI == EPI_F32 && a.res && w == 0 && em < a.M && ep0 + 3 < a.N && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
     if (EPI == EPI_DEC_QKV && a.pos_ptr && w == 0 && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
     // ---- LayerNorm of the block's 16 rows -> ya (row stride d halves; 16-byte chunk c of row r sits at chunk c ^ (r & 7)).
-    // Sixteen threads per row, all rows at once.  A thread owns whole kperm groups — the eight k with k % 4 == q of a 32-block, which
-    // are adjacent in the image — so it loads x with stride 4 (its three neighbours fill in the 128-byte line) and stores each group
-    // with one 16-byte LDS write.  Statistics as ggml_norm: f64 sums, mean and variance rounded to f32, then scale, gain, bias, f16.
+    // Sixteen threads per row, all rows at once; a thread takes 16-byte pieces t16, t16 + 16, ... of its row (coalesced f32x4 loads, all
+    // issued before anything waits).  Gain and bias are the same for every row: the workgroup copies them to LDS once, while the rows'
+    // statistics are being reduced.  Statistics as ggml_norm: f64 sums, mean and variance rounded to f32, then scale, gain, bias, f16;
+    // the four k of a piece land in four different kperm groups of the image (2-byte LDS writes).
     {
         const int lr = threadIdx.x >> 4, t16 = threadIdx.x & 15, row = my0 + lr;
-        const int ngrp = d >> 3;                                  // kperm groups per row; thread t16 takes groups t16, t16 + 16, ...
-        const float* xr = a.ln_x + (long)min(row, a.M - 1) * d;
-        constexpr int GMAX = 12;                                  // d <= 1536: 192 groups / 16 threads
-        float v[GMAX][8];
+        const int npc = d >> 2;                                   // 16-byte pieces per row
+        const f32x4* xr = (const f32x4*)(a.ln_x + (long)min(row, a.M - 1) * d);
+        constexpr int PMAX = 24;                                  // d <= 1536: 384 pieces / 16 threads
+        f32x4 v[PMAX];
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) { const int pi = t16 + 16 * j; v[j] = (pi < npc) ? xr[pi] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int i = threadIdx.x; i < npc; i += 256) { gb[i] = ((const f32x4*)a.ln_w)[i]; gb[npc + i] = ((const f32x4*)a.ln_b)[i]; }
         double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < GMAX; ++j) {
-            const int gi = t16 + 16 * j;
-            if (gi < ngrp) {
-                const float* xp = xr + (gi >> 2) * 32 + (gi & 3);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[j][e] = xp[4 * e];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < GMAX; ++j) if (t16 + 16 * j < ngrp) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (double)v[j][e];
-        }
+        for (int j = 0; j < PMAX; ++j) if (t16 + 16 * j < npc) { sum += (double)v[j][0]; sum += (double)v[j][1]; sum += (double)v[j][2]; sum += (double)v[j][3]; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const float mean = (float)(sum / (double)d);
         double sum2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < GMAX; ++j) if (t16 + 16 * j < ngrp) {
+        for (int j = 0; j < PMAX; ++j) if (t16 + 16 * j < npc) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float t = v[j][e] - mean; v[j][e] = t; sum2 += (double)(t * t); }
+            for (int e = 0; e < 4; ++e) { const float t = v[j][e] - mean; v[j][e] = t; sum2 += (double)(t * t); }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o, 64);
         const float variance = (float)(sum2 / (double)d);
         const float scale = 1.0f / sqrtf(variance + 1e-5f);
+        __syncthreads();                                          // gain / bias are in LDS
 #pragma unroll
-        for (int j = 0; j < GMAX; ++j) {
-            const int gi = t16 + 16 * j;
-            if (gi < ngrp) {
-                const int k0 = (gi >> 2) * 32 + (gi & 3);
-                f16x8 o;
+        for (int j = 0; j < PMAX; ++j) {
+            const int pi = t16 + 16 * j;
+            if (pi < npc) {
+                const f32x4 g4 = gb[pi], b4 = gb[npc + pi];
+                const int k0 = pi << 2, blk = k0 >> 5, q8 = (k0 >> 2) & 7;          // k = k0 + e sits at position 8 e + q8 of its 32-block: kperm group 4 blk + e
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float t = v[j][e] * scale; t = t * a.ln_w[k0 + 4 * e]; t = t + a.ln_b[k0 + 4 * e]; o[e] = f2h(t); }
-                *(f16x8*)(ya + lr * d + ((gi ^ (lr & 7)) << 3)) = o;
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[j][e] * scale; t = t * g4[e]; t = t + b4[e];
+                    const int grp = 4 * blk + e;
+                    ya[lr * d + ((grp ^ (lr & 7)) << 3) + q8] = f2h(t);
+                }
             }
         }
     }
