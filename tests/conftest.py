@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+# the oracle's OpenMP regions are many and short (a decode step is dozens): with spinning waits, any oversubscription of the host (a second
+# pytest, torch's own pool) turns every barrier into a scheduler quantum — a 50 s suite was seen to take half an hour.  Sleep instead.
+os.environ.setdefault("GOMP_SPINCOUNT", "100000")     # ~50 us of spinning, then sleep
 
 
 def pytest_configure(config):
