@@ -24,7 +24,8 @@
  *              q5_0, q8_0:    sumf += (dw * dy) * (float)sumi                     qw = 5-bit - 16 / int8
  *              q4_1, q5_1:    sumf += ((dw * dy) * (float)sumi + mw * sy)         qw = nibble / 5-bit, unsigned
  *      every product and sum rounded to f32 separately (no contraction).  What cannot be restated is the SIMD build's order of the
- *      block sums (AVX2 keeps eight partial sums): like D3 this is a chain of our choosing, block-ascending.  get_rows on the
+ *      block sums (AVX2 keeps eight partial sums): like D3 this is a chain of our choosing, block-ascending — in the one-token decoder
+ *      graph cut into four contiguous runs of blocks whose partial sums are added in ascending order (D3', as for f16 weights).  get_rows on the
  *      quantised token embedding dequantises (q * d, + m) to f32 without rounding to f16.
  *
  *  (b) the dequantised f16 twin — what the f16_mfma precision runs, and what SKW_QUANT_TWIN=1 / quant_mode 0 selects everywhere:

@@ -460,23 +460,28 @@ static void gemm_chain_seg4(const float* A, long lda, int M, const float* Wt, lo
     free(t);
 }
 /* ggml's quantised mul_mat (include/skw_ggml_quant.h (a)): rows of A (f32, NOT rounded to f16) -> q8 blocks, block-ascending chain of integer dots */
-static void linear_q8(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
-    const int K = L->n_in, nb = K / 32, N = L->n_out, form = skw_ggml_dot_form(L->qtype);
+static void linear_q8_seg(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo, int nseg) {
+    const int K = L->n_in, nb = K / 32, N = L->n_out, form = skw_ggml_dot_form(L->qtype); const int bps = nb / nseg;   /* blocks per segment */
     int8_t* qa = (int8_t*)malloc((size_t)rows * K); float* da = xmalloc_f((size_t)rows * nb); float* sa = xmalloc_f((size_t)rows * nb);
 #pragma omp parallel for schedule(static)
     for (int r = 0; r < rows; ++r) for (int b = 0; b < nb; ++b) skw_ggml_quantize_q8_block(A + (long)r * lda + b * 32, qa + ((size_t)r * nb + b) * 32, &da[(size_t)r * nb + b], &sa[(size_t)r * nb + b]);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < rows; ++r) for (int n = 0; n < N; ++n) {
         const int8_t* x = qa + (size_t)r * K; const int8_t* w = L->qw + (size_t)n * K;
-        float sumf = 0.0f;
-        for (int b = 0; b < nb; ++b) {
-            int sumi = 0; for (int j = 0; j < 32; ++j) sumi += (int)w[b * 32 + j] * (int)x[b * 32 + j];
-            sumf = skw_ggml_block_dot(form, sumf, sumi, L->qd[(size_t)n * nb + b], L->qm[(size_t)n * nb + b], da[(size_t)r * nb + b], sa[(size_t)r * nb + b]);
+        float total = 0.0f;
+        for (int sg = 0; sg < nseg; ++sg) {       /* nseg == 1: ggml's single block-ascending sum; 4: the decoder's segmented form (D3'), added in ascending order */
+            float sumf = 0.0f;
+            for (int b = sg * bps; b < (sg + 1) * bps; ++b) {
+                int sumi = 0; for (int j = 0; j < 32; ++j) sumi += (int)w[b * 32 + j] * (int)x[b * 32 + j];
+                sumf = skw_ggml_block_dot(form, sumf, sumi, L->qd[(size_t)n * nb + b], L->qm[(size_t)n * nb + b], da[(size_t)r * nb + b], sa[(size_t)r * nb + b]);
+            }
+            total = sg == 0 ? sumf : total + sumf;
         }
-        out[(long)r * ldo + n] = sumf;
+        out[(long)r * ldo + n] = total;
     }
     free(qa); free(da); free(sa);
 }
+static void linear_q8(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) { linear_q8_seg(A, lda, rows, L, out, ldo, 1); }
 /* test hook: out [rows][n_out] = ggml's quantised mul_mat of A [rows][n_in] f32 with n_out * n_in / 32 blocks of the given type */
 int skwo_debug_linear_q8(int type, const uint8_t* blocks, int n_out, int n_in, const float* A, int rows, float* out) {
     const size_t bb = skw_ggml_block_bytes(type); if (!bb || n_in % 32) return -1;
@@ -497,7 +502,11 @@ static void linear(const float* A, long lda, int rows, const lin_t* L, float* ou
 
 /* the decoder's projections: segmented contraction (f16 weights) or ggml's q8 arithmetic (quantised files), then the bias */
 static void linear_dec(const float* A, long lda, int rows, const lin_t* L, float* out, long ldo) {
-    if (L->qw) { linear(A, lda, rows, L, out, ldo); return; }
+    if (L->qw) {   /* quantised weights: the block sums of the decoder's products are segmented the same way (four contiguous runs of blocks) */
+        linear_q8_seg(A, lda, rows, L, out, ldo, (L->n_in % 128) ? 1 : 4);
+        if (L->b) for (int r = 0; r < rows; ++r) { float* o = out + (long)r * ldo; for (int i = 0; i < L->n_out; ++i) o[i] = o[i] + L->b[i]; }
+        return;
+    }
     gemm_chain_seg4(A, lda, rows, L->wt, L->n_out, L->n_out, L->n_in, out, ldo);
     if (L->b) for (int r = 0; r < rows; ++r) { float* o = out + (long)r * ldo; for (int i = 0; i < L->n_out; ++i) o[i] = o[i] + L->b[i]; }
 }
@@ -674,7 +683,7 @@ static void dec_one(skwo_dec* s, int token, int pos, float* logits) {
     }
     if (logits) {
         layer_norm(x, 1, d, &m->d_ln, y); if (!m->quant) for (int i = 0; i < d; ++i) y[i] = skw_round_f16(y[i]);
-        if (m->d_te_lin.qw) linear_q8(y, d, 1, &m->d_te_lin, logits, m->hp.n_vocab);
+        if (m->d_te_lin.qw) linear_q8_seg(y, d, 1, &m->d_te_lin, logits, m->hp.n_vocab, (d % 128) ? 1 : 4);
         else gemm_chain_seg4(y, d, 1, m->d_te_lin.wt, m->d_te_lin.n_out, m->hp.n_vocab, d, logits, m->hp.n_vocab);
     }
 }

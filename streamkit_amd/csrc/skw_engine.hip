@@ -546,9 +546,10 @@ static void Q8_LN(skw_ctx* c, const float* x, int M, int d, const DevLN& ln, int
     { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(x, M, d, ln.w, ln.b, nullptr, y32, c->cur); }
     Q8_ROWS(c, y32, d, M, d, r0);
 }
-static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0) {
+static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0, bool decoder = false) {
     a.K = L.n_in; a.N = L.n_out; a.bias = L.b;
-    SkwQ8Args qa{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), L.qw, L.dwT, L.mwT, L.n_pad, L.qform};
+    SkwQ8Args qa{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), L.qw, L.dwT, L.mwT, L.n_pad, L.qform,
+                 decoder && !(L.n_in & 127) ? 1 : 0};
     ProfScope p(c, a.M <= 64 ? PC_GEMM_SMALL : PC_GEMM, 2.0 * a.M * a.N * a.K, 1.0 * a.M * a.K + 1.0 * a.N * a.K + 4.0 * a.M * a.N);
     skw_gemm_q8(a, qa, c->cur);
 }
@@ -686,24 +687,24 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
             half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
             Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
-            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
             { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt);
               SkwQ8Out qo{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), Bw};
               skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo); }
-            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.cross_ln, r0, dy32);
-            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0, true); }
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
             Q8_ROWS(c, datt32, dt, Bw, dt, r0);
-            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.mlp_ln, r0, dy32);
-            { SkwGemmArgs a = q8_args(Bw, dh32, 4L * dt, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dh32, 4L * dt, EPI_GELU_F32); a.gelu_tab = m->gelu_tab; Q8_GEMM(c, a, L.fc1, r0, true); }
             Q8_ROWS(c, dh32, 4L * dt, Bw, 4 * dt, r0);
-            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.fc2, r0); }
+            { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.fc2, r0, true); }
         }
         if (want_logits) {
             Q8_LN(c, dx, Bw, dt, m->d_ln, r0, dy32);
-            SkwGemmArgs a = q8_args(Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); Q8_GEMM(c, a, m->te, r0);
+            SkwGemmArgs a = q8_args(Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); Q8_GEMM(c, a, m->te, r0, true);
         }
         c->cur = c->stream;
         return;

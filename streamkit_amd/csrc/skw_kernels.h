@@ -85,7 +85,8 @@ void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int*
 // ggml's arithmetic for block-quantised files (skw_kernels_q8.hip)
 struct SkwQ8Out { int8_t* q; float* dT; float* sT; int M; };   // where a producer leaves its rows as q8 blocks (q == nullptr: it does not)
 struct SkwQ8Args { const int8_t* qa; const float* dyT; const float* syT;        // activations: int8 [M][K], scales [K/32][M]
-                   const int8_t* qw; const float* dwT; const float* mwT; int n_pad; int form; };   // weights: int8 [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
+                   const int8_t* qw; const float* dwT; const float* mwT; int n_pad; int form;
+                   int segmented; };   // segmented: the decoder's form — four contiguous runs of blocks, partial sums added in ascending order (D3'); needs K % 128 == 0   // weights: int8 [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
 void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s);
 bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s);
 void skw_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);

@@ -122,48 +122,58 @@ __global__ __launch_bounds__(256) void k_gemm_q8(SkwGemmArgs a, SkwQ8Args qa) {
             for (int r = 0; r < 4; ++r) { const int n = n0 + i * 16 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[i][j][r]); }
         }
 }
-// the decode step's shape (M <= 64 rows): a 64 x 64 tile per workgroup would put N / 64 = 12 workgroups on the chip.  Here a workgroup is one
-// 16-feature strip, wave w takes rows 16w .. 16w + 15 with the whole block-ascending chain (the order is part of the result: no split over K).
-template <int EPI, int FORM>
+// The decode step's shape (M <= 128 rows).  A workgroup is one 16-feature strip x one 16-row tile; the block sum is cut into FOUR contiguous
+// runs of blocks (the decoder's segmented contraction, D3' / D4: oracle linear_q8_seg), wave s chains run s block-ascending from zero with all of
+// its operands requested up front (six blocks at K = 768), the partial sums meet in LDS and wave 0 adds them ((s0 + s1) + s2) + s3.
+template <int EPI, int FORM, int UB>
 __global__ __launch_bounds__(256) void k_gemm_q8_small(SkwGemmArgs a, SkwQ8Args qa) {
+    __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 64 + w * 16, n0 = blockIdx.x * 16;
-    if (m0 >= a.M) return;
-    const int nb = a.K >> 5, mrow = min(m0 + r16, a.M - 1);
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int nb = a.K >> 5, bps = nb >> 2, b_lo = w * bps, mrow = min(m0 + r16, a.M - 1);      // host guarantees K % 128 == 0
     const int8_t* wp = qa.qw + (long)min(n0 + r16, a.N - 1) * a.K + g * 8;
     const int8_t* ap = qa.qa + (long)mrow * a.K + g * 8;
+    const int nq = min(n0 + 4 * g, qa.n_pad - 4);
     float sumf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int U = 4;                                           // blocks whose operands are requested together
-    for (int b0 = 0; b0 < nb; b0 += U) {
-        long fw[U], fa[U]; f32x4 dw[U], mw[U]; float dy[U], sy[U];
+    for (int b0 = 0; b0 < bps; b0 += UB) {
+        long fw[UB], fa[UB]; f32x4 dw[UB], mw[UB]; float dy[UB], sy[UB];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = min(b0 + u, nb - 1);
+        for (int u = 0; u < UB; ++u) {
+            const int b = b_lo + min(b0 + u, bps - 1);
             fw[u] = *(const long*)(wp + b * 32); fa[u] = *(const long*)(ap + b * 32);
-            dw[u] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + n0 + 4 * g);
-            if (FORM == 3) mw[u] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + n0 + 4 * g);
+            dw[u] = *(const f32x4*)(qa.dwT + (long)b * qa.n_pad + nq);
+            if (FORM == 3) mw[u] = *(const f32x4*)(qa.mwT + (long)b * qa.n_pad + nq);
             dy[u] = qa.dyT[(long)b * a.M + mrow];
             if (FORM == 3) sy[u] = qa.syT[(long)b * a.M + mrow];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (b0 + u >= nb) break;
+        for (int u = 0; u < UB; ++u) {
+            if (b0 + u >= bps) break;
             const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[u], fa[u], (i32x4){0, 0, 0, 0}, 0, 0, 0);
             q8_update4<FORM>(sumf, si, dw[u], FORM == 3 ? mw[u] : (f32x4){0.f, 0.f, 0.f, 0.f}, dy[u], FORM == 3 ? sy[u] : 0.0f);
         }
     }
+    red[w][lane] = (f32x4){sumf[0], sumf[1], sumf[2], sumf[3]};
+    __syncthreads();
+    if (w != 0) return;
+    const f32x4 s1 = red[1][lane], s2 = red[2][lane], s3 = red[3][lane];
     const int m = m0 + r16;
     if (m >= a.M) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int n = n0 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[r]); }
+    for (int r = 0; r < 4; ++r) {
+        float v = sumf[r] + s1[r]; v = v + s2[r]; v = v + s3[r];
+        const int n = n0 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, v);
+    }
+}
+template <int EPI, int FORM> static void launch_gemm_q8_small(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
+    const dim3 gs((a.N + 15) / 16, (a.M + 15) / 16); const int bps = (a.K >> 5) >> 2;
+    if (bps <= 6) hipLaunchKernelGGL((k_gemm_q8_small<EPI, FORM, 6>), gs, dim3(256), 0, s, a, qa);
+    else hipLaunchKernelGGL((k_gemm_q8_small<EPI, FORM, 8>), gs, dim3(256), 0, s, a, qa);
 }
 template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
-    if (a.M <= 128) {
-        const dim3 gs((a.N + 15) / 16, (a.M + 63) / 64);
-        if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8_small<EPI, 1>), gs, dim3(256), 0, s, a, qa);
-        else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8_small<EPI, 2>), gs, dim3(256), 0, s, a, qa);
-        else hipLaunchKernelGGL((k_gemm_q8_small<EPI, 3>), gs, dim3(256), 0, s, a, qa);
+    if (qa.segmented) {                     // the decoder's products
+        if (qa.form == 1) launch_gemm_q8_small<EPI, 1>(a, qa, s); else if (qa.form == 2) launch_gemm_q8_small<EPI, 2>(a, qa, s); else launch_gemm_q8_small<EPI, 3>(a, qa, s);
         return;
     }
     static const int tw_env = getenv("SKW_Q8_TW") ? atoi(getenv("SKW_Q8_TW")) : 4;
@@ -180,7 +190,7 @@ template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8A
     else hipLaunchKernelGGL((k_gemm_q8<EPI, 3, 2>), grid, dim3(256), 0, s, a, qa);
 }
 bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s) {
-    if ((a.K & 31) || qa.form < 1 || qa.form > 3) return false;
+    if ((a.K & 31) || qa.form < 1 || qa.form > 3 || (qa.segmented && ((a.K & 127) || a.M > 4096))) return false;
     switch (a.epi) {
         case EPI_F32: launch_gemm_q8<EPI_F32>(a, qa, s); return true;
         case EPI_GELU_F32: launch_gemm_q8<EPI_GELU_F32>(a, qa, s); return true;
