@@ -7,10 +7,12 @@
 // (/root/reference/plugins/native/whisper/src/lib.rs:114-116), so this is the arithmetic its default configuration runs.
 //
 //   k_q8_quantize   f32 rows -> int8 values [M][K] + per-block d (f16-rounded) and s = f16(d_unrounded * sum q), stored [K/32][M]
-//   k_gemm_q8<EPI>  64 x 64 output tile per workgroup, four waves of 32 x 32; per 32-block one v_mfma_i32_16x16x32_i8 per 16 x 16
-//                   sub-tile gives the sixteen-by-sixteen integer dots, the block's scales come in as 16-byte loads from the
-//                   transposed scale tables, and the f32 update of skw_ggml_block_dot runs on the VALU (the path is VALU-bound: ~10
-//                   f32 operations per integer dot of 32, which is why it is ~3x the f16 MFMA path and still 2x faster than the f32 chains)
+//   k_gemm_q8_lds   the encoder's products: 128 x 128 tile per workgroup, operands and scales staged through LDS by LDS-DMA (two stage buffers),
+//                   per 32-block one v_mfma_i32_16x16x32_i8 per 16 x 16 sub-tile gives the sixteen-by-sixteen integer dots and the f32 update
+//                   of skw_ggml_block_dot runs on the VALU, packed two features per instruction (the path is VALU-bound: ~14 instructions per
+//                   integer dot of 16 x 16 x 32)
+//   k_gemm_q8<TW>   the same fed from global memory (tails, geometries the staged form does not take)
+//   k_gemm_q8_small the decoder's products: four waves = the four runs of the segmented block sum (D3')
 // The weights are the MFMA's first operand as everywhere else: a lane ends with four adjacent features of one row.
 #include <hip/hip_runtime.h>
 #include "skw_dev_common.h"
@@ -122,6 +124,99 @@ __global__ __launch_bounds__(256) void k_gemm_q8(SkwGemmArgs a, SkwQ8Args qa) {
             for (int r = 0; r < 4; ++r) { const int n = n0 + i * 16 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[i][j][r]); }
         }
 }
+// The encoder's shape, staged through LDS.  Same tile (128 x 128 per workgroup, four waves of 64 x 64) and the same arithmetic as k_gemm_q8<.., 4>,
+// but the operands of two 32-blocks at a time — 64 bytes of every A and W row of the tile and the four scale / offset rows — arrive by LDS-DMA
+// (global_load_lds, 16 B per lane, no registers in between) into one of two stage buffers while the other is being consumed, so a wave never
+// waits on HBM / L2 with its 64 running sums idle.  A stage is [A 128 x 64 B][W 128 x 64 B][dw 2 x 128][mw 2 x 128][dy 2 x 128][sy 2 x 128] = 20 KB;
+// the 16-byte pieces of a row are stored at piece ^ ((row >> 2) & 3) (by permuting which global piece a lane fetches), which spreads the sixteen
+// rows of an 8-byte fragment read over all banks.  Requires N % 128 == 0, K % 64 == 0, M % 4 == 0 (every Whisper encoder product).
+typedef __attribute__((address_space(1))) const void* q8_gptr_t;
+typedef __attribute__((address_space(3))) void* q8_lptr_t;
+template <int EPI, int FORM>
+__global__ __launch_bounds__(256) void k_gemm_q8_lds(SkwGemmArgs a, SkwQ8Args qa) {
+    constexpr int STAGE = 128 * 64 * 2 + 4 * 2 * 128 * 4;                    // 20480 bytes
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128, wm = w >> 1, wn = w & 1;
+    const int nbg = a.K >> 6;                                                 // stages: two 32-blocks each
+    // DMA sources.  Operand tiles: DMA instruction q (0..7; wave w issues q = 2w, 2w + 1) covers tile rows 16q .. 16q + 15: lane -> row 16q + (lane >> 2),
+    // LDS piece lane & 3, which must hold global piece (lane & 3) ^ ((row >> 2) & 3).
+    const int8_t* srcA[2]; const int8_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * w + i) * 16 + (lane >> 2), piece = (lane & 3) ^ ((row >> 2) & 3);
+        srcA[i] = qa.qa + (long)min(m0 + row, a.M - 1) * a.K + piece * 16;
+        srcW[i] = qa.qw + (long)min(n0 + row, a.N - 1) * a.K + piece * 16;
+    }
+    // scale tables: wave 0 -> dw, 1 -> mw, 2 -> dy, 3 -> sy; lanes 0-31 fetch the first block's 128 values, lanes 32-63 the second block's
+    const int sc_blk = lane >> 5, sc_col = (lane & 31) * 4;
+    const float* sc_src; long sc_stride;
+    if (w < 2) { sc_src = (w == 0 ? qa.dwT : qa.mwT) + n0 + sc_col; sc_stride = qa.n_pad; }
+    else { sc_src = (w == 2 ? qa.dyT : qa.syT) + min(m0 + sc_col, a.M - 4); sc_stride = a.M; }
+    auto stage = [&](int buf, int bg) {
+        char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((q8_gptr_t)(srcA[i] + bg * 64), (q8_lptr_t)(base + (2 * w + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((q8_gptr_t)(srcW[i] + bg * 64), (q8_lptr_t)(base + 8192 + (2 * w + i) * 1024), 16, 0, 0);
+        }
+        if (FORM == 3 || (w != 1 && w != 3))
+            __builtin_amdgcn_global_load_lds((q8_gptr_t)(sc_src + (long)(2 * bg + sc_blk) * sc_stride), (q8_lptr_t)(base + 16384 + w * 1024), 16, 0, 0);
+    };
+    // fragment offsets inside a stage: row * 64 + ((piece ^ ((row >> 2) & 3)) << 4) + (g & 1) * 8, piece = 2 * blk + (g >> 1)
+    int offA[4], offW[4], colA[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ra = wm * 64 + t * 16 + r16, rw = wn * 64 + t * 16 + r16;
+        offA[t] = ra * 64 + (g & 1) * 8; offW[t] = 8192 + rw * 64 + (g & 1) * 8; colA[t] = ra;
+    }
+    const int swA = (r16 >> 2) & 3;                                           // ((row >> 2) & 3) is the same for every 16-row tile of the wave: rows t * 16 + r16 with 16 | 16 t
+    float sumf[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sumf[i][j][r] = 0.0f;
+    stage(0, 0);
+    for (int bg = 0; bg < nbg; ++bg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (bg + 1 < nbg) stage((bg + 1) & 1, bg + 1);
+        const char* base = lds + (bg & 1) * STAGE;
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+            long fw[4], fa[4]; f32x4 dw[4], mw[4]; float dy[4], sy[4];
+            const int pc = (((2 * bl + (g >> 1)) ^ swA) << 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = *(const long*)(base + offA[t] + pc); fw[t] = *(const long*)(base + offW[t] + pc);
+                dw[t] = *(const f32x4*)(base + 16384 + (bl * 128 + wn * 64 + t * 16 + 4 * g) * 4);
+                if (FORM == 3) mw[t] = *(const f32x4*)(base + 16384 + 1024 + (bl * 128 + wn * 64 + t * 16 + 4 * g) * 4);
+                dy[t] = *(const float*)(base + 16384 + 2048 + (bl * 128 + colA[t]) * 4);
+                if (FORM == 3) sy[t] = *(const float*)(base + 16384 + 3072 + (bl * 128 + colA[t]) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i32x4 si = __builtin_amdgcn_mfma_i32_16x16x32_i8(fw[i], fa[j], (i32x4){0, 0, 0, 0}, 0, 0, 0);     // D[n = 4g + r][m = r16]
+                    q8_update4<FORM>(sumf[i][j], si, dw[i], FORM == 3 ? mw[i] : (f32x4){0.f, 0.f, 0.f, 0.f}, dy[j], FORM == 3 ? sy[j] : 0.0f);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + r16;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int n = n0 + wn * 64 + i * 16 + 4 * g + r; if (n < a.N) q8_store<EPI>(a, m, n, sumf[i][j][r]); }
+        }
+}
+
 // The decode step's shape (M <= 128 rows).  A workgroup is one 16-feature strip x one 16-row tile; the block sum is cut into FOUR contiguous
 // runs of blocks (the decoder's segmented contraction, D3' / D4: oracle linear_q8_seg), wave s chains run s block-ascending from zero with all of
 // its operands requested up front (six blocks at K = 768), the partial sums meet in LDS and wave 0 adds them ((s0 + s1) + s2) + s3.
@@ -177,6 +272,14 @@ template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8A
         return;
     }
     static const int tw_env = getenv("SKW_Q8_TW") ? atoi(getenv("SKW_Q8_TW")) : 4;
+    static const int lds_env = getenv("SKW_Q8_LDS") ? atoi(getenv("SKW_Q8_LDS")) : 1;
+    if (lds_env && tw_env == 4 && a.M >= 1024 && !(a.N & 127) && !(a.K & 63) && !(a.M & 3)) {
+        const dim3 grid(a.N / 128, (a.M + 127) / 128);
+        if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 1>), grid, dim3(256), 0, s, a, qa);
+        else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 2>), grid, dim3(256), 0, s, a, qa);
+        else hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 3>), grid, dim3(256), 0, s, a, qa);
+        return;
+    }
     if (tw_env == 4 && a.M >= 1024) {
         const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
         if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1, 4>), grid, dim3(256), 0, s, a, qa);
