@@ -522,7 +522,8 @@ static void softmax_row2(float* s, int n, float scale, float* omax, float* oinv)
     for (int i = 0; i < n; ++i) { float v = skw_expf(s[i] - mx); s[i] = v; sum += (double)v; }
     const float inv = (float)(1.0 / sum);
     for (int i = 0; i < n; ++i) s[i] = s[i] * inv;
-    if (omax) *omax = mx; if (oinv) *oinv = inv;
+    if (omax) *omax = mx;
+    if (oinv) *oinv = inv;
 }
 
 /* --------------------------------------------- K2: conv stem (+pos emb) */
