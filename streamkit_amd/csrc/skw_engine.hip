@@ -540,8 +540,8 @@ static void Q8_ROWS(skw_ctx* c, const float* act32, long lda, int M, int K, int 
     ProfScope p(c, PC_LAYERNORM, 0, 5.0 * M * K);
     skw_q8_quantize(act32, lda, M, K, c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), c->cur);
 }
-// LayerNorm -> f32 rows -> q8 blocks (a LayerNorm kernel that quantises its own rows, one wave per row with half-wave reductions per block,
-// was measured slower than the two launches: 372 vs 356 ms of decode per batch, 189 vs 184 ms of encode)
+// LayerNorm -> f32 rows -> q8 blocks.  (A LayerNorm kernel that quantises its own rows was measured slower than the two launches, twice: one wave
+// then owns a whole row's 24 blocks — 266 - 298 vs 243 ms of decode per batch — where the quantiser has a thread per block.)
 static void Q8_LN(skw_ctx* c, const float* x, int M, int d, const DevLN& ln, int r0, float* y32) {
     { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * M * d); skw_layernorm(x, M, d, ln.w, ln.b, nullptr, y32, c->cur); }
     Q8_ROWS(c, y32, d, M, d, r0);
