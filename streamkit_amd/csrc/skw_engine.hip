@@ -727,8 +727,14 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
           a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
-        { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
+        // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
+        bool fused_q = false;
+        if (!tail && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
+            fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
+        if (!fused_q) {
+            { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
+        }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s, tail); }
         { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;

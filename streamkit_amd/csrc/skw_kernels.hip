@@ -981,25 +981,34 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // 16-byte load = 8 keys of one channel), B = p broadcast to every column, so each output channel is the same key-ascending fma chain
 // as the scalar form; an 8-deep ring keeps V^T in flight (4 .. 16 deep measure the same within 2 %).  HBM-bound: 55.3 MB per sequence per step over all layers.
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
-template <int MAXT, int WPH, int HPW>
+// FQ: the kernel also makes its own query.  The LayerNorm of the sequence's residual row (K3: the block-wide form of skw_ln_rows, same
+// operations per element, f64 sums) and the query projection of the workgroup's heads run in front of the score passes: lane = output
+// channel, wave s of a head = K segment s of the decoder's segmented contraction (D3'), each a k-ascending v_fma_mix chain, the four
+// partial sums added ((s0 + s1) + s2) + s3, bias, scale, f16 — oracle/skw_oracle.c gemm_chain_seg4, bit for bit.  The weight rows of a
+// head (64 rows x 128 B per step) arrive the way K rows do — coalesced into the ring registers, transposed through the wave's LDS slab —
+// and the K ring is refilled as its slots drain: two launches (LayerNorm, a 64 x 768 x 768 product: 10.4 us of a 125 us layer) become a prologue —
+// which measured 14.6 us (the HBM stream idles behind it on every CU at once), so the form is opt-in (skw_dec_cross_attn_vt_q_ok).
+// In both precisions the query is this exact chain.  Needs WPH == 4, d % 128 == 0, d <= 1536.
+struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
+template <int MAXT, int WPH, int HPW, bool FQ = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
-                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out) {
+                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq) {
     if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
     __shared__ float smax[HPW][WPH];
     __shared__ double ssum[HPW][WPH];
+    __shared__ __attribute__((aligned(16))) half_t xln[FQ ? 1536 : 8];           // LayerNorm(x[b]) as f16, kperm order (what k_layernorm writes)
+    __shared__ float qred[FQ ? HPW : 1][4][64];
+    __shared__ __attribute__((aligned(16))) half_t qown[FQ ? HPW * WPH : 1][64];
+    __shared__ double lnred[HPW * WPH];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
     const int hraw = blockIdx.x * HPW + hs, b = blockIdx.y;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
     const half_t* K = kbase + (long)b * k_batch_stride + h * 64;
+    auto ldk16 = [&](const half_t* p) -> u32x4 { return *(const u32x4*)p; };   // (non-temporal loads of the once-read K / V^T bytes measured 2 us slower per launch: 62.7 vs 60.4)
     H8v qh[8];                                  // q stays packed (32 VGPRs instead of 64); converted in the chain's shadow
-    {
-        const u32x4* qp = (const u32x4*)(q + (long)b * ldq + h * 64);
-#pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = qp[c8];
-    }
     const int nt = (n_ctx + 63) >> 6, nth = (nt + WPH - 1) / WPH;
     const int t_lo = half * nth, t_hi = min(nt, t_lo + nth);
     float lmax = -INFINITY;
@@ -1007,17 +1016,110 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     float* pl = plds[hs];
     const int lrow = lane >> 3, lseg = lane & 7;
     u32x4 k0[8], k1[8], k2[8];
+    auto kfill = [&](u32x4 (&dst)[8], int t) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) k0[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 8; ++i) dst[i] = ldk16(K + (long)min(t * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (!FQ) {
+        const u32x4* qp = (const u32x4*)(q + (long)b * ldq + h * 64);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) k1[i] = *(const u32x4*)(K + (long)min(t_lo * 64 + 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = qp[c8];
+        kfill(k0, t_lo); kfill(k1, t_lo + 1);
+    } else {
+        static_assert(!FQ || WPH == 4, "one wave per K segment");
+        constexpr int NTH = 64 * HPW * WPH, NSL = (1536 + NTH - 1) / NTH;
+        const int d = xq.d, tid = threadIdx.x, nkq = d >> 7, nst = (nkq + 1) >> 1;   // 32-blocks per segment; steps of two blocks (one 128-byte line per weight row)
+        // the row, its gain and bias: one element per thread (two past d = 768)
+        float xv[NSL], gw[NSL], gb[NSL];
+        { const float* xr = xq.x + (long)b * d;
+#pragma unroll
+          for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; const bool in = i < d; xv[c] = in ? xr[i] : 0.0f; gw[c] = in ? xq.ln_w[i] : 0.0f; gb[c] = in ? xq.ln_b[i] : 0.0f; } }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's weight rows (channel = 64 h + i*8 + lrow, 16-byte piece lseg of the step's 128 bytes); a step's second block may lie past the segment: it is fetched from inside the row and not used
+        const char* Wseg = (const char*)(xq.W + (long)(h * 64) * xq.ldw + half * nkq * 32);      // wave-uniform base + one 32-bit lane offset: eight loads share the address registers
+        const unsigned wlo = (unsigned)((lrow * (int)xq.ldw + (lseg & 3) * 8) * 2);
+        auto wfill = [&](u32x4 (&dst)[8], int t) {
+            const unsigned off = wlo + (unsigned)min(2 * t + (lseg >> 2), nkq - 1) * 64u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = *(const u32x4*)(Wseg + (long)i * 16 * xq.ldw + off);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        wfill(k0, 0); if (nst > 1) wfill(k1, 1); if (nst > 2) wfill(k2, 2);
+        // LayerNorm of the row by the whole workgroup
+        double sm = 0.0;
+#pragma unroll
+        for (int c = 0; c < NSL; ++c) sm += (double)xv[c];
+        sm = wave_sum_f64(sm);
+        if (lane == 0) lnred[w] = sm;
+        __syncthreads();
+        sm = 0.0;
+#pragma unroll
+        for (int i = 0; i < HPW * WPH; ++i) sm += lnred[i];
+        const float mean = (float)(sm / (double)d);
+        __syncthreads();
+        double sm2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; if (i < d) { const float t = xv[c] - mean; xv[c] = t; sm2 += (double)(t * t); } }
+        sm2 = wave_sum_f64(sm2);
+        if (lane == 0) lnred[w] = sm2;
+        __syncthreads();
+        sm2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < HPW * WPH; ++i) sm2 += lnred[i];
+        const float variance = (float)(sm2 / (double)d);
+        const float scl = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; if (i < d) { float t = xv[c] * scl; t = t * gw[c]; t = t + gb[c]; xln[skw_kperm(i)] = f2h(t); } }
+        __syncthreads();
+        // the chain: one step = 64 k of this wave's segment for all 64 channels
+        float qa = 0.0f;
+        const half_t* xs = xln + half * nkq * 32;
+        auto wstep = [&](int t, u32x4 (&cur)[8]) {
+            if (t < nst) {      // workgroup-uniform
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = cur[i];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (2 * t + u < nkq) {
+                        H8v wq[4], xq4[4];      // the activations are the same for every lane: they ride in SGPRs
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { wq[r].v = *(const u32x4*)(kl + lane * 72 + u * 32 + r * 8); const u32x4 xr4 = *(const u32x4*)(xs + (2 * t + u) * 32 + r * 8);
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) xq4[r].v[z] = __builtin_amdgcn_readfirstlane(xr4[z]); }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qa = __builtin_fmaf(h2f(xq4[r].h[e]), h2f(wq[r].h[e]), qa);     // logical k = 32 blk + 4 e + r, ascending
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        // a drained slot takes the segment's next weight step while there is one (d > 768), and in the last round the first two K passes
+        const int T = ((nst + 2) / 3) * 3;
+        for (int t0 = 0; t0 < T; t0 += 3) {
+            const bool last = t0 + 3 >= T;
+            wstep(t0, k0);     if (t0 + 3 < nst) wfill(k0, t0 + 3); else if (last) kfill(k0, t_lo);
+            wstep(t0 + 1, k1); if (t0 + 4 < nst) wfill(k1, t0 + 4); else if (last) kfill(k1, t_lo + 1);
+            wstep(t0 + 2, k2); if (t0 + 5 < nst) wfill(k2, t0 + 5);
+        }
+        qred[hs][half][lane] = qa;
+        __syncthreads();
+        { float v = qred[hs][0][lane] + qred[hs][1][lane]; v = v + qred[hs][2][lane]; v = v + qred[hs][3][lane];
+          if (xq.bias) v = v + xq.bias[h * 64 + lane];
+          v = v * xq.scale;
+          qown[w][lane] = f2h(v); }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = *(const u32x4*)(qown[w] + c8 * 8);
+    }
     // one pass = 64 keys: refill the free ring slot with pass t+2 first, then consume `cur`.  Roles rotate by name (three passes per
     // loop trip) so no register copies force early waits, and the scheduling barriers keep the loads where they are written.
     auto pass = [&](int t, u32x4 (&cur)[8], u32x4 (&fill)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fill[i] = *(const u32x4*)(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+        for (int i = 0; i < 8; ++i) fill[i] = ldk16(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
         __builtin_amdgcn_sched_barrier(0);
         if (t < t_hi) {       // wave-uniform
             const int key = t * 64 + lane;
@@ -1109,12 +1211,31 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
+    const SkwXQ none{};
     // heads per workgroup: 3 (256 workgroups of 12 waves at 64 rows x 12 heads: every CU)
     static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
-    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
-    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out);
+    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
+    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
+}
+// LayerNorm + query projection + cross attention in one launch (k_dec_cross_attn<.., FQ>): x f32 [B][d] residual rows, Wq f16 [d][ldw] kperm.
+// Returns false (nothing launched) for geometries the fused prologue does not cover; the caller then runs the three launches.
+bool skw_dec_cross_attn_vt_q_ok(int H, int d) {
+    // Off unless SKW_XATTN_FUSEQ=1: measured at B = 64, Whisper-small, the fused launch takes 75.0 us where the three launches take 4.9 + 5.5 + 60.4:
+    // the prologue (one row's LayerNorm across the workgroup, 3 weight steps through LDS, the 4-segment exchange) runs with the HBM stream not yet
+    // started, and every CU does it at the same time (one workgroup per CU, all in phase).  Kept: bit-identical to the oracle at every Whisper width
+    // (tests/test_gpu_parity.py::test_fused_query_cross_attention_matches_oracle).
+    static const bool on = getenv("SKW_XATTN_FUSEQ") && atoi(getenv("SKW_XATTN_FUSEQ")) != 0 && !getenv("SKW_XATTN_WPH") && !getenv("SKW_XATTN_HPW");
+    return on && !(d & 127) && d <= 1536 && d == H * 64;
+}
+bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
+                             const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s) {
+    if (!skw_dec_cross_attn_vt_q_ok(H, d)) return false;
+    const int as = (int)(sizeof(SkwSeqState) / 4);
+    const SkwXQ xq{x, ln_w, ln_b, Wq, ldw, bq, scale, d};
+    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, 0, xq);
+    return true;
 }
 
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8) {

@@ -161,6 +161,10 @@ int main(int argc, char** argv) {
             else if (!strcmp(s, "base")) { hp.n_audio_state = hp.n_text_state = 512; hp.n_audio_head = hp.n_text_head = 8; hp.n_audio_layer = hp.n_text_layer = 6; }
             else if (!strcmp(s, "small")) {}
             else if (!strcmp(s, "micro")) { hp.n_audio_state = hp.n_text_state = 128; hp.n_audio_head = hp.n_text_head = 2; hp.n_audio_layer = hp.n_text_layer = 2; }
+            /* one-layer models of the other Whisper widths (base 512, medium 1024, large 1280): geometry coverage for kernels whose loop structure depends on d */
+            else if (!strcmp(s, "w512")) { hp.n_audio_state = hp.n_text_state = 512; hp.n_audio_head = hp.n_text_head = 8; hp.n_audio_layer = hp.n_text_layer = 1; }
+            else if (!strcmp(s, "w1024")) { hp.n_audio_state = hp.n_text_state = 1024; hp.n_audio_head = hp.n_text_head = 16; hp.n_audio_layer = hp.n_text_layer = 1; }
+            else if (!strcmp(s, "w1280")) { hp.n_audio_state = hp.n_text_state = 1280; hp.n_audio_head = hp.n_text_head = 20; hp.n_audio_layer = hp.n_text_layer = 1; }
             else { fprintf(stderr, "unknown size %s\n", s); return 2; }
         } else if (!strcmp(argv[a], "--seed") && a + 1 < argc) g_seed = strtoull(argv[++a], NULL, 0);
         else if (!strcmp(argv[a], "--f32")) g_f16 = 0;
