@@ -31,19 +31,59 @@ union H8v { u32x4 v; half_t h[8]; };
 // Lane l owns elements l, l + 64, ... of each row (d <= 1536).  Statistics as ggml_norm: f64 sums over the row, mean and variance
 // rounded to f32, then scale, gain, bias; the f16 image is written in kperm order.  k_layernorm, the embedding kernel and the
 // LayerNorm tail of the decode GEMMs all call this, so every one of them produces the same bits for the same row.
-__device__ __forceinline__ double skw_wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions without the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 — an LDS round trip per level (two for a
+// double), six dependent levels per reduction: ~0.3 us, and a decode-step LayerNorm (4.9 us, launch included) does two.  Here the
+// four levels inside a row of 16 lanes are DPP moves (quad_perm [1,0,3,2] and [2,3,0,1], then row_half_mirror and row_mirror: after
+// the quad stages every lane of a quad holds the same value, so "the lane mirrored across the half row" is "the other quad"), and the
+// four row totals are read with v_readlane and combined as the xor-16 / xor-32 levels would: (r0 + r1) + (r2 + r3) — the same tree in
+// every lane, addition being commutative.  All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ int skw_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float skw_dpp_f32(float v) { return __int_as_float(skw_dpp_i32<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double skw_dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = skw_dpp_i32<CTRL>((int)(b & 0xffffffffll)), hi = skw_dpp_i32<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-template <int R>
-__device__ __forceinline__ void skw_ln_rows(float (&v)[R][24], const float (&wv)[24], const float (&bv)[24], int d, int lane, const bool (&live)[R], half_t* const (&out16)[R], float* const (&out32)[R]) {
+__device__ __forceinline__ double skw_readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double skw_wave_sum_f64(double v) {
+    v += skw_dpp_f64<0xB1>(v); v += skw_dpp_f64<0x4E>(v); v += skw_dpp_f64<0x141>(v); v += skw_dpp_f64<0x140>(v);
+    const double r0 = skw_readlane_f64(v, 0), r1 = skw_readlane_f64(v, 16), r2 = skw_readlane_f64(v, 32), r3 = skw_readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+// The xor-16 and xor-32 levels for values that differ per lane of a row (one query per lane): gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange odd rows of one register with even rows of another (upper and lower half waves for the 32 form); fed the same value twice they
+// leave (own row pair's even row, own row pair's odd row) in the two results, whose max / sum is what `op(v, __shfl_xor(v, 16))` gives.
+__device__ __forceinline__ float skw_rows_max_f32(float v) {      // max over the four lanes l, l ^ 16, l ^ 32, l ^ 48
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float skw_rows_sum_f32(float v) {      // (v[l] + v[l ^ 16]) + (v[l ^ 32] + v[l ^ 48]), the order of the two shuffle levels
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float skw_wave_max_f32(float v) {
+    v = fmaxf(v, skw_dpp_f32<0xB1>(v)); v = fmaxf(v, skw_dpp_f32<0x4E>(v)); v = fmaxf(v, skw_dpp_f32<0x141>(v)); v = fmaxf(v, skw_dpp_f32<0x140>(v));
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+template <int R, int NC = 24, bool FULL = false>     // NC slots of 64 elements per row: 12 covers d <= 768 with half the instructions (same operations on the live elements); FULL: d == 64 NC, no tail predicates
+__device__ __forceinline__ void skw_ln_rows(float (&v)[R][NC], const float (&wv)[NC], const float (&bv)[NC], int d, int lane, const bool (&live)[R], half_t* const (&out16)[R], float* const (&out32)[R]) {
     double sum[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         sum[r] = 0.0;
 #pragma unroll
-        for (int c = 0; c < 24; ++c) sum[r] += (double)v[r][c];
+        for (int c = 0; c < NC; ++c) sum[r] += (double)v[r][c];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) sum[r] = skw_wave_sum_f64(sum[r]);
@@ -53,7 +93,7 @@ __device__ __forceinline__ void skw_ln_rows(float (&v)[R][24], const float (&wv)
         const float mean = (float)(sum[r] / (double)d);
         sum2[r] = 0.0;
 #pragma unroll
-        for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; if (i < d) { const float t = v[r][c] - mean; v[r][c] = t; sum2[r] += (double)(t * t); } }
+        for (int c = 0; c < NC; ++c) { const int i = lane + 64 * c; if (FULL || i < d) { const float t = v[r][c] - mean; v[r][c] = t; sum2[r] += (double)(t * t); } }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) sum2[r] = skw_wave_sum_f64(sum2[r]);
@@ -63,9 +103,9 @@ __device__ __forceinline__ void skw_ln_rows(float (&v)[R][24], const float (&wv)
         const float scale = 1.0f / sqrtf(variance + 1e-5f);
         if (!live[r]) continue;
 #pragma unroll
-        for (int c = 0; c < 24; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int i = lane + 64 * c;
-            if (i < d) {
+            if (FULL || i < d) {
                 float t = v[r][c] * scale; t = t * wv[c]; t = t + bv[c];
                 v[r][c] = t;                                    // (left in place for callers that go on with the normalised row: k_layernorm_q8)
                 if (out16[r]) out16[r][skw_kperm(i)] = f2h(t);

@@ -331,25 +331,25 @@ __device__ __forceinline__ void att_store(half_t* out, long row_off, int col, fl
     if (f32_out) ((float*)out)[row_off + col] = v; else out[row_off + skw_kperm(col)] = f2h(v);
 }
 // ------------------------------------------------------------------ LayerNorm
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// one wave per row; d <= 1536
+__device__ __forceinline__ double wave_sum_f64(double v) { return skw_wave_sum_f64(v); }   // DPP + readlane, no LDS crossbar (skw_dev_common.h)
+// one wave per row; d <= 64 NC (NC = 12 for every width up to Whisper-small's, 24 up to 1536); FULL: d == 64 NC (Whisper-small: straight-line code, no tail predicates)
+template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long)row * d;
-    float v[1][24], wv[24], bv[24];
+    float v[1][NC], wv[NC], bv[NC];
     // the gain / bias loads go out together with the row (a 64-row decode launch is three dependent round trips otherwise)
 #pragma unroll
-    for (int c = 0; c < 24; ++c) { int i = lane + 64 * c; const bool in = i < d; v[0][c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
+    for (int c = 0; c < NC; ++c) { int i = lane + 64 * c; const bool in = FULL || i < d; v[0][c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
     const bool live[1] = {true}; half_t* const o16[1] = {out16 ? out16 + (long)row * d : nullptr}; float* const o32[1] = {out32 ? out32 + (long)row * d : nullptr};
-    skw_ln_rows<1>(v, wv, bv, d, lane, live, o16, o32);
+    skw_ln_rows<1, NC, FULL>(v, wv, bv, d, lane, live, o16, o32);
 }
 void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s) {
-    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+    const dim3 g((rows + 3) / 4);
+    if (d == 768) hipLaunchKernelGGL((k_layernorm<12, true>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+    else if (d <= 768) hipLaunchKernelGGL((k_layernorm<12, false>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+    else hipLaunchKernelGGL((k_layernorm<24, false>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
 }
 
 // ------------------------------------------------------------------ encoder attention (three-pass exact softmax)
@@ -819,29 +819,32 @@ __global__ void k_dec_embed(const half_t* te, const float* pe, const int* tok, c
     for (int i = threadIdx.x; i < d; i += blockDim.x) x[(long)b * d + i] = h2f(te[(long)tk * d + skw_kperm(i)]) + pe[(long)ps * d + i];
 }
 // the same with the first layer's LayerNorm attached: one wave per row, x written in passing (d <= 1536)
+template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void k_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const int tk = tok[row * (int)(sizeof(SkwSeqState) / 4)], ps = pos[row * (int)(sizeof(SkwSeqState) / 4)];
-    float v[1][24], wv[24], bv[24];
+    float v[1][NC], wv[NC], bv[NC];
 #pragma unroll
-    for (int c = 0; c < 24; ++c) {
-        const int i = lane + 64 * c; const bool in = i < d;
+    for (int c = 0; c < NC; ++c) {
+        const int i = lane + 64 * c; const bool in = FULL || i < d;
         v[0][c] = in ? h2f(te[(long)tk * d + skw_kperm(i)]) + pe[(long)ps * d + i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f;
         if (in) x[(long)row * d + i] = v[0][c];
     }
     const bool live[1] = {true}; half_t* const o16[1] = {y16 + (long)row * d}; float* const o32[1] = {nullptr};
-    skw_ln_rows<1>(v, wv, bv, d, lane, live, o16, o32);
+    skw_ln_rows<1, NC, FULL>(v, wv, bv, d, lane, live, o16, o32);
 }
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_embed, dim3(B), dim3(256), 0, s, te, pe, tok, pos, d, x);
 }
 void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_embed_ln, dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
+    if (d == 768) hipLaunchKernelGGL((k_dec_embed_ln<12, true>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
+    else if (d <= 768) hipLaunchKernelGGL((k_dec_embed_ln<12, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
+    else hipLaunchKernelGGL((k_dec_embed_ln<24, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
 }
 
 __device__ __forceinline__ float block_max(float v, float* sh) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = skw_wave_max_f32(v);
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) sh[w] = v;
     __syncthreads();
@@ -923,8 +926,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
             if (key < n_kv) { sc[t] = a; lmax = fmaxf(lmax, a); }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    lmax = skw_wave_max_f32(lmax);
     double lsum = 0.0;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) if (t * 64 < n_kv) { float e = skw_expf(sc[t] - lmax); sc[t] = e; lsum += (double)e; }
@@ -1154,8 +1156,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     for (int j = 0; j < RD; ++j)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (j < nkb) ? vo + ct * 16 * Tpad * 2 + j * 64 : 0x7fffff00u, 0, 0); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    lmax = skw_wave_max_f32(lmax);
     if (lane == 0) smax[hs][half] = lmax;
     __syncthreads();
     lmax = smax[hs][0];
@@ -1420,6 +1421,7 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
 // packed math; f64 partial sums are grouped differently, which the f64 accumulation makes immaterial (D1).
 #define SMP_PT 104
 #define SMP_NT 512      // 8 waves: 2 per SIMD, so the 104 resident logits fit the 256-VGPR budget
+#define SMP_TX 96       // stripes [0, SMP_TX) hold text tokens only in every Whisper vocabulary (tok_eot = 50256 / 50257 >= 96 * 512)
 struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; float top1, top2; };
 // element index of slot c: recomputed inside each pass from a value the optimiser cannot see through -- shared across passes, the
 // ~100 indices would stay live for the whole kernel and push the logits into scratch
@@ -1453,7 +1455,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     const float temperature = st->temperature;
     const int has_ts = st->has_ts; const int ts_lo = has_ts ? p.tok_beg + st->seek_delta / 2 : 0;
     auto bmax2 = [&](float a, float c2, float* oa, float* oc) {     // two block-wide maxima with one exchange
-        for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); c2 = fmaxf(c2, __shfl_xor(c2, o, 64)); }
+        a = skw_wave_max_f32(a); c2 = skw_wave_max_f32(c2);
         if (lane == 0) { sh_f[0][w] = a; sh_f[1][w] = c2; }
         __syncthreads();
         float ra = sh_f[0][0], rc = sh_f[1][0];
@@ -1486,11 +1488,29 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     }
     const bool last_ts = n_tok > 0 && last_id >= p.tok_beg;
     const bool pen_ts = n_tok < 2 || pen_id >= p.tok_beg;
+    // stripes [0, tx) hold text tokens only (every index below both tok_eot and tok_beg): there the index rules reduce to block-uniform
+    // conditions plus the blank rule's tok_space, and no pass needs a per-lane index compare — 98 of the 104 stripes of the multilingual vocabulary
+    constexpr int tx = SMP_TX;      // (compile-time: the index rules are then only compiled for the last SMP_PT - SMP_TX stripes; the host checks tok_eot, tok_beg >= SMP_TX * SMP_NT)
+    const bool text_all_killed = last_ts && !pen_ts;            // "a lone timestamp must be followed by a timestamp": every token below tok_eot goes
+    // (the blank rule's tok_space joins the static kill bits of the thread that owns it, so a text stripe's rule is one bit test: written with
+    //  index compares, hipcc turned the rules into 104 scalar lane masks, spilled through v_writelane, ~50 instructions and four branches per logit)
+    if (is_initial && p.suppress_blank) {
+        const int cs = p.tok_space / SMP_NT;
+        if (tid == p.tok_space % SMP_NT && cs < SMP_PT) { if (cs < 64) killbits[0] |= 1ull << cs; else killbits[1] |= 1ull << (cs - 64); }
+    }
+    if (text_all_killed) {      // (uniform)
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) if (c < tx) v[c] = -INFINITY;
+    }
     SMP_PASS_BEGIN
 #pragma unroll
     for (int c = 0; c < SMP_PT; ++c) {
         const int i = SMP_IDX(c);
         bool kill = (killbits[c >> 6] >> (c & 63)) & 1;
+        if (c < tx) {      // (uniform)
+            v[c] = kill ? -INFINITY : v[c];
+            continue;
+        }
         if (is_initial && p.suppress_blank && (i == p.tok_eot || i == p.tok_space)) kill = true;
         if (p.no_timestamps && i >= p.tok_beg) kill = true;
         if (last_ts) { if (pen_ts) { if (i >= p.tok_beg) kill = true; } else { if (i < p.tok_eot) kill = true; } }
@@ -1516,14 +1536,14 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     float m_ts = -INFINITY, max_text = -INFINITY;
     SMP_PASS_BEGIN
 #pragma unroll
-    for (int c = 0; c < SMP_PT; ++c) { const float lp = v[c] - lse; if (SMP_IDX(c) >= p.tok_beg) m_ts = fmaxf(m_ts, lp); else max_text = fmaxf(max_text, lp); }
+    for (int c = 0; c < SMP_PT; ++c) { const float lp = v[c] - lse; if (c < tx) max_text = fmaxf(max_text, lp); else if (SMP_IDX(c) >= p.tok_beg) m_ts = fmaxf(m_ts, lp); else max_text = fmaxf(max_text, lp); }
     SMP_PASS_END
     bmax2(m_ts, max_text, &m_ts, &max_text);
     double acc_ts = 0.0;
     SMP_PASS_BEGIN
 #pragma unroll
     for (int c = 0; c < SMP_PT; ++c) {
-        if (SMP_NT * (c + 1) > p.tok_beg) {     // (uniform) only the last few stripes reach the timestamp range
+        if (c >= tx && SMP_NT * (c + 1) > p.tok_beg) {     // (uniform) only the last few stripes reach the timestamp range
             const float e = skw_expf((v[c] - lse) - m_ts);
             if (SMP_IDX(c) >= p.tok_beg) acc_ts += (double)e;
         }
@@ -1535,39 +1555,65 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     if (force_ts) {
         SMP_PASS_BEGIN
 #pragma unroll
-        for (int c = 0; c < SMP_PT; ++c) if (SMP_IDX(c) < p.tok_beg) v[c] = -INFINITY;
+        for (int c = 0; c < SMP_PT; ++c) if (c < tx || SMP_IDX(c) < p.tok_beg) v[c] = -INFINITY;
         SMP_PASS_END
     }
-    // best token over probs = expf(logprob), first index wins ties; timestamp statistics; top-2 margin
+    // The two largest admissible logits and the owner of the largest (order-free; also the margin diagnostic).  exp is increasing and
+    // skw_expf follows it to a couple of ulps, so a logit more than 1e-4 below another has a strictly smaller probability (1e-4 is ~1700 ulps
+    // of the ratio): when the runner-up is that far down, the winner of "largest probability, first index on ties" is the owner of
+    // the largest logit, and the only exponentials the step still needs are the timestamp stripes' (their sum and their best).  Otherwise —
+    // a near-tie, or a temperature pass that needs every probability — the whole row goes through the pass, as before.  Same bits either way.
     const bool sampled = temperature > 0.0f;
     float* probs = probs_all + (long)b * NV;
-    SmpMain r; r.best = {0.0f, 0}; r.best_logit = -INFINITY; r.bts = {0.0f, 0x7fffffff}; r.sum_ts = 0.0; r.top1 = -INFINITY; r.top2 = -INFINITY;
+    float t1 = -INFINITY, t2 = -INFINITY; int i1 = 0;
+    SMP_PASS_BEGIN
+#pragma unroll
+    for (int c = 0; c < SMP_PT; ++c) { const float x = v[c]; const bool gt = x > t1; t2 = gt ? t1 : fmaxf(t2, x); i1 = gt ? c : i1; t1 = gt ? x : t1; }     // (selects, not branches; i1 counts stripes here)
+    i1 = SMP_IDX(i1);
+    SMP_PASS_END
+    for (int o = 32; o > 0; o >>= 1) {
+        const float o1 = __shfl_xor(t1, o, 64), o2 = __shfl_xor(t2, o, 64); const int oi = __shfl_xor(i1, o, 64);
+        if (o1 > t1 || (o1 == t1 && oi < i1)) { t2 = fmaxf(t1, o2); t1 = o1; i1 = oi; } else t2 = fmaxf(t2, o1);
+    }
+    __shared__ float sh_t1[SMP_NT / 64], sh_t2[SMP_NT / 64]; __shared__ int sh_i1[SMP_NT / 64];
+    if (lane == 0) { sh_t1[w] = t1; sh_t2[w] = t2; sh_i1[w] = i1; }
+    __syncthreads();
+    t1 = sh_t1[0]; t2 = sh_t2[0]; i1 = sh_i1[0];
+    for (int k = 1; k < SMP_NT / 64; ++k) { const float o1 = sh_t1[k], o2 = sh_t2[k]; const int oi = sh_i1[k];
+        if (o1 > t1 || (o1 == t1 && oi < i1)) { t2 = fmaxf(t1, o2); t1 = o1; i1 = oi; } else t2 = fmaxf(t2, o1); }
+    const bool fast = !sampled && (t1 - t2 > 1e-4f);           // (t2 == -inf: a single admissible token)
+    const int c_lo = fast ? tx : 0;
+    // best token over probs = expf(logprob), first index wins ties; timestamp statistics
+    SmpMain r; r.best = {0.0f, 0}; r.best_logit = -INFINITY; r.bts = {0.0f, 0x7fffffff}; r.sum_ts = 0.0; r.top1 = t1; r.top2 = t2;
     SMP_PASS_BEGIN
 #pragma unroll
     for (int c = 0; c < SMP_PT; c += 2) {
+        if (c < c_lo) continue;      // (uniform)
         const f32x2 e2 = expf_nonpos_x2((f32x2){v[c], v[c + 1]} - (f32x2){lse, lse});     // 0 for suppressed logits: they can win nothing below
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = SMP_IDX(c + u); const float x = v[c + u]; const float pr = e2[u];
             if (pr > r.best.v || (pr == r.best.v && i < r.best.i)) { r.best.v = pr; r.best.i = i; r.best_logit = x; }
-            if (i >= p.tok_beg) { r.sum_ts += (double)pr; if (pr > r.bts.v || (pr == r.bts.v && pr > 0.0f && i < r.bts.i)) { r.bts.v = pr; r.bts.i = i; } }
-            if (x > r.top1) { r.top2 = r.top1; r.top1 = x; } else if (x > r.top2) r.top2 = x;
+            if (c >= tx && i >= p.tok_beg) { r.sum_ts += (double)pr; if (pr > r.bts.v || (pr == r.bts.v && pr > 0.0f && i < r.bts.i)) { r.bts.v = pr; r.bts.i = i; } }
             if (sampled && i < NV) { probs[i] = pr; lg[i] = x; }     // the draw (one lane, below) walks the row in memory
         }
         if ((c & 7) == 6) __builtin_amdgcn_sched_barrier(0);
     }
     SMP_PASS_END
+    if (fast && tid == 0) {      // the row's winner, wherever its stripe is: (probability, index) beats whatever the timestamp stripes hold
+        const f32x2 e1 = expf_nonpos_x2((f32x2){t1, t1} - (f32x2){lse, lse});
+        if (e1[0] > r.best.v || (e1[0] == r.best.v && i1 < r.best.i)) { r.best.v = e1[0]; r.best.i = i1; r.best_logit = t1; }
+    }
     auto comb = [](SmpMain a, const SmpMain& c2) {
         if (c2.best.v > a.best.v || (c2.best.v == a.best.v && c2.best.i < a.best.i)) { a.best = c2.best; a.best_logit = c2.best_logit; }
         a.bts = better(a.bts, c2.bts); a.sum_ts += c2.sum_ts;
-        if (c2.top1 > a.top1) { a.top2 = fmaxf(a.top1, c2.top2); a.top1 = c2.top1; } else a.top2 = fmaxf(a.top2, c2.top1);
         return a;
     };
     for (int o = 32; o > 0; o >>= 1) {
         SmpMain y;
         y.best.v = __shfl_xor(r.best.v, o, 64); y.best.i = __shfl_xor(r.best.i, o, 64); y.best_logit = __shfl_xor(r.best_logit, o, 64);
         y.bts.v = __shfl_xor(r.bts.v, o, 64); y.bts.i = __shfl_xor(r.bts.i, o, 64); y.sum_ts = __shfl_xor(r.sum_ts, o, 64);
-        y.top1 = __shfl_xor(r.top1, o, 64); y.top2 = __shfl_xor(r.top2, o, 64);
+        y.top1 = t1; y.top2 = t2;
         r = comb(r, y);
     }
     if (lane == 0) sh_m[w] = r;
@@ -1575,7 +1621,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     __syncthreads();
     if (tid != 0) return;
     r = sh_m[0]; for (int k = 1; k < SMP_NT / 64; ++k) r = comb(r, sh_m[k]);
-    const ArgBest best = r.best, bts = r.bts; const double sum_ts = r.sum_ts; const float t1 = r.top1, t2 = r.top2;
+    const ArgBest best = r.best, bts = r.bts; const double sum_ts = r.sum_ts;
     SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = r.best_logit - lse;
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
@@ -1614,7 +1660,7 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
 }
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s) {
-    if (p.n_vocab <= SMP_PT * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
+    if (p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
     else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
 }
 

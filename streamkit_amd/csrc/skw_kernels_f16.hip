@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             const char* base = lds + (kb & 1) * (BM + BN) * 128;
             if (kb + 1 < nk && !(a.probe & 1)) stage((kb + 1) & 1, kb + 1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {       // (SIMD partners taking the two halves in opposite order — a stagger — measured the same: 28.76 vs 28.63 ms per batch)
                 if (a.probe & 2) break;
                 const int fo = kk ? fo1 : fo0;
                 f16x8 fx[TX], fy[TY];
@@ -294,13 +294,14 @@ static int skw_cu_count() {
     if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
     return n;
 }
-template <int EPI> static void launch_gemm16(const SkwGemmArgs& a, hipStream_t s) {
+template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves, one workgroup per CU) when both extents fill it, 128 x 128 (4 waves, two per CU) otherwise;
     // persistent workgroups: one grid slot per resident workgroup (rounded to the 8 XCDs), each walks tile ids slot, slot + grid, ...
     static const int force = getenv("SKW_GEMM16_TILE") ? atoi(getenv("SKW_GEMM16_TILE")) : 0;
-    const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
-    const bool big = force ? force == 256 : (Mv >= 256 && a.N >= 256 && Mv % 256 == 0 && a.N % 256 == 0);
+    const int Mv = Epi16<EPI>::X_IS_M ? (a_in.M / a_in.n_ctx) * a_in.Tpad : a_in.M;
+    const bool big = force ? force == 256 : (Mv >= 256 && a_in.N >= 256 && Mv % 256 == 0 && a_in.N % 256 == 0);
     const int cus = skw_cu_count() & ~7;
+    const SkwGemmArgs& a = a_in;
     if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else { const int nblk = ((Mv + 127) / 128) * ((a.N + 127) / 128); hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(std::min(nblk, 2 * cus)), dim3(256), 0, s, a); }
 }
@@ -349,18 +350,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     // staging: chunk id c = tid + 256 i -> row c >> 3, 16-byte chunk c & 7
-    unsigned st_lds[2], st_k[2], st_v[2]; int st_vkey[2];
+    // bank swizzles: a ds_read_b128 is served eight lanes at a time (8 x 16 B = 128 B), and two rows of 128 B span the 64 banks, so eight lanes are
+    // conflict-free when their (row parity, stored chunk) pairs differ.  V^T fragments read rows r16 = 0..7 / 8..15: chunk ^ (row & 7) does it.  K fragments
+    // read rows kappa(r16) = 0, 4, 8, 12, 1, 5, 9, 13 / 2, 6, ...: there (row & 7) repeats (0, 4, 0, 4: two-way conflicts on every K read, SQ_LDS_BANK_CONFLICT =
+    // 81 % of the LDS-active cycles in profiles/r02f) and ((row >> 1) & 7) = 0, 2, 4, 6 per parity does not.
+    unsigned st_lds[2], st_ldsk[2], st_k[2], st_v[2]; int st_vkey[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = tid + 256 * i, row = c >> 3, pos = c & 7;
         st_lds[i] = (unsigned)(row * 128 + ((pos ^ (row & 7)) << 4));
+        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ ((row >> 1) & 7)) << 4));
         st_k[i] = (unsigned)((row * 64 + pos * 8) * 2);              // + kb * 64 rows; rows past Tpad fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
         st_vkey[i] = pos * 8;
     }
     const int nkb = (Tpad + 63) >> 6;
     const int kappa = 4 * (r16 & 3) + (r16 >> 2);
-    const int k_off = kappa * 128, k_sw = kappa & 7, v_off = r16 * 128, v_sw = r16 & 7;
+    const int k_off = kappa * 128, k_sw = (kappa >> 1) & 7, v_off = r16 * 128, v_sw = r16 & 7;
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     };
     auto store_k = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *(u32x4*)(&lds[buf][0][st_lds[i]]) = sk[i];
+        for (int i = 0; i < 2; ++i) *(u32x4*)(&lds[buf][0][st_ldsk[i]]) = sk[i];
     };
     auto store_v = [&](int buf) {
 #pragma unroll
@@ -411,8 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) { bm0 = fmaxf(bm0, s0[kt][r]); bm1 = fmaxf(bm1, s1[kt][r]); }
         }
-        bm0 = fmaxf(bm0, __shfl_xor(bm0, 16, 64)); bm0 = fmaxf(bm0, __shfl_xor(bm0, 32, 64));
-        bm1 = fmaxf(bm1, __shfl_xor(bm1, 16, 64)); bm1 = fmaxf(bm1, __shfl_xor(bm1, 32, 64));
+        bm0 = skw_rows_max_f32(bm0); bm1 = skw_rows_max_f32(bm1);      // (v_permlane swaps: no LDS round trip inside the block loop)
         if (__builtin_amdgcn_ballot_w64(bm0 > m0 || bm1 > m1)) {                // wave-uniform
             const float n0 = fmaxf(m0, bm0), n1 = fmaxf(m1, bm1);
             const float a0 = __builtin_amdgcn_exp2f((m0 - n0) * c1), a1 = __builtin_amdgcn_exp2f((m1 - n1) * c1);   // first block: exp2(-inf) = 0 on empty accumulators
@@ -443,8 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         if (kb + 1 < nkb) { store_k((kb + 1) & 1); store_v((kb + 1) & 1); }
         __syncthreads();
     }
-    l0 += __shfl_xor(l0, 16, 64); l0 += __shfl_xor(l0, 32, 64);
-    l1 += __shfl_xor(l1, 16, 64); l1 += __shfl_xor(l1, 32, 64);
+    l0 = skw_rows_sum_f32(l0); l1 = skw_rows_sum_f32(l1);
     const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
     // O^T tiles: lane (query = r16, g) holds channels ct * 16 + 4 g + r
 #pragma unroll
