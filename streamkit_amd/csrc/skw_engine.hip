@@ -733,7 +733,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s, tail); }
@@ -1145,6 +1145,28 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_per_launch = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(C); hipFree(bias); hipFree(res);
+    return 0;
+}
+
+// tools/xattn_probe.py: the decode step's cross attention alone, B rows, launched back to back over `layers` different K / V^T images (so no launch
+// re-reads what a previous one left in a cache), parts switched off by `probe` (see k_dec_cross_attn).  Average microseconds per launch.
+extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int iters, float* us_per_launch) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    const skw_hparams& hp = c->m->hp; const int d = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, Tpad = c->Tpad;
+    const size_t kn = (size_t)B * nc * d, vn = (size_t)B * H * 64 * Tpad;
+    half_t *K = nullptr, *V = nullptr, *q = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc((void**)&K, kn * 2 * layers)); HIPCHK(hipMalloc((void**)&V, vn * 2 * layers)); HIPCHK(hipMalloc((void**)&q, (size_t)B * d * 2)); HIPCHK(hipMalloc((void**)&out, (size_t)B * d * 4));
+    { std::vector<uint16_t> h(std::max(kn, vn)); uint32_t x = 777; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16((((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.25f); }
+      for (int l = 0; l < layers; ++l) { HIPCHK(hipMemcpy(K + kn * l, h.data(), kn * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(V + vn * l, h.data(), vn * 2, hipMemcpyHostToDevice)); }
+      HIPCHK(hipMemcpy(q, h.data(), (size_t)B * d * 2, hipMemcpyHostToDevice)); }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int pv16 = c->precision == SKW_PRECISION_F16_MFMA;
+    for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
+    HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_per_launch = 1000.0f * ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(K); hipFree(V); hipFree(q); hipFree(out);
     return 0;
 }
 

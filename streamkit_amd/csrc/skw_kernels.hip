@@ -992,10 +992,11 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // which measured 14.6 us (the HBM stream idles behind it on every CU at once), so the form is opt-in (skw_dec_cross_attn_vt_q_ok).
 // In both precisions the query is this exact chain.  Needs WPH == 4, d % 128 == 0, d <= 1536.
 struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
-template <int MAXT, int WPH, int HPW, bool FQ = false>
+template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
                                                            const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq) {
     if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
+    const int probe = f32_out >> 8; f32_out &= 1;      // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
     __shared__ float smax[HPW][WPH];
@@ -1004,6 +1005,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     __shared__ float qred[FQ ? HPW : 1][4][64];
     __shared__ __attribute__((aligned(16))) half_t qown[FQ ? HPW * WPH : 1][64];
     __shared__ double lnred[HPW * WPH];
+    __shared__ __attribute__((aligned(16))) half_t p16[PV16 ? HPW : 1][PV16 ? MAXT * 64 : 8];      // PV16: the probabilities as f16 in kperm order, the f16 MFMA's second operand
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
     const int hraw = blockIdx.x * HPW + hs, b = blockIdx.y;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
@@ -1125,16 +1127,22 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
         __builtin_amdgcn_sched_barrier(0);
         if (t < t_hi) {       // wave-uniform
             const int key = t * 64 + lane;
+            float a = 0.0f;
+            if (probe & 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a += __uint_as_float(cur[i][0] ^ cur[i][1] ^ cur[i][2] ^ cur[i][3]) * 1e-30f;
+            } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = cur[i];
             __builtin_amdgcn_wave_barrier();   // same wave, LDS in order: a compiler-level fence is all that is needed
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) asm volatile("" : "+v"(qh[c8].v));   // opaque: stops the 64 conversions being hoisted out of the loop into 64 live registers
-            float a = 0.0f;
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) { H8v t8; t8.v = *(const u32x4*)(kl + lane * 72 + c8 * 8);
+                if (probe & 2) { a += h2f(t8.h[0]); continue; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = __builtin_fmaf(h2f(qh[c8].h[e]), h2f(t8.h[e]), a); }
+            }
             __builtin_amdgcn_wave_barrier();
             if (key >= n_ctx) a = -INFINITY;
             pl[key] = a; lmax = fmaxf(lmax, a);
@@ -1171,13 +1179,18 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
     for (int i = 1; i < WPH; ++i) tot += ssum[hs][i];
     const float inv = (float)(1.0 / tot);
+    if constexpr (PV16) {
+        for (int t = t_lo; t < t_hi; ++t) p16[hs][skw_kperm(t * 64 + lane)] = f2h(pl[t * 64 + lane] * inv);
+        for (int t = nt + half; t < MAXT; t += WPH) p16[hs][t * 64 + lane] = (half_t)0.0f;
+    } else {
     for (int t = t_lo; t < t_hi; ++t) pl[t * 64 + lane] = h2f(f2h(pl[t * 64 + lane] * inv));
     for (int t = nt + half; t < MAXT; t += WPH) pl[t * 64 + lane] = 0.0f;      // key slots past the last pass (V^T pad is zero as well)
+    }
     __syncthreads();
     f32x4 oacc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < nkb; kb0 += RD) {
+    for (int kb0 = 0; kb0 < ((probe & 8) ? 0 : nkb); kb0 += RD) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const int kb = kb0 + j;
@@ -1188,16 +1201,33 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (nb < nkb) ? vo + ct * 16 * Tpad * 2 + nb * 64 : 0x7fffff00u, 0, 0);
             const int kbc = min(kb, nkb - 1);     // blocks past the end multiply p by zero-filled fragments
+            if constexpr (PV16) {
+                // f16_mfma precision: p is f16-valued and V^T is f16, so a 32-key block is ONE v_mfma_f32_16x16x32_f16 (16 cycles) instead of eight dependent
+                // f32 MFMAs (256 cycles: tools/xattn_probe.py put them at 8.7 us of a 65 us launch that is otherwise at the memory system's pace).
+                // Same products, summed in the matrix core's order for the block rather than key by key.
+                typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+                const f16x8_t pb = *(const f16x8_t*)(&p16[hs][kbc * 32 + g * 8]);
+                if (!(probe & 1)) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, vf[ct].v), pb, oacc[ct], 0, 0, 0);
+                }
+                continue;
+            }
             float pe[8], xv[CT][8];      // operands first, then the MFMAs back to back (a dependent MFMA directly behind its producer is the cheap case)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { pe[e] = pl[kbc * 32 + 4 * e + g];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xv[ct][e] = h2f(vf[ct].h[e]); }
             __builtin_amdgcn_sched_barrier(0);
+            if (probe & 1) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) oacc[ct][0] += xv[ct][0] + pe[0];
+            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) oacc[ct] = MFMA16(xv[ct][e], pe[e], oacc[ct]);   // O^T[c][*] += V^T[c][key] * p[key]
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1209,7 +1239,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
             for (int r = 0; r < 4; ++r) att_store(out, (long)b * ldo, h * 64 + (half * CT + ct) * 16 + 4 * g + r, oacc[ct][r], f32_out);
     }
 }
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out) {
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     const SkwXQ none{};
@@ -1217,6 +1247,7 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
     if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
+    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
     else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
     else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
 }

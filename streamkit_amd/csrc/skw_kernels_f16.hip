@@ -561,10 +561,10 @@ __device__ __forceinline__ void gemm16_small_ln_tail(const SkwGemmArgs& a, int m
 // kernel's K/4 dependent f32 MFMAs), the partial tiles meet in LDS and wave t finishes row tile t.  As in k_gemm16 the weights
 // are the MFMA's first operand, so a lane ends up with four adjacent outputs of one row: 16-byte residual loads and stores.
 // Operands come straight from global memory (16-byte buffer loads with hardware range checks; a ring of RD k-blocks in flight).
-template <int EPI, int MT, int NW>
+template <int EPI, int MT, int NW, int RDP = 0>
 __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
-    constexpr int RD = (MT == 4) ? 6 : 12;               // k-blocks in flight per wave
+    constexpr int RD = RDP ? RDP : ((MT == 4) ? 6 : 12);               // k-blocks in flight per wave (RDP = 24: a wave's whole quarter of K = 3072, one round trip instead of two)
     __shared__ f32x4 red[NW][MT][64];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16, my0 = blockIdx.y * (16 * MT);
@@ -874,11 +874,13 @@ template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStre
     static const int mt_vocab = getenv("SKW_DEC_MT_VOCAB") ? atoi(getenv("SKW_DEC_MT_VOCAB")) : 4;   // the logits product: thousands of strips, W read once
     static const int nw_deep = getenv("SKW_DEC_NW_DEEP") ? atoi(getenv("SKW_DEC_NW_DEEP")) : 4;      // K >= 2048 (fc2); eight waves measured slower: a launch costs ~0.8 us per 1000 waves
     static const int nw_env = getenv("SKW_DEC_NW") ? atoi(getenv("SKW_DEC_NW")) : 4;
+    static const int rd_deep = getenv("SKW_DEC_RD_DEEP") ? atoi(getenv("SKW_DEC_RD_DEEP")) : 12;     // fc2: 24 = the whole K quarter of a wave in flight at once instead of two rounds of 12 k-blocks; measured slower (decode 167.6 vs 166.3 ms)
     const int mt = a.N >= 8192 ? mt_vocab : (a.N >= 2048 ? mt_wide : mt_env);
     const int nw = (a.K >= 2048 ? nw_deep : nw_env) == 8 && !(a.K & 255) && mt == 1 ? 8 : 4;
     if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
     else if (mt == 2) hipLaunchKernelGGL((k_gemm16_small<EPI, 2, 4>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(256), 0, s, a);
     else if (nw == 8) hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 8>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(512), 0, s, a);
+    else if (EPI == EPI_F32 && rd_deep == 24 && (a.K >> 7) > 12 && (a.K >> 7) <= 24) hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 4, 24>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 4>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
 }
 // f16-MFMA form of skw_gemm_smallm; returns false when the geometry is outside what it handles (K % 128 != 0): the caller then
