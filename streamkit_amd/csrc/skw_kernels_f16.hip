@@ -13,6 +13,7 @@
 // Reference call site of everything here: /root/reference/plugins/native/whisper/src/lib.rs:644-646 (`whisper_state.full`).
 #include "skw_dev_common.h"
 #include <algorithm>
+#include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16X32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
@@ -233,7 +234,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                 __syncthreads();
             }
             for (int pass = 0; pass < NPASS; ++pass) {
-                // phase A: this pass's rows, from the waves that hold them
+                // phase A: this pass's rows, from the waves that hold them.  (RAW = the probe's "no per-element epilogue math": a compile-time copy of the loop —
+                // tested per element, the measurement hook was a scalar branch in front of every one of a lane's 128 outputs)
+                auto phase_a = [&](auto raw_tag) {
+                    constexpr bool RAW = decltype(raw_tag)::value;
 #pragma unroll
                 for (int j = 0; j < TY; ++j) {
                     const int yl = wY * WTY + j * 16 + r16;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         const f32x4 bx = X_IS_M ? (f32x4){bias_l[yl], bias_l[yl], bias_l[yl], bias_l[yl]} : *(const f32x4*)(bias_l + xl);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            o[r] = (a.probe & 16) ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
+                            o[r] = RAW ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
                             if (X_IS_M) { int key = rb + (((xl + r) & ~31) | inv_kperm32((xl + r) & 31)); if (key >= a.Tpad) key -= a.Tpad; if (key >= a.n_ctx) o[r] = 0.0f; }   // V^T: pad keys stay zero (logical key of this memory position)
                         }
                         const int ck = xl / CE;
@@ -255,6 +259,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
                     }
                 }
+                };
+                if (a.probe & 16) phase_a(std::true_type{}); else phase_a(std::false_type{});
                 __syncthreads();
                 // phase B: whole rows out, 16 bytes per lane; the row-wise operands of a batch of chunks are requested together
                 constexpr int NCH = RP * CPR / (NW * 64), BATCH = !F32OUT ? 2 : (NCH < 4 ? NCH : 4);     // (f16 outputs have no row-wise operand to wait for)
@@ -350,23 +356,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     // staging: chunk id c = tid + 256 i -> row c >> 3, 16-byte chunk c & 7
-    // bank swizzles: a ds_read_b128 is served eight lanes at a time (8 x 16 B = 128 B), and two rows of 128 B span the 64 banks, so eight lanes are
-    // conflict-free when their (row parity, stored chunk) pairs differ.  V^T fragments read rows r16 = 0..7 / 8..15: chunk ^ (row & 7) does it.  K fragments
-    // read rows kappa(r16) = 0, 4, 8, 12, 1, 5, 9, 13 / 2, 6, ...: there (row & 7) repeats (0, 4, 0, 4: two-way conflicts on every K read, SQ_LDS_BANK_CONFLICT =
-    // 81 % of the LDS-active cycles in profiles/r02f) and ((row >> 1) & 7) = 0, 2, 4, 6 per parity does not.
+    // bank swizzles: a ds_read_b128 is served eight lanes at a time (8 x 16 B = the 32 banks), so eight lanes are conflict-free when their stored chunk
+    // positions differ, whatever their rows.  V^T fragments read rows r16 = 0..7 / 8..15: chunk ^ (row & 7) does it.  K fragments read rows
+    // kappa(r16) = 0, 4, 8, 12, 1, 5, 9, 13 / 2, 6, ...: there (row & 7) repeats (0, 4, 0, 4, 1, 5, 1, 5: two-way conflicts on every K read,
+    // SQ_LDS_BANK_CONFLICT = 81 % of the LDS-active cycles in profiles/r02f); the K image is swizzled by the READING lane's index instead:
+    // kappa is an involution of r16, so row -> r16(row) & 7 = ((row & 1) << 2) | ((row >> 2) & 3).
     unsigned st_lds[2], st_ldsk[2], st_k[2], st_v[2]; int st_vkey[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = tid + 256 * i, row = c >> 3, pos = c & 7;
         st_lds[i] = (unsigned)(row * 128 + ((pos ^ (row & 7)) << 4));
-        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ ((row >> 1) & 7)) << 4));
+        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (((row & 1) << 2) | ((row >> 2) & 3))) << 4));
         st_k[i] = (unsigned)((row * 64 + pos * 8) * 2);              // + kb * 64 rows; rows past Tpad fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
         st_vkey[i] = pos * 8;
     }
     const int nkb = (Tpad + 63) >> 6;
     const int kappa = 4 * (r16 & 3) + (r16 >> 2);
-    const int k_off = kappa * 128, k_sw = (kappa >> 1) & 7, v_off = r16 * 128, v_sw = r16 & 7;
+    const int k_off = kappa * 128, k_sw = r16 & 7, v_off = r16 * 128, v_sw = r16 & 7;
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
