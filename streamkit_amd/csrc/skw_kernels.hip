@@ -876,30 +876,32 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
     const int act = active ? active[b * active_stride] : 1;   // (tested after the prefetches below are on their way: one round trip for all of them)
     const half_t* K = kbase + (long)b * batch_stride + h * 64;
     const half_t* V = vbase + (long)b * batch_stride + h * 64;
-    // V rows of the first NPRE keys are requested before anything else waits on memory (their addresses depend on nothing that is
-    // loaded; rows past n_kv exist in the cache and are simply not used): the short-context steps then pay one round trip, not
-    // one per 16 keys after the softmax
+    // Everything whose address depends on nothing loaded is requested before the first wait, in the order it is needed (a wave's loads return in
+    // order): q and the first 64 K rows, which the score chains start on, then the V rows of the first NPRE keys, which arrive under them (rows
+    // past n_kv exist in the cache and are simply not used): the short-context steps pay one round trip, not one per 16 keys after the softmax.
     constexpr int NPRE = (MAXT * 64 < 128) ? MAXT * 64 : 128;
     const int rows_cap = (int)(batch_stride / ldkv);
+    uint4 qraw[8];
+    { const uint4* qp = (const uint4*)(q + (long)b * ldq + h * 64);
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) qraw[c8] = qp[c8]; }
+    uint4 kk0[8];
+    { const uint4* kr = (const uint4*)(K + (long)min(lane, rows_cap - 1) * ldkv);
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) kk0[c8] = kr[c8]; }
+    __builtin_amdgcn_sched_barrier(0);
     half_t vpre[NPRE];
     {
         const half_t* vp0 = V + lane;
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) vpre[u] = vp0[(long)min(u, rows_cap - 1) * ldkv];
     }
+    __builtin_amdgcn_sched_barrier(0);
     float qv[64];
-    {
-        const uint4* qp = (const uint4*)(q + (long)b * ldq + h * 64);
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) { H8 t; t.u = qp[c8];
+    for (int c8 = 0; c8 < 8; ++c8) { H8 t; t.u = qraw[c8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qv[c8 * 8 + e] = h2f(t.h[e]); }
-    }
-    // the first 64 K rows likewise: requested before n_kv has arrived (every step needs them; rows past n_kv are masked below)
-    uint4 kk0[8];
-    { const uint4* kr = (const uint4*)(K + (long)min(lane, rows_cap - 1) * ldkv);
-#pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) kk0[c8] = kr[c8]; }
+        for (int e = 0; e < 8; ++e) qv[c8 * 8 + e] = h2f(t.h[e]); }
     const int n_kv = n_kv_ptr ? (n_kv_ptr[b * n_kv_stride] + 1) : n_kv_fixed;
     if (!act) return;                                        // a finished sequence keeps its slot in the batch; its row is never sampled again
     float sc[MAXT];
