@@ -364,8 +364,10 @@ struct skw_ctx {
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
-    SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; int* n_active = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
-    SkwSeqState* h_st = nullptr; SkwTokenOut* h_toks = nullptr; int* h_n_active = nullptr; // pinned
+    SkwSeqState* st = nullptr; SkwTokenOut* toks = nullptr; uint8_t* static_mask = nullptr; int static_mask_nst = -1;
+    SkwSeqState* h_st = nullptr; SkwTokenOut* h_toks = nullptr; // pinned
+    int* h_row_live = nullptr; int* d_row_live = nullptr;      // per-row live flags in pinned host memory and their device-side address: k_dec_sample clears a row's flag itself,
+                                                               // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
     skw_timing timing{};
     int last_enc_B = 0;
@@ -419,11 +421,11 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
         WS(q8_a, int8_t, rows * kmax, false); WS(q8_d, float, rows * (kmax / 32), false); WS(q8_s, float, rows * (kmax / 32), false);
     }
     c->max_tok = hp.n_text_ctx / 2;
-    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(n_active, int, skw_ctx::MAX_GROUPS, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
+    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(probs, float, (size_t)B * hp.n_vocab, false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
 #undef WS
     ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&c->h_n_active, sizeof(int) * skw_ctx::MAX_GROUPS) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_row_live, sizeof(int) * B, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_row_live, c->h_row_live, 0) == hipSuccess;
     if (!ok) { set_err(err, errlen, "workspace allocation failed (max_batch %d)", max_batch); skw_ctx_free(c); return nullptr; }
     hipDeviceSynchronize();
     return c;
@@ -438,7 +440,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
     for (int g = 0; g < skw_ctx::MAX_GROUPS; ++g) { if (c->gstream[g]) { hipStreamSynchronize(c->gstream[g]); hipStreamDestroy(c->gstream[g]); } if (c->gev[g]) hipEventDestroy(c->gev[g]); }
     for (void* p : c->allocs) hipFree(p);
     hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map);
-    if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_n_active) hipHostFree(c->h_n_active);
+    if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_row_live) hipHostFree(c->h_row_live);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -761,8 +763,7 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     run_decoder_step(c, r0, n, 0, true, s);
-    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->n_active + g, c->probs + (size_t)r0 * NV, c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
-    hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, s);
+    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->d_row_live + r0, c->probs + (size_t)r0 * NV, c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
     hipGraphDestroy(graph);
@@ -940,8 +941,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;   // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
         const int G = std::max(1, std::min(n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
-        for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; c->h_n_active[g] = g_n[g]; }
-        HIPCHK(hipMemcpyAsync(c->n_active, c->h_n_active, sizeof(int) * G, hipMemcpyHostToDevice, c->stream));
+        for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; }
+        for (int j = 0; j < Bw; ++j) c->h_row_live[j] = 1;      // (every kernel of the previous window has drained: c->stream was synchronised at its end)
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
         // every step = decoder step (token and position from the device state) + k_dec_sample, which feeds the next prompt token
@@ -950,9 +951,9 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         if (use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->n_active + g, c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g]); }
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->d_row_live + g_r0[g], c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g]); }
             c->cur = c->stream;
-            return hipMemcpyAsync(c->h_n_active + g, c->n_active + g, sizeof(int), hipMemcpyDeviceToHost, c->gstream[g]);
+            return hipSuccess;
         };
         // The host learns whether a group still has live rows only by waiting for its stream, and a wait + relaunch per step leaves the
         // GPU idle for the turnaround.  So steps are enqueued `ahead` at a time and the count is read once per block: a step that
@@ -969,7 +970,8 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
                     else { run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); HIPCHK(sample(g)); }
                 }
             bool any = false;
-            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); if (c->h_n_active[g] <= 0) g_live[g] = false; else any = true; }
+            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); int live = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) live += ((volatile int*)c->h_row_live)[j] != 0;
+                                                        if (live <= 0) g_live[g] = false; else any = true; }
             if (!any) break;
         }
         for (int g = 0; g < G; ++g) { HIPCHK(hipEventRecord(c->gev[g], c->gstream[g])); HIPCHK(hipStreamWaitEvent(c->stream, c->gev[g], 0)); }

@@ -138,7 +138,8 @@ struct SkwLogitParams {
 // kernel's thread layout (two 64-bit words per thread); build it on the host with skw_static_mask_pack
 size_t skw_static_mask_bytes(int n_vocab);
 void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
-// probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]]
+// probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
+// n_active: [B] live flags (1 while the row decodes; the kernel stores 0 when it completes or fails) — host-mapped memory in the engine
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s);
 void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip

@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
     if (!failed && !completed && i + 1 >= p.n_max) completed = 1;   // loop bound reached (whisper.cpp leaves the for loop)
     st->failed = failed; st->completed = completed;
     st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
-    if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
+    if (failed || completed) { st->active = 0; n_active[b] = 0; }     // the row's live flag, in host-mapped memory: the host reads it after the stream drains (no copy kernel in the step)
 }
 // Register-resident form: the row's logits (<= 104 per thread) are loaded once, every pass of whisper_process_logits then runs on
 // registers -- the streaming form above re-reads the row from L2 six times with nothing to overlap the latency (90 us per step).
@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     if (!failed && !completed && i + 1 >= p.n_max) completed = 1;   // loop bound reached (whisper.cpp leaves the for loop)
     st->failed = failed; st->completed = completed;
     st->cur_token = tk.id; st->cur_pos = st->n_prompt + i;
-    if (failed || completed) { st->active = 0; atomicSub(n_active, 1); }
+    if (failed || completed) { st->active = 0; n_active[b] = 0; }     // the row's live flag, in host-mapped memory: the host reads it after the stream drains (no copy kernel in the step)
 }
 size_t skw_static_mask_bytes(int n_vocab) { return (size_t)((n_vocab + 15) & ~15) + 2 * SMP_NT * sizeof(unsigned long long); }
 void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
