@@ -10,7 +10,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 # the oracle's OpenMP regions are many and short (a decode step is dozens): with spinning waits, any oversubscription of the host (a second
 # pytest, torch's own pool) turns every barrier into a scheduler quantum — a 50 s suite was seen to take half an hour.  Sleep instead.
-os.environ.setdefault("GOMP_SPINCOUNT", "100000")     # ~50 us of spinning, then sleep
+os.environ.setdefault("GOMP_SPINCOUNT", "2000")       # a microsecond of spinning, then sleep
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# ... and the other pools of this process stay out of the way: numpy's BLAS workers busy-wait after every call and torch keeps its own team; the
+# restatements they run here are small.  (With 100000 spins and the pools left alone the suite still stalled for > 15 min, intermittently, on an 8-vCPU VM.)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
 
 
 def pytest_configure(config):
