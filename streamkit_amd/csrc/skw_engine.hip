@@ -524,7 +524,8 @@ static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, 
     if (normalised) { GEMM_S(c, a, a.K); return; }                     // y16 already holds LayerNorm(x): the GEMM that wrote x did it (ln_tail)
     // measured (profiles/r02c): the fused kernel costs 17 - 18 us at N = 2304 / 3072 and 9.6 us at N = 768 where LayerNorm (5 us)
     // + plain GEMM (5 - 8.6 us) cost 10 - 13.6: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
-    static const bool fuse = getenv("SKW_DEC_LN_FUSE") != nullptr;
+    static const int fuse_n = getenv("SKW_DEC_LN_FUSE") ? atoi(getenv("SKW_DEC_LN_FUSE")) : 0;      // 1: every LayerNorm-fed decode GEMM; n > 1: those with N <= n
+    const bool fuse = fuse_n == 1 || (fuse_n > 1 && a.N <= fuse_n);
     if (c->precision == SKW_PRECISION_F16_MFMA && fuse) {
         a.ln_x = x; a.ln_w = ln.w; a.ln_b = ln.b;
         double fl, by; fl = 2.0 * a.M * a.N * a.K; by = 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N;

@@ -687,8 +687,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
         double sum = 0.0;
 #pragma unroll
         for (int j = 0; j < PMAX; ++j) if (t16 + 16 * j < npc) { sum += (double)v[j][0]; sum += (double)v[j][1]; sum += (double)v[j][2]; sum += (double)v[j][3]; }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sum += skw_dpp_f64<0xB1>(sum); sum += skw_dpp_f64<0x4E>(sum); sum += skw_dpp_f64<0x141>(sum); sum += skw_dpp_f64<0x140>(sum);      // the 16 lanes of a row: DPP, no LDS crossbar
         const float mean = (float)(sum / (double)d);
         double sum2 = 0.0;
 #pragma unroll
@@ -696,8 +695,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float t = v[j][e] - mean; v[j][e] = t; sum2 += (double)(t * t); }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o, 64);
+        sum2 += skw_dpp_f64<0xB1>(sum2); sum2 += skw_dpp_f64<0x4E>(sum2); sum2 += skw_dpp_f64<0x141>(sum2); sum2 += skw_dpp_f64<0x140>(sum2);
         const float variance = (float)(sum2 / (double)d);
         const float scale = 1.0f / sqrtf(variance + 1e-5f);
         __syncthreads();                                          // gain / bias are in LDS
