@@ -8,14 +8,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
-# the oracle's OpenMP regions are many and short (a decode step is dozens): with spinning waits, any oversubscription of the host (a second
-# pytest, torch's own pool) turns every barrier into a scheduler quantum — a 50 s suite was seen to take half an hour.  Sleep instead.
-os.environ.setdefault("GOMP_SPINCOUNT", "2000")       # a microsecond of spinning, then sleep
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-# ... and the other pools of this process stay out of the way: numpy's BLAS workers busy-wait after every call and torch keeps its own team; the
-# restatements they run here are small.  (With 100000 spins and the pools left alone the suite still stalled for > 15 min, intermittently, on an 8-vCPU VM.)
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-os.environ.setdefault("MKL_NUM_THREADS", "1")
 
 
 def pytest_configure(config):
@@ -31,6 +23,19 @@ def _have_gpu():
 
 
 HAVE_GPU = _have_gpu()
+
+# The oracle's OpenMP regions are many and short (a decode step is dozens).  With spinning waits, anything that takes a core away — a second pytest,
+# numpy's busy-waiting BLAS workers, torch's own team, a hypervisor descheduling a vCPU — turns every barrier into a scheduler quantum: a 40 s suite was
+# seen to stall for > 15 min, intermittently, in the 8-vCPU container the CPU tier runs in.  There: passive waits and single-threaded BLAS (70 s, also
+# under six busy loops).  On the GPU box (dedicated cores) the parity tests lean on the oracle and passive waits triple their time (16 min instead of
+# 5.5), so it keeps a bounded spin.  Set here, before oracle/libskw_oracle.so brings in the system libgomp (torch, imported above, carries its own copy).
+if HAVE_GPU:
+    os.environ.setdefault("GOMP_SPINCOUNT", "100000")     # ~50 us of spinning, then sleep
+else:
+    os.environ.setdefault("GOMP_SPINCOUNT", "2000")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
 
 
 def pytest_collection_modifyitems(config, items):
