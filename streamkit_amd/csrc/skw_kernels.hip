@@ -993,6 +993,9 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // and the K ring is refilled as its slots drain: two launches (LayerNorm, a 64 x 768 x 768 product: 10.4 us of a 125 us layer) become a prologue —
 // which measured 14.6 us (the HBM stream idles behind it on every CU at once), so the form is opt-in (skw_dec_cross_attn_vt_q_ok).
 // In both precisions the query is this exact chain.  Needs WPH == 4, d % 128 == 0, d <= 1536.
+#ifndef SKW_XATTN_RD16
+#define SKW_XATTN_RD16 16      // V^T blocks in flight per wave in the f16_mfma P.V (8: 56.4 us per launch in tools/xattn_probe.py, 12: 55.7, 16: 55.7, 24: 56.1)
+#endif
 struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
 template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
@@ -1160,7 +1163,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     constexpr int CT = 4 / WPH;                                                   // channel tiles per wave
     const unsigned vo = (unsigned)(((half * CT * 16 + r16) * Tpad + g * 8) * 2);
     const int nkb = Tpad >> 5;
-    constexpr int RD = 8;
+    constexpr int RD = PV16 ? SKW_XATTN_RD16 : 8;
     H8v ring[RD][CT];
 #pragma unroll
     for (int j = 0; j < RD; ++j)
