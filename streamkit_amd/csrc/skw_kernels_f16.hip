@@ -357,10 +357,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     // staging: chunk id c = tid + 256 i -> row c >> 3, 16-byte chunk c & 7
     // bank swizzles: a ds_read_b128 is served eight lanes at a time (8 x 16 B = the 32 banks), so eight lanes are conflict-free when their stored chunk
-    // positions differ, whatever their rows.  V^T fragments read rows r16 = 0..7 / 8..15: chunk ^ (row & 7) does it.  K fragments read rows
-    // kappa(r16) = 0, 4, 8, 12, 1, 5, 9, 13 / 2, 6, ...: there (row & 7) repeats (0, 4, 0, 4, 1, 5, 1, 5: two-way conflicts on every K read,
-    // SQ_LDS_BANK_CONFLICT = 81 % of the LDS-active cycles in profiles/r02f); the K image is swizzled by the READING lane's index instead:
-    // kappa is an involution of r16, so row -> r16(row) & 7 = ((row & 1) << 2) | ((row >> 2) & 3).
+    // positions differ, whatever their rows.  V^T fragments read rows r16 = 0..7 / 8..15: chunk ^ (row & 7) does it (k_gemm16's reads, the same shape, count
+    // zero conflicts).  K fragments read rows kappa(r16) = 0, 4, 8, 12, 1, 5, 9, 13 / 2, 6, ...: the K image is swizzled by the READING lane's index —
+    // kappa is an involution of r16, so row -> r16(row) & 7 = ((row & 1) << 2) | ((row >> 2) & 3).  (SQ_LDS_BANK_CONFLICT stays at 82 % of this kernel's
+    // LDS-active cycles with either K swizzle, one conflict cycle per MFMA issued: the remaining suspect is the 16-byte staging stores.  <= 7 % of the kernel.)
     unsigned st_lds[2], st_ldsk[2], st_k[2], st_v[2]; int st_vkey[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
