@@ -755,8 +755,8 @@ bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
 // are consumed, across pair boundaries.  A lane's chain for one output runs over the whole K in ascending order (no split): every
 // row sees the same arithmetic whatever the batch.
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));             // n_vocab is odd: a row of logits starts on any 4-byte boundary
-template <int MT, int RD>
-__global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_per_wg) {
+template <int MT, int RD, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int strips_per_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_a[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -766,13 +766,13 @@ __global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_
     const int n_strips = (a.N + 15) >> 4;
     const int s_lo = blockIdx.x * strips_per_wg, s_hi = min((int)(blockIdx.x + 1) * strips_per_wg, n_strips);
     const int n_pairs = (s_hi - s_lo + 1) >> 1;
-    const int np = w < n_pairs ? (n_pairs - w + 3) >> 2 : 0;        // this wave's pairs: w, w + 4, ...
+    const int np = w < n_pairs ? (n_pairs - w + NWV - 1) / NWV : 0;        // this wave's pairs: w, w + NWV, ...
     const int nblk = np * bps;
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     auto w_off = [&](int b, int h) -> unsigned {             // byte offset of this lane's 16 bytes of ring block b (strip h of the pair), k-block 0 of the block
         if (b >= nblk || (a.probe & 1)) return oob;
-        const int strip = s_lo + 2 * (w + 4 * (b / bps)) + h, kb0 = (b % bps) * RD, wn = strip * 16 + r16;
+        const int strip = s_lo + 2 * (w + NWV * (b / bps)) + h, kb0 = (b % bps) * RD, wn = strip * 16 + r16;
         return (strip < s_hi && wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb0 * 32 + g * 8) * 2) : oob;
     };
     u32x4 fw[2][RD];
@@ -785,11 +785,11 @@ __global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_
     // A -> LDS (16-byte chunks, coalesced, eight in flight per thread; rows past M read as zeros)
     { const int cpr = a.K >> 3, total = 16 * MT * cpr;
       __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
-      for (int q0 = threadIdx.x; q0 < total; q0 += 256 * 8) {
+      for (int q0 = threadIdx.x; q0 < total; q0 += 64 * NWV * 8) {
           u32x4 v[8]; int dsto[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-              const int q = q0 + 256 * u, row = q / cpr, c = q - row * cpr, m = my0 + row;
+              const int q = q0 + 64 * NWV * u, row = q / cpr, c = q - row * cpr, m = my0 + row;
               dsto[u] = q < total ? row * rowb + c * 16 : -1;
               v[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, (q < total && m < a.M && !(a.probe & 2)) ? (unsigned)(((long)m * a.lda + c * 8) * 2) : oob, 0, 0);
           }
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_
         if ((b + 1) % bps == 0) {                                                // the pair is complete: out it goes
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int strip = s_lo + 2 * (w + 4 * (b / bps)) + h, p0 = strip * 16 + 4 * g;
+                const int strip = s_lo + 2 * (w + NWV * (b / bps)) + h, p0 = strip * 16 + 4 * g;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const int m = my0 + t * 16 + r16;
@@ -848,14 +848,19 @@ __global__ __launch_bounds__(256) void k_gemm16_vocab(SkwGemmArgs a, int strips_
         }
     }
 }
-template <int MT, int RD> static void launch_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
+template <int MT, int RD, int NWV> static void launch_gemm16_vocab_n(const SkwGemmArgs& a, hipStream_t s) {
     const int lds = 16 * MT * (a.K * 2 + 16);
     static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+    if (!once) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
     const int n_strips = (a.N + 15) / 16, rows = (a.M + 16 * MT - 1) / (16 * MT);
     const int slots = std::max(1, skw_cu_count() / rows);
     const int spw = (n_strips + slots - 1) / slots;
-    hipLaunchKernelGGL((k_gemm16_vocab<MT, RD>), dim3((n_strips + spw - 1) / spw, rows), dim3(256), lds, s, a, spw);
+    hipLaunchKernelGGL((k_gemm16_vocab<MT, RD, NWV>), dim3((n_strips + spw - 1) / spw, rows), dim3(64 * NWV), lds, s, a, spw);
+}
+template <int MT, int RD> static void launch_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
+    // waves per workgroup: a workgroup walks ~12.7 strips = 6.4 strip pairs at Whisper-small's vocabulary; with four waves some take two pairs and some one
+    static const int nwv = getenv("SKW_DEC_VOCAB_WAVES") ? atoi(getenv("SKW_DEC_VOCAB_WAVES")) : 8;      // eight: 21.0 us per launch against 22.5 (tools/dec_gemm_probe.py), same arithmetic per output
+    if (nwv == 4) launch_gemm16_vocab_n<MT, RD, 4>(a, s); else launch_gemm16_vocab_n<MT, RD, 8>(a, s);
 }
 // plain f32 output with optional bias, no residual; false when the geometry is outside what it handles
 static bool skw_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
