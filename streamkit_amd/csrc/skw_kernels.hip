@@ -722,18 +722,24 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float* pcm, const long
         x[j] = v;
     }
     __syncthreads();
-    // 16 leaf DFTs of length 25: leaf o holds x[o + 16 n]
-    for (int u = tid; u < 400; u += 128) {
-        int o = u / 25, k = u % 25;
-        float re = 0.0f, im = 0.0f;
+    // 16 leaf DFTs of length 25: leaf o holds x[o + 16 n].  A thread owns one output bin k of up to four leaves (o = og, og + 5, og + 10, og + 15):
+    // the twiddle of term n is the same for all of them, so it is fetched (and its index advanced) once per term instead of once per output —
+    // each output is still its own n-ascending chain of separately rounded products and sums.
+    if (tid < 125) {
+        const int k = tid % 25, og = tid / 25;
+        float re[4] = {0.0f, 0.0f, 0.0f, 0.0f}, im[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const int step = (k * 16) % 400; int idx = 0;          // (k * n * 16) % 400 without a division per term
+        const bool four = og == 0;                             // leaf 15 exists only for og = 0
         for (int n = 0; n < 25; ++n) {
-            float xin = x[o + 16 * n];
-            re += xin * cs_t[idx];
-            im -= xin * sn_t[idx];
+            const float c = cs_t[idx], sn = sn_t[idx];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const float xin = x[og + 5 * j + 16 * n]; re[j] += xin * c; im[j] -= xin * sn; }
+            if (four) { const float xin = x[15 + 16 * n]; re[3] += xin * c; im[3] -= xin * sn; }
             idx += step; if (idx >= 400) idx -= 400;
         }
-        bufA[2 * (o * 25 + k)] = re; bufA[2 * (o * 25 + k) + 1] = im;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int o = og + 5 * j; bufA[2 * (o * 25 + k)] = re[j]; bufA[2 * (o * 25 + k) + 1] = im[j]; }
+        if (four) { bufA[2 * (15 * 25 + k)] = re[3]; bufA[2 * (15 * 25 + k) + 1] = im[3]; }
     }
     __syncthreads();
     float* src = bufA; float* dst = bufB;
