@@ -107,12 +107,22 @@ def lib():
     return _LIB
 
 
+_TOKEN_DT = np.dtype([("id", "<i4"), ("tid", "<i4"), ("p", "<f4"), ("plog", "<f4"), ("pt", "<f4"), ("ptsum", "<f4"), ("margin", "<f4")])      # struct Token
+_SEGMENT_DT = np.dtype([("t0", "<i8"), ("t1", "<i8"), ("tok_begin", "<i4"), ("tok_end", "<i4"), ("text_off", "<i4"), ("text_len", "<i4")])      # struct Segment
+assert _TOKEN_DT.itemsize == C.sizeof(Token) and _SEGMENT_DT.itemsize == C.sizeof(Segment)
+
+
 def _result_to_dict(r):
     text = C.string_at(r.text, r.text_len) if r.text else b""
-    toks = [(r.tokens[i].id, r.tokens[i].tid, r.tokens[i].p, r.tokens[i].plog, r.tokens[i].margin) for i in range(r.n_tokens)]
-    segs = [dict(t0=r.segments[i].t0, t1=r.segments[i].t1,
-                 tokens=[t[0] for t in toks[r.segments[i].tok_begin:r.segments[i].tok_end]],
-                 text=text[r.segments[i].text_off:r.segments[i].text_off + r.segments[i].text_len]) for i in range(r.n_segments)]
+    if r.n_tokens > 0:      # one structured view of the token array instead of five ctypes field reads per token (5 ms per 64 results in the bench's timed step)
+        a = np.frombuffer((C.c_char * (r.n_tokens * C.sizeof(Token))).from_address(C.addressof(r.tokens.contents)), dtype=_TOKEN_DT)
+        toks = list(zip(a["id"].tolist(), a["tid"].tolist(), a["p"].tolist(), a["plog"].tolist(), a["margin"].tolist()))
+    else:
+        toks = []
+    segs = []
+    if r.n_segments > 0:
+        sg = np.frombuffer((C.c_char * (r.n_segments * C.sizeof(Segment))).from_address(C.addressof(r.segments.contents)), dtype=_SEGMENT_DT).tolist()
+        segs = [dict(t0=t0, t1=t1, tokens=[t[0] for t in toks[b:e]], text=text[o:o + n]) for (t0, t1, b, e, o, n) in sg]
     return dict(segments=segs, tokens=toks, n_windows=r.n_windows, n_decode_steps=r.n_decode_steps,
                 fallback_requested=r.fallback_requested, min_margin=r.min_margin, lang_id=r.lang_id)
 
