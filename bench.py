@@ -7,10 +7,12 @@ c -> rank c mod N (independent clips: no data-path collective), then one RCCL al
 `python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (fresh child processes; the parent never
 touches the GPU); under torchrun it is one of the ranks.  Rank 0 prints ONE JSON line.
 
-The headline runs the f16-MFMA precision (f16 operands on the f16 matrix cores, f32 accumulate; its transcripts are compared
-with the exact mode's on every clip of the batch — they may differ only from a near-tie of the greedy argmax on, DESIGN.md §1 —
-and with the CPU oracle's on a sample); the exact mode (f32-chain contractions, bit-identical to the oracle) is timed beside
-it and reported under "modes".
+The headline runs the f16-MFMA precision (f16 operands on the f16 matrix cores, f32 accumulate).  Outside the timed region every one of
+its greedy decisions on this batch is checked against the exact precision under teacher forcing (streamkit_amd/parity.py; the line carries
+steps_checked / argmax_disagreements / max_margin_at_disagreement, and the process exits non-zero when a decision differs away from a
+near-tie); the exact mode (f32-chain contractions, bit-identical to the CPU oracle) is timed beside it and reported under "modes", and a
+sample of clips is compared with the oracle in the cpu_baseline leg.  `value` is with the PCM resident in HBM (the bench contract);
+`value_pcie_inclusive` starts from pinned host memory.
 """
 import argparse
 import json
@@ -113,8 +115,18 @@ def main():
     tool = os.path.join(ROOT, "tools", "make_synth_model")
     if not os.path.exists(tool):
         subprocess.check_call(["gcc", "-O2", "-o", tool, tool + ".c", "-lm"])
-    path = "/tmp/skw_bench_%s_r%d.bin" % (args.size, file_rank)
-    subprocess.check_call([tool, path, "--size", args.size, "--seed", "1234"])
+    # one model file per node, written by local rank 0 (eight concurrent 0.49 GB generations would make the first multi-GPU run host-bound before the
+    # timed region); the generator is deterministic, the rename is atomic, the other ranks wait for the name to appear
+    path = "/tmp/skw_bench_%s_seed1234_v3.bin" % args.size
+    if file_rank == 0:
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        subprocess.check_call([tool, tmp, "--size", args.size, "--seed", "1234"])
+        os.replace(tmp, path)
+        open(path + ".ready", "w").write(str(os.stat(path).st_mtime_ns))
+    if world > 1:
+        dist.barrier()          # every rank of this node sees rank 0's file from here on (one node: the driver's launch shape)
+    if not os.path.exists(path):
+        raise SystemExit("rank %d: model file %s was not written" % (rank, path))
     model = engine.Model(path, device=local_rank)
     hp = model.hp
     B = args.clips
@@ -200,6 +212,19 @@ def main():
                      "note": "transcripts may differ only from a near-tie of the greedy argmax on (DESIGN.md section 1; tests/test_gpu_f16.py bounds the margin)"}
         ctx.set_precision(args.precision)
 
+    # every decision of the f16_mfma precision on THIS batch, checked against the exact precision under teacher forcing (streamkit_amd/parity.py)
+    parity = None
+    if not args.no_other_mode:
+        from streamkit_amd.parity import teacher_forced_compare
+        tf = teacher_forced_compare(ctx, None, params, device_ptrs=ptrs, n_samples=ns)
+        parity = {k: tf[k] for k in ("steps_checked", "argmax_disagreements", "disagreements_on_exact_runner_up", "max_margin_at_disagreement", "max_logit_err", "logit_err_bound", "margin_bound", "ok")}
+        parity["clips_checked"] = len(tf["per_clip"])
+        parity["what"] = ("f16_mfma fed the exact precision's tokens: each of its greedy decisions, on every clip and step of this batch, equals the exact one "
+                          "or sits where the exact top1 - top2 logit margin is below margin_bound; deciding logits agree within logit_err_bound")
+        if identical is not None:
+            parity["free_running_identical_clips"] = identical["identical_clips"]; parity["of"] = identical["of"]
+        ctx.set_precision(args.precision)
+
     fast = args.precision == "f16_mfma"
     out = {
         "metric": "real-time factor (audio-sec/wall-sec) Whisper-small Oneshot batch",
@@ -215,6 +240,7 @@ def main():
                    "fallback_requested": int(sum(r["fallback_requested"] for r in res))},
         "modes": modes,
         "transcripts_f16_vs_exact": identical,
+        "parity_f16_vs_exact_teacher_forced": parity,
         "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
         "value_pcie_inclusive": round(pcie_value, 2),
     }
@@ -255,19 +281,34 @@ def main():
         else:
             ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
-        roof.update({"traffic": traffic, "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern})
+        roof.update({"traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured by this run)",
+                     "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern})
+        if name == "k_dec_cross_attn":
+            # `achieved` books the bytes of LIVE rows only (a finished sequence's workgroups return at once): sum over launches of 4 x live rows x n_ctx x d,
+            # over the summed launch time.  Beside it: one full launch (all rows live) in isolation, back to back over 12 different K / V^T images.
+            import ctypes as C
+            Lb = engine.lib()
+            Lb.skw_debug_xattn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+            us = C.c_float()
+            if Lb.skw_debug_xattn(ctx.h, B, hp.n_text_layer, 0, 240, C.byref(us)) == 0 and us.value > 0:
+                full_bytes = 4.0 * B * hp.n_audio_ctx * hp.n_text_state
+                roof["full_launch"] = {"rows": B, "bytes": full_bytes, "us": round(us.value, 2), "achieved": round(full_bytes / us.value / 1e3, 1), "unit": "GB/s",
+                                       "frac": round(full_bytes / us.value / 1e3 / HBM_PEAK_GBS, 4)}
+            roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * 4.0 * B * hp.n_audio_ctx * hp.n_text_state), 4)
+            roof["booking"] = "algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state per launch (K and V^T, f16), live rows counted per step on the host"
         # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times
-        nwin, nsteps = timing["n_windows"], timing["n_decode_steps"]
+        nwin, nsteps, nrow = timing["n_windows"], timing["n_decode_steps"], timing["n_row_steps"]
         d, dt_, nc, L = hp.n_audio_state, hp.n_text_state, hp.n_audio_ctx, hp.n_text_layer
         enc_fl = sum(prof[k]["flops"] for k in ("k_gemm", "k_attn_encoder"))                  # 386.7 GF per window at Whisper-small
         xkv = 2.0 * L * nc * dt_ * 2                                                           # cross K/V bytes per sequence per step (55.3 MB)
         dec_w = 2.0 * (L * (4 * dt_ * dt_ + 4 * dt_ * dt_ + 8 * dt_ * dt_) + hp.n_vocab * dt_)  # decoder weights streamed per step (306 MB)
-        dec_bytes = nsteps * (B * xkv + dec_w)
+        dec_bytes = nrow * xkv + nsteps * dec_w                                                  # cross K/V only for the steps a row was live in
         fe_bytes = nwin * (n_samples * 4 + 2 * nc * hp.n_mels * 4.0)
         t_enc, t_dec, t_fe = timing["encode_ms"] * 1e-3, timing["decode_ms"] * 1e-3, timing["mel_ms"] * 1e-3
         ph = {"encode": {"bound": "mfma", "achieved": round(enc_fl / t_enc / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s", "ms": round(t_enc * 1e3, 3)},
               "decode": {"bound": "hbm", "achieved": round(dec_bytes / t_dec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms": round(t_dec * 1e3, 3),
-                         "bytes": "steps x (B x %.1f MB cross K/V + %.0f MB weights)" % (xkv / 1e6, dec_w / 1e6), "steps": nsteps},
+                         "bytes": "row-steps x %.1f MB cross K/V + steps x %.0f MB weights" % (xkv / 1e6, dec_w / 1e6), "steps": nsteps, "row_steps": nrow,
+                         "live_row_fraction": round(nrow / max(1.0, float(nsteps) * B), 4)},
               "front_end": {"bound": "hbm", "achieved": round(fe_bytes / t_fe / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms": round(t_fe * 1e3, 3)}}
         for v in ph.values():
             v["frac"] = round(v["achieved"] / v["peak"], 4)
@@ -305,6 +346,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: the f16_mfma precision left the exact precision away from a near-tie (max margin %s, max logit error %s)\n"
+                         % (parity["max_margin_at_disagreement"], parity["max_logit_err"]))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -369,6 +369,8 @@ struct skw_ctx {
     int* h_row_live = nullptr; int* d_row_live = nullptr;      // per-row live flags in pinned host memory and their device-side address: k_dec_sample clears a row's flag itself,
                                                                // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
+    int live_rows_hint = -1;                         // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
+    int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
     skw_timing timing{};
     int last_enc_B = 0;
 };
@@ -439,7 +441,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
     c->step_graphs.clear();
     for (int g = 0; g < skw_ctx::MAX_GROUPS; ++g) { if (c->gstream[g]) { hipStreamSynchronize(c->gstream[g]); hipStreamDestroy(c->gstream[g]); } if (c->gev[g]) hipEventDestroy(c->gev[g]); }
     for (void* p : c->allocs) hipFree(p);
-    hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map);
+    hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); hipFree(c->forced_dev); hipFree(c->trace_dev);
     if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_row_live) hipHostFree(c->h_row_live);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -679,6 +681,7 @@ __global__ void k_lang_argmax(const float* logits, int n_vocab, int tok_sot, int
 static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logits, hipStream_t s) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int dt = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, ntc = hp.n_text_ctx;
     const float KQscale = (float)pow((double)((float)dt / H), -0.25);
+    const int live = c->live_rows_hint >= 0 ? std::min(c->live_rows_hint, Bw) : Bw;      // rows whose attention kernels do work (algorithmic-byte booking of the profile)
     c->cur = s;
     float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
     half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = c->st + r0;
@@ -691,13 +694,13 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
             Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
-            { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt);
+            { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
               SkwQ8Out qo{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), Bw};
               skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo); }
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.cross_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0, true); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
             Q8_ROWS(c, datt32, dt, Bw, dt, r0);
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.mlp_ln, r0, dy32);
@@ -728,7 +731,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s, tail || (l == 0 && embed_ln)); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * Bw * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
@@ -736,7 +739,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt, 4.0 * Bw * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s, tail); }
@@ -847,10 +850,19 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
     return 0;
 }
 
-extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
+static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results,
+                           const int32_t* const* forced_ids, const int32_t* n_forced, std::vector<std::vector<SkwTraceStep>>* traces) {
     char* errbuf = c->errbuf; errbuf[0] = 0;
     if (n_clips < 1 || n_clips > c->max_batch) { snprintf(errbuf, 512, "n_clips %d outside [1, %d]", n_clips, c->max_batch); return -1; }
     HIPCHK(hipSetDevice(c->m->device));
+    const bool tracing = traces != nullptr;
+    std::vector<int> f_cursor(n_clips, 0);      // tracing: decisions of clip i made so far (= its position in forced_ids[i])
+    if (tracing && !c->trace_dev) {
+        int* f = nullptr; SkwTraceStep* t = nullptr;
+        if (hipMalloc((void**)&f, sizeof(int) * (size_t)c->max_batch * c->max_tok) != hipSuccess || hipMalloc((void**)&t, sizeof(SkwTraceStep) * (size_t)c->max_batch * c->max_tok) != hipSuccess) {
+            hipFree(f); snprintf(errbuf, 512, "trace buffers: device allocation failed"); return -1; }
+        c->forced_dev = f; c->trace_dev = t;
+    }
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int NV = hp.n_vocab;
     for (int i = 0; i < n_clips; ++i) { memset(&results[i], 0, sizeof(skw_result)); results[i].min_margin = INFINITY; }
     std::vector<int> n_len, n_len_org;
@@ -859,7 +871,7 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     build_static_mask(c, p);
     run_mel(c, n_clips);
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0;
+    float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0; long tot_row_steps = 0;
 
     std::vector<int> seek(n_clips, 0); std::vector<SeqAcc> acc(n_clips);
     // temperature ladder (whisper_full_with_state): per clip, the index of the temperature its current window is decoded at
@@ -926,6 +938,13 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             np_row[j] = n;
         }
         HIPCHK(hipMemcpyAsync(c->prompt_buf, pbuf.data(), sizeof(int) * pbuf.size(), hipMemcpyHostToDevice, c->stream));
+        std::vector<int> fbuf;
+        if (tracing) {      // this pass's forced tokens per row: the clip's sequence from its cursor on (-1 = none: the row feeds its own choices)
+            fbuf.assign((size_t)Bw * c->max_tok, -1);
+            if (forced_ids) for (int j = 0; j < Bw; ++j) { const int ci = act[j]; if (!forced_ids[ci]) continue;
+                for (int k = 0; k < c->max_tok && f_cursor[ci] + k < n_forced[ci]; ++k) fbuf[(size_t)j * c->max_tok + k] = forced_ids[ci][f_cursor[ci] + k]; }
+            HIPCHK(hipMemcpyAsync(c->forced_dev, fbuf.data(), sizeof(int) * fbuf.size(), hipMemcpyHostToDevice, c->stream));
+        }
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
         if (R < Bw) { run_conv(c, Bw, R); run_encoder(c, Bw, false, true, R); }
         HIPCHK(hipEventRecord(c->ev[3], c->stream));
@@ -949,10 +968,11 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         // every step = decoder step (token and position from the device state) + k_dec_sample, which feeds the next prompt token
         // while a row is still inside its prompt and samples afterwards; rows have prompts of different lengths
         hipGraphExec_t gexec[skw_ctx::MAX_GROUPS] = {};
-        if (use_graphs && !profiling) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
+        if (use_graphs && !profiling && !tracing) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->d_row_live + g_r0[g], c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g]); }
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->d_row_live + g_r0[g], c->probs + (size_t)g_r0[g] * NV, c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g],
+                                                                                     tracing ? c->forced_dev + (size_t)g_r0[g] * c->max_tok : nullptr, tracing ? c->trace_dev + (size_t)g_r0[g] * c->max_tok : nullptr); }
             c->cur = c->stream;
             return hipSuccess;
         };
@@ -968,7 +988,10 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
             for (int k = 0; k < nstep; ++k)
                 for (int g = 0; g < G; ++g) if (g_live[g]) {
                     if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
-                    else { run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); HIPCHK(sample(g)); }
+                    else {
+                        if (profiling) { int lv = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) lv += ((volatile int*)c->h_row_live)[j] != 0; c->live_rows_hint = lv; }   // (ahead == 1: the previous step has drained)
+                        run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); c->live_rows_hint = -1; HIPCHK(sample(g));
+                    }
                 }
             bool any = false;
             for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); int live = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) live += ((volatile int*)c->h_row_live)[j] != 0;
@@ -980,9 +1003,19 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
         HIPCHK(hipMemcpyAsync(c->h_toks, c->toks, sizeof(SkwTokenOut) * Bw * c->max_tok, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(c->ev[4], c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (tracing) {
+            std::vector<SkwTraceStep> tb((size_t)Bw * c->max_tok);
+            HIPCHK(hipMemcpy(tb.data(), c->trace_dev, sizeof(SkwTraceStep) * tb.size(), hipMemcpyDeviceToHost));
+            for (int j = 0; j < Bw; ++j) {
+                const int ci = act[j], n = std::min(c->h_st[j].n_tokens, c->max_tok);
+                if (forced_ids && forced_ids[ci] && f_cursor[ci] + n > n_forced[ci]) { snprintf(errbuf, 512, "clip %d: forced token sequence exhausted (%d given, decision %d reached): the runs' control flow diverged", ci, n_forced[ci], f_cursor[ci] + n); return -4; }
+                (*traces)[ci].insert((*traces)[ci].end(), tb.begin() + (size_t)j * c->max_tok, tb.begin() + (size_t)j * c->max_tok + n);
+                f_cursor[ci] += n;
+            }
+        }
         { float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[2], c->ev[3]); hipEventElapsedTime(&b, c->ev[3], c->ev[4]); enc_ms += a; dec_ms += b; }
         tot_windows += Bw;
-        { int mx = 0; for (int j = 0; j < Bw; ++j) mx = std::max(mx, c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens); tot_steps += mx; }   // decoder steps until the last row finished
+        { int mx = 0; for (int j = 0; j < Bw; ++j) { const int rs = c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens; mx = std::max(mx, rs); tot_row_steps += rs; } tot_steps += mx; }   // decoder steps until the last row finished; row-steps: steps a row was live in
         // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];
@@ -1041,9 +1074,30 @@ extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float*
     }
     prof_collect(c);
     { float a = 0, t = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&t, c->ev[0], c->ev[5]);
-      c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms; c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps; c->timing.n_tokens = tot_tokens; }
+      c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms; c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps; c->timing.n_tokens = tot_tokens; c->timing.n_row_steps = (int32_t)tot_row_steps; }
     return 0;
 }
+extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
+    try { return full_batch_impl(c, p, pcm, n_samples, n_clips, pcm_on_device, results, nullptr, nullptr, nullptr); }
+    catch (const std::exception& e) { snprintf(c->errbuf, 512, "skw_full_batch: %s", e.what()); return -5; }      // nothing may unwind across the C ABI
+}
+extern "C" int skw_full_batch_traced(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device,
+                                     const int32_t* const* forced_ids, const int32_t* n_forced, skw_trace* traces, skw_result* results) {
+    static_assert(sizeof(skw_trace_step) == sizeof(SkwTraceStep), "skw_trace_step is SkwTraceStep");
+    try {
+        if (!traces || (forced_ids && !n_forced)) { snprintf(c->errbuf, 512, "skw_full_batch_traced: bad arguments"); return -1; }
+        for (int i = 0; i < n_clips; ++i) { traces[i].n = 0; traces[i].steps = nullptr; }
+        std::vector<std::vector<SkwTraceStep>> tr(std::max(0, n_clips));
+        const int rc = full_batch_impl(c, p, pcm, n_samples, n_clips, pcm_on_device, results, forced_ids, n_forced, &tr);
+        if (rc) return rc;
+        for (int i = 0; i < n_clips; ++i) {
+            traces[i].n = (int32_t)tr[i].size(); traces[i].steps = (skw_trace_step*)malloc(sizeof(skw_trace_step) * std::max<size_t>(1, tr[i].size()));
+            memcpy(traces[i].steps, tr[i].data(), sizeof(skw_trace_step) * tr[i].size());
+        }
+        return 0;
+    } catch (const std::exception& e) { snprintf(c->errbuf, 512, "skw_full_batch_traced: %s", e.what()); return -5; }
+}
+extern "C" void skw_trace_free(skw_trace* t) { if (!t) return; free(t->steps); t->steps = nullptr; t->n = 0; }
 extern "C" void skw_result_free(skw_result* r) { if (!r) return; free(r->segments); free(r->tokens); free(r->text); memset(r, 0, sizeof *r); }
 
 // ------------------------------------------------------------------ stage taps

@@ -125,6 +125,10 @@ struct SkwSeqState {
 #define SKW_PROMPT_CAP 240   // [prev] + n_text_ctx/2 past tokens + sot, language, task, notimestamps
 #define SKW_RNG_WORDS 625   // std::mt19937 state per clip: mt[624] + index
 struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum, margin; };
+// one sampling decision as the trace / teacher-forced mode records it (skw_full_batch_traced): what this precision would have chosen, what it was made to
+// feed instead (forced_id == chosen_id in a free run), the two largest admissible logits with their owners, the (filtered) logit of the fed token and the
+// log-sum-exp of the admissible logits.  Layout == skw_trace_step of include/skw_engine.h.
+struct SkwTraceStep { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; };
 struct SkwLogitParams {
     int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
     int n_lang; int tok_space, tok_sp_dash, tok_sp_quote;
@@ -141,7 +145,8 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
 // probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
 // n_active: [B] live flags (1 while the row decodes; the kernel stores 0 when it completes or fails) — host-mapped memory in the engine
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
-                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s);
+                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s,
+                    const int* forced = nullptr /* [B][max_tok]: token to feed after decision i instead of the chosen one (< 0: the chosen one) */, SkwTraceStep* trace = nullptr /* [B][max_tok] */);
 void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip
 
 // ---------------- resampler (R1) ----------------

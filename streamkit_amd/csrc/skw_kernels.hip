@@ -1346,8 +1346,21 @@ __device__ int discrete_draw(const float* probs, int n, uint32_t* mt) {
     return n - 1;
 }
 
+// Trace / teacher-forced decisions (skw_full_batch_traced): record what this precision chose and, when `forced` names another token, feed that one —
+// the state below then evolves exactly as in the run the forced tokens came from.  lg: the row's logits in memory (filtered in place by the streaming
+// kernel and by sampled passes; raw otherwise — the same number for an admissible token).
+__device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg, float lse, int i, int max_tok, long row, const int* forced, SkwTraceStep* trace,
+                                               int i1, int i2, float t1, float t2, const SkwLogitParams& p) {
+    if (!trace || i >= max_tok) return;
+    int fid = forced ? forced[row * max_tok + i] : -1;
+    if (fid < 0 || fid >= p.n_vocab) fid = tk.id;
+    SkwTraceStep ts; ts.chosen_id = tk.id; ts.forced_id = fid; ts.top1_id = i1; ts.top2_id = (t2 > -INFINITY) ? i2 : -1; ts.top1 = t1; ts.top2 = t2; ts.forced_logit = lg[fid]; ts.lse = lse;
+    trace[row * max_tok + i] = ts;
+    if (fid != tk.id) { tk.id = fid; tk.plog = lg[fid] - lse; tk.p = skw_expf(tk.plog); }
+}
 __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
-                                                     int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf) {
+                                                     int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf,
+                                                     const int* forced, SkwTraceStep* trace) {
     __shared__ float sh_f[16]; __shared__ double sh_d[16]; __shared__ ArgBest sh_a[16];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     SkwSeqState* st = &st_all[b];
@@ -1429,11 +1442,12 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
     SkwTokenOut tk; tk.id = best.i; tk.p = best.v;
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; }
     tk.plog = lg[tk.id] - lse;
+    const int i = n_tok;
+    smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, best.i, -1, t1, t2, p);
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
     tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;
     if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
-    const int i = n_tok;
     if (i < max_tok) toks[i] = tk;
     st->n_tokens = i + 1;
     int failed = 0, completed = 0;
@@ -1470,8 +1484,10 @@ struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; flo
 #define SMP_PASS_BEGIN { int tq = tid; asm volatile("" : "+v"(tq));
 #define SMP_PASS_END }
 #define SMP_IDX(c) (tq + SMP_NT * (c))
+template <bool TRACE>      // TRACE: the trace / teacher-forced form (one more pass for the runner-up's index); the decode step's graph holds <false>
 __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
-                                                       int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf) {
+                                                       int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf,
+                                                       const int* forced, SkwTraceStep* trace) {
     __shared__ float sh_f[2][SMP_NT / 64]; __shared__ double sh_d[SMP_NT / 64]; __shared__ SmpMain sh_m[SMP_NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     SkwSeqState* st = &st_all[b];
@@ -1623,6 +1639,18 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     t1 = sh_t1[0]; t2 = sh_t2[0]; i1 = sh_i1[0];
     for (int k = 1; k < SMP_NT / 64; ++k) { const float o1 = sh_t1[k], o2 = sh_t2[k]; const int oi = sh_i1[k];
         if (o1 > t1 || (o1 == t1 && oi < i1)) { t2 = fmaxf(t1, o2); t1 = o1; i1 = oi; } else t2 = fmaxf(t2, o1); }
+    int i2 = 0x7fffffff;
+    if (TRACE) {      // owner of the runner-up: lowest index other than i1 that holds t2
+        SMP_PASS_BEGIN
+#pragma unroll
+        for (int c = 0; c < SMP_PT; ++c) { const int i = SMP_IDX(c); if (v[c] == t2 && i != i1 && i < i2) i2 = i; }
+        SMP_PASS_END
+        for (int o = 32; o > 0; o >>= 1) i2 = min(i2, __shfl_xor(i2, o, 64));
+        __syncthreads();
+        if (lane == 0) sh_i1[w] = i2;
+        __syncthreads();
+        i2 = sh_i1[0]; for (int k = 1; k < SMP_NT / 64; ++k) i2 = min(i2, sh_i1[k]);
+    }
     const bool fast = !sampled && (t1 - t2 > 1e-4f);           // (t2 == -inf: a single admissible token)
     const int c_lo = fast ? tx : 0;
     // best token over probs = expf(logprob), first index wins ties; timestamp statistics
@@ -1666,11 +1694,12 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     const ArgBest best = r.best, bts = r.bts; const double sum_ts = r.sum_ts;
     SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = r.best_logit - lse;
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
+    const int i = n_tok;
+    if (TRACE) smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, i1, i2, t1, t2, p);
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
     tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;
     if (!sampled && t2 > -INFINITY && t1 - t2 < st->min_margin) st->min_margin = t1 - t2;   // argmax passes only (diagnostic)
-    const int i = n_tok;
     if (i < max_tok) toks[i] = tk;
     st->n_tokens = i + 1;
     int failed = 0, completed = 0;
@@ -1701,9 +1730,11 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
     for (int i = 0; i < n_vocab && i < SMP_PT * SMP_NT; ++i) if (mask[i]) { const int t = i % SMP_NT, c = i / SMP_NT; kw[(c >> 6) * SMP_NT + t] |= 1ull << (c & 63); }
 }
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
-                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s) {
-    if (p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) hipLaunchKernelGGL(k_dec_sample, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
-    else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf);
+                    float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s, const int* forced, SkwTraceStep* trace) {
+    if (p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) {
+        if (trace) hipLaunchKernelGGL(k_dec_sample<true>, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
+        else hipLaunchKernelGGL(k_dec_sample<false>, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
+    } else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
 }
 
 // ------------------------------------------------------------------ R1: audio::resampler arithmetic (rubato FastFixedIn, Linear)

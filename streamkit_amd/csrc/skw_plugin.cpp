@@ -5,7 +5,8 @@
 // ABI: include/streamkit_native_abi.h.
 //
 // Params beyond the reference's are ADDITIVE (unknown keys are ignored by the reference's serde config, lib.rs:66-104):
-// vad_mode, batch_window_ms, max_batch, flush_tail, precision, and gpu_device: "auto".
+// vad_mode, batch_window_ms, max_batch, flush_tail, precision, gpu_device: "auto", and input_sample_rate / input_resample_mode (the
+// audio::resampler node's arithmetic run inside this plugin, skw_resampler_core.h: a 48 kHz Opus source then needs no node in between).
 // One BEHAVIOURAL difference remains and is not additive: with the default vad_mode "auto" the Silero model at `vad_model_path`
 // gates what Whisper sees exactly as in the reference (skw_silero.h) only when that file exists; when it does not, the
 // reference fails ("Failed to initialize VAD: ...") while this build logs a warning and falls back to an RMS energy gate
@@ -15,6 +16,7 @@
 #include "../../include/skw_engine.h"
 #include "skw_segmenter.h"
 #include "skw_silero.h"
+#include "skw_resampler_core.h"
 #include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
@@ -26,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <future>
 #include <map>
 #include <memory>
@@ -44,6 +47,13 @@ CResult err_result(const std::string& msg) {
     CResult r; r.success = false; r.error_message = g_last_error.c_str(); return r;
 }
 CResult err_null() { CResult r; r.success = false; r.error_message = nullptr; return r; }
+// Nothing may unwind into the host's Rust frames (SURVEY.md section 8b "Errors": panics / C++ exceptions must not cross): every entry point
+// body runs under this — std::bad_alloc / length_error from the buffers, std::system_error from the worker thread, std::future_error ...
+template <typename F> CResult guarded(const char* what, F&& f) {
+    try { return f(); }
+    catch (const std::exception& e) { return err_result(std::string(what) + ": " + e.what()); }
+    catch (...) { return err_result(std::string(what) + ": unknown C++ exception"); }
+}
 
 // ------------------------------------------------------------------ configuration (lib.rs:25-157)
 struct WhisperConfig {
@@ -61,6 +71,7 @@ struct WhisperConfig {
     std::string vad_mode = "auto";   // auto | silero | energy | always
     int batch_window_ms = 2; int max_batch = 64; bool flush_tail = false;
     std::string precision = "exact"; // exact | f16_mfma  (include/skw_engine.h, SKW_PRECISION_*)
+    uint32_t input_sample_rate = 16000; std::string input_resample_mode = "linear";   // linear (the audio::resampler node's rubato arithmetic, bit for bit) | polyphase
 };
 
 bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
@@ -75,6 +86,9 @@ bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
     double d;
     if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode) || !str("precision", &cfg->precision)) return false;
     if (cfg->precision != "exact" && cfg->precision != "f16_mfma") { *err = "Invalid config: precision must be \"exact\" or \"f16_mfma\""; return false; }
+    if (!str("input_resample_mode", &cfg->input_resample_mode)) return false;
+    if (cfg->input_resample_mode != "linear" && cfg->input_resample_mode != "polyphase") { *err = "Invalid config: input_resample_mode must be \"linear\" or \"polyphase\""; return false; }
+    d = cfg->input_sample_rate; if (!num("input_sample_rate", &d)) return false; if (d < 1000 || d > 768000 || d != std::floor(d)) { *err = "Invalid config: input_sample_rate must be an integer between 1000 and 768000"; return false; } cfg->input_sample_rate = (uint32_t)d;
     d = cfg->vad_threshold; if (!num("vad_threshold", &d)) return false; cfg->vad_threshold = (float)d;
     d = (double)cfg->min_silence_duration_ms; if (!num("min_silence_duration_ms", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: min_silence_duration_ms must be a non-negative integer"; return false; } cfg->min_silence_duration_ms = (uint64_t)d;
     d = cfg->max_segment_duration_secs; if (!num("max_segment_duration_secs", &d)) return false; cfg->max_segment_duration_secs = (float)d;
@@ -98,7 +112,20 @@ struct Job {
     std::vector<float> pcm; skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
 };
 struct SharedEngine {
-    skw_model* model = nullptr; skw_ctx* ctx = nullptr; int max_batch = 64; int window_ms = 2; int max_samples = 0;
+    skw_model* model = nullptr; skw_ctx* ctx = nullptr; int max_batch = 64; int window_ms = 2; int max_samples = 0; int precision = SKW_PRECISION_EXACT;
+    static const int kMaxSamples = 16000 * 121;   // schema maximum of max_segment_duration_secs (120 s) + one VAD frame of slack: no segment is longer
+    static int samples_for(float max_segment_secs) { const double s = std::min(120.0, std::max(1.0, (double)max_segment_secs)); return std::min(kMaxSamples, (int)std::ceil(s * 16000.0) + 1024); }
+    // The workspace is sized for the longest segment an instance of this engine can cut (its max_segment_duration_secs), not for the schema's
+    // maximum: 31 s by default instead of 121 (0.2 GB instead of 0.8 at 64 rows).  An instance that allows longer segments grows it, between batches.
+    bool ensure_samples(int need, std::string* err) {
+        if (need <= max_samples) return true;
+        char ebuf[512] = {0};
+        skw_ctx* nc = skw_ctx_create(model, max_batch, need, ebuf, sizeof ebuf);
+        if (!nc) { *err = std::string("Failed to create Whisper state: ") + ebuf; return false; }
+        skw_ctx_set_precision(nc, precision);
+        if (ctx) skw_ctx_free(ctx);
+        ctx = nc; max_samples = need; return true;
+    }
     std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<Job>> queue; bool stop = false; std::thread worker;
     ~SharedEngine() {
         { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); if (worker.joinable()) worker.join();
@@ -121,13 +148,16 @@ struct SharedEngine {
                 }
             }
             const int n = (int)batch.size();
-            std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n);
-            for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->pcm.data(); ns[i] = (int32_t)batch[i]->pcm.size(); }
-            int rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
-            for (int i = 0; i < n; ++i) {
-                if (rc == 0) batch[i]->result = res[i]; else batch[i]->error = skw_ctx_last_error(ctx);
-                batch[i]->done.set_value(rc);
-            }
+            int rc = -1; std::string why;
+            try {
+                std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n); int need = 0;
+                for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->pcm.data(); ns[i] = (int32_t)batch[i]->pcm.size(); need = std::max(need, (int)ns[i]); }
+                if (ensure_samples(need, &why)) {
+                    rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
+                    if (rc == 0) for (int i = 0; i < n; ++i) batch[i]->result = res[i]; else why = skw_ctx_last_error(ctx);
+                }
+            } catch (const std::exception& e) { rc = -1; why = e.what(); }     // the worker thread must not die with waiters blocked on it
+            for (int i = 0; i < n; ++i) { if (rc != 0) batch[i]->error = why; batch[i]->done.set_value(rc); }
         }
     }
 };
@@ -145,10 +175,8 @@ std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, std::string* 
     eng->model = skw_model_load(cfg.model_path.c_str(), cfg.gpu_device, ebuf, sizeof ebuf);
     if (!eng->model) { *err = ebuf[0] ? ebuf : ("Failed to load Whisper model from '" + cfg.model_path + "'"); return nullptr; }
     eng->max_batch = cfg.max_batch; eng->window_ms = cfg.batch_window_ms;
-    eng->max_samples = 16000 * 121;   // schema maximum of max_segment_duration_secs (120 s) + one VAD frame of slack
-    eng->ctx = skw_ctx_create(eng->model, eng->max_batch, eng->max_samples, ebuf, sizeof ebuf);
-    if (!eng->ctx) { *err = std::string("Failed to create Whisper state: ") + ebuf; return nullptr; }
-    skw_ctx_set_precision(eng->ctx, cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT);
+    eng->precision = cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT;
+    if (!eng->ensure_samples(SharedEngine::samples_for(cfg.max_segment_duration_secs), err)) return nullptr;
     eng->worker = std::thread([e = eng.get()] { e->run(); });
     g_cache[key] = eng;
     return eng;
@@ -166,6 +194,7 @@ void resolve_auto_device(WhisperConfig* cfg) {
 // ------------------------------------------------------------------ the plugin instance (lib.rs:199-221)
 struct WhisperPlugin {
     WhisperConfig config; std::shared_ptr<SharedEngine> engine; skw::Segmenter seg; std::unique_ptr<skw::Vad> vad;
+    std::unique_ptr<skw::ResamplerCore> front;      // input_sample_rate != 16000: the audio::resampler node's arithmetic on the GPU, feeding the segmenter
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
     void log(CLogLevel lv, const char* fmt, ...) {
         if (!log_cb) return; char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -186,7 +215,8 @@ std::shared_ptr<const skw::SileroWeights> get_silero(const std::string& path, st
     auto it = g_vad_cache.find(path);
     if (it != g_vad_cache.end()) if (auto sp = it->second.lock()) return sp;
     auto w = std::make_shared<skw::SileroWeights>();
-    if (!skw::SileroVad::load_weights(path, w.get(), err)) return nullptr;
+    try { if (!skw::SileroVad::load_weights(path, w.get(), err)) return nullptr; }
+    catch (const std::exception& e) { *err = "Failed to load VAD model from '" + path + "': " + e.what(); return nullptr; }     // a malformed file must not unwind across the C ABI
     g_vad_cache[path] = w; return w;
 }
 
@@ -195,8 +225,15 @@ std::unique_ptr<skw::Vad> make_vad(const WhisperConfig& cfg, WhisperPlugin* p, s
     std::string mode = cfg.vad_mode;
     if (mode == "auto") {
         struct stat sb;
-        if (stat(cfg.vad_model_path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) mode = "silero";
-        else {
+        if (stat(cfg.vad_model_path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            // The file is there: run it — unless this build cannot read it (the graph is restated from the published v5 layout and has only ever
+            // seen files of tools/make_synth_silero.py's making; the reference names v6, vad.rs:5).  In auto mode that is a warning and the energy
+            // gate, not a node that fails to start; `vad_mode: "silero"` keeps the reference's hard failure.
+            std::string e; auto w = get_silero(cfg.vad_model_path, &e);
+            if (w) { if (p) p->log(SK_LOG_INFO, "Silero VAD: %s", w->bound.c_str()); return std::unique_ptr<skw::Vad>(new SileroGate(w)); }
+            if (p) p->log(SK_LOG_WARN, "%s; using vad_mode=energy (set vad_mode to \"silero\" to make this an error)", e.c_str());
+            mode = "energy";
+        } else {
             // the reference fails here; this build keeps running on an energy gate and says so (header comment)
             if (p) p->log(SK_LOG_WARN, "Silero VAD model '%s' not found; using vad_mode=energy (set vad_mode to \"silero\" to make this an error)", cfg.vad_model_path.c_str());
             mode = "energy";
@@ -207,6 +244,7 @@ std::unique_ptr<skw::Vad> make_vad(const WhisperConfig& cfg, WhisperPlugin* p, s
     if (mode == "silero") {
         std::string e; auto w = get_silero(cfg.vad_model_path, &e);
         if (!w) { *err = "Failed to initialize VAD: " + e; return nullptr; }
+        if (p) p->log(SK_LOG_INFO, "Silero VAD: %s", w->bound.c_str());
         return std::unique_ptr<skw::Vad>(new SileroGate(w));
     }
     *err = "Failed to initialize VAD: unknown vad_mode '" + mode + "'"; return nullptr;
@@ -243,7 +281,7 @@ bool transcribe_and_emit(WhisperPlugin* self, const Emit& em, const skw::Segment
     job->params.lang_id = lang; job->params.translate = 0;
     job->params.suppress_blank = self->config.suppress_blank ? 1 : 0; job->params.suppress_nst = self->config.suppress_non_speech_tokens ? 1 : 0;
     job->params.n_threads = (int32_t)self->config.n_threads;
-    if ((int)job->pcm.size() > self->engine->max_samples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
+    if ((int)job->pcm.size() > SharedEngine::kMaxSamples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
     std::future<int> fut = job->done.get_future();
     { std::lock_guard<std::mutex> l(self->engine->mu); self->engine->queue.push_back(job); }
     self->engine->cv.notify_all();
@@ -308,12 +346,17 @@ const char* const kSchema =
     "\"precision\":{\"type\":\"string\",\"description\":\"(additive) exact (f32-chain contractions, bit-reproducible; block-quantised model files run ggml's q8 arithmetic) | f16_mfma (f16 matrix cores; quantised files as their f16 twin)\",\"default\":\"exact\"},"
     "\"batch_window_ms\":{\"type\":\"integer\",\"description\":\"(additive) how long the per-GPU scheduler waits for concurrent instances before launching a batch\",\"default\":2},"
     "\"max_batch\":{\"type\":\"integer\",\"description\":\"(additive) largest number of segments transcribed in one GPU batch\",\"default\":64},"
-    "\"flush_tail\":{\"type\":\"boolean\",\"description\":\"(additive) transcribe buffered speech when the input stream ends (the reference drops it)\",\"default\":false}"
+    "\"flush_tail\":{\"type\":\"boolean\",\"description\":\"(additive) transcribe buffered speech when the input stream ends (the reference drops it)\",\"default\":false},"
+    "\"input_sample_rate\":{\"type\":\"integer\",\"description\":\"(additive) sample rate of the mono f32 packets fed to this node; anything but 16000 is resampled to 16 kHz on the GPU with the audio::resampler node's arithmetic (chunk_frames 960) before VAD segmentation\",\"default\":16000,\"minimum\":1000,\"maximum\":768000},"
+    "\"input_resample_mode\":{\"type\":\"string\",\"description\":\"(additive) linear (rubato FastFixedIn/Linear, bit for bit what audio::resampler gives) | polyphase (Kaiser-windowed sinc)\",\"default\":\"linear\"}"
     "}}";
 
 const CAudioFormat kInFormat = {16000, 1, SK_SAMPLE_F32};
-const CPacketTypeInfo kInTypes[1] = {{SK_PACKET_RAW_AUDIO, &kInFormat, nullptr}};
-const CInputPin kInputs[1] = {{"in", kInTypes, 1}};
+// the reference's one accepted type first; (additive) mono f32 at any rate (0 = wildcard, packet_meta.rs:97-109) so that a graph with
+// `input_sample_rate: 48000` passes the host's connection check — the rate is validated per packet either way (lib.rs:183-197)
+const CAudioFormat kInAnyRate = {0, 1, SK_SAMPLE_F32};
+const CPacketTypeInfo kInTypes[2] = {{SK_PACKET_RAW_AUDIO, &kInFormat, nullptr}, {SK_PACKET_RAW_AUDIO, &kInAnyRate, nullptr}};
+const CInputPin kInputs[1] = {{"in", kInTypes, 2}};
 const COutputPin kOutputs[1] = {{"out", {SK_PACKET_TRANSCRIPTION, nullptr, nullptr}}};
 const char* const kCategories[3] = {"ml", "speech", "transcription"};
 const CNodeMetadata kMetadata = {"whisper", kDescription, kInputs, 1, kOutputs, 1, kSchema, kCategories, 3};
@@ -321,7 +364,7 @@ const CNodeMetadata kMetadata = {"whisper", kDescription, kInputs, 1, kOutputs, 
 // ------------------------------------------------------------------ the six entry points (sdk lib.rs:462-854)
 const CNodeMetadata* plugin_get_metadata() { return &kMetadata; }
 
-CPluginHandle plugin_create_instance(const char* params, CLogCallback log_cb, void* log_ud) {
+CPluginHandle create_instance_impl(const char* params, CLogCallback log_cb, void* log_ud) {
     auto p = std::unique_ptr<WhisperPlugin>(new WhisperPlugin()); p->log_cb = log_cb; p->log_ud = log_ud;
     std::string err;
     if (!parse_config(params, &p->config, &err)) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
@@ -331,68 +374,100 @@ CPluginHandle plugin_create_instance(const char* params, CLogCallback log_cb, vo
     p->vad = make_vad(p->config, p.get(), &err);
     if (!p->vad) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     p->seg.configure(p->config.vad_threshold, p->config.min_silence_duration_ms, p->config.max_segment_duration_secs);
+    if (p->config.input_sample_rate != 16000) {
+        p->front.reset(new skw::ResamplerCore());
+        p->front->target = 16000; p->front->chunk_frames = 960; p->front->out_frame = 0; p->front->gpu_device = p->config.gpu_device; p->front->polyphase = p->config.input_resample_mode == "polyphase";
+    }
     return (CPluginHandle)p.release();
+}
+CPluginHandle plugin_create_instance(const char* params, CLogCallback log_cb, void* log_ud) {
+    auto fail = [&](const std::string& m) -> CPluginHandle { if (log_cb) log_cb(SK_LOG_ERROR, "whisper_plugin_native", m.c_str(), log_ud); return nullptr; };
+    try { return create_instance_impl(params, log_cb, log_ud); }          // NULL = "Plugin failed to create instance" at the host (wrapper.rs:184-188)
+    catch (const std::exception& e) { return fail(std::string("Failed to create Whisper plugin instance: ") + e.what()); }
+    catch (...) { return fail("Failed to create Whisper plugin instance: unknown C++ exception"); }
+}
+
+// 16 kHz mono samples into the VAD segmenter (lib.rs:411-493)
+bool feed_segmenter(WhisperPlugin* self, const Emit& em, const float* samples, size_t n, std::string* err) {
+    bool failed = false;
+    self->seg.push(samples, n, *self->vad,
+                   [&](const skw::SpeechStart& s) { emit_speech_start(self, em, s); },
+                   [&](const skw::SegmentCut& cut) { if (!transcribe_and_emit(self, em, cut, err)) { failed = true; return false; } return true; }, err);
+    return !failed && err->empty();
 }
 
 CResult plugin_process_packet(CPluginHandle handle, const char* input_pin, const CPacket* packet, COutputCallback out_cb, void* out_ud,
                               CTelemetryCallback tel_cb, void* tel_ud) {
     if (!handle || !input_pin || !packet) return err_null();
-    WhisperPlugin* self = (WhisperPlugin*)handle;
-    if (!packet->data) return err_result("Invalid packet: Null packet data pointer");
-    if (packet->packet_type != SK_PACKET_RAW_AUDIO) {
-        if (packet->packet_type == SK_PACKET_TEXT || packet->packet_type == SK_PACKET_TRANSCRIPTION || packet->packet_type == SK_PACKET_CUSTOM || packet->packet_type == SK_PACKET_BINARY)
-            return err_result("Whisper plugin only accepts audio packets");
-        return err_result("Invalid packet: Unsupported packet type");
-    }
-    const CAudioFrame* fr = (const CAudioFrame*)packet->data;
-    if (!fr->samples) return err_result("Invalid packet: Null samples pointer in audio frame");
-    // validate_audio_format (lib.rs:183-197)
-    if (fr->sample_rate != 16000) return err_result("Whisper requires 16kHz audio, got " + std::to_string(fr->sample_rate) + "Hz. Please add an audio_resample node upstream.");
-    if (fr->channels != 1) return err_result("Whisper requires mono audio, got " + std::to_string(fr->channels) + " channels. Please add an audio_resample node upstream.");
-    Emit em{out_cb, out_ud, tel_cb, tel_ud};
-    std::string err; bool failed = false;
-    self->seg.push(fr->samples, fr->sample_count, *self->vad,
-                   [&](const skw::SpeechStart& s) { emit_speech_start(self, em, s); },
-                   [&](const skw::SegmentCut& cut) { if (!transcribe_and_emit(self, em, cut, &err)) { failed = true; return false; } return true; }, &err);
-    if (failed || !err.empty()) return err_result(err);
-    return ok_result();
+    return guarded("Whisper plugin", [&]() -> CResult {
+        WhisperPlugin* self = (WhisperPlugin*)handle;
+        if (!packet->data) return err_result("Invalid packet: Null packet data pointer");
+        if (packet->packet_type != SK_PACKET_RAW_AUDIO) {
+            if (packet->packet_type == SK_PACKET_TEXT || packet->packet_type == SK_PACKET_TRANSCRIPTION || packet->packet_type == SK_PACKET_CUSTOM || packet->packet_type == SK_PACKET_BINARY)
+                return err_result("Whisper plugin only accepts audio packets");
+            return err_result("Invalid packet: Unsupported packet type");
+        }
+        const CAudioFrame* fr = (const CAudioFrame*)packet->data;
+        if (!fr->samples) return err_result("Invalid packet: Null samples pointer in audio frame");
+        // validate_audio_format (lib.rs:183-197); with the additive input_sample_rate the expected rate is the configured one
+        const uint32_t want = self->config.input_sample_rate;
+        if (fr->sample_rate != want) {
+            if (want == 16000) return err_result("Whisper requires 16kHz audio, got " + std::to_string(fr->sample_rate) + "Hz. Please add an audio_resample node upstream.");
+            return err_result("Whisper plugin is configured for " + std::to_string(want) + "Hz input (input_sample_rate), got " + std::to_string(fr->sample_rate) + "Hz.");
+        }
+        if (fr->channels != 1) return err_result("Whisper requires mono audio, got " + std::to_string(fr->channels) + " channels. Please add an audio_resample node upstream.");
+        Emit em{out_cb, out_ud, tel_cb, tel_ud};
+        std::string err;
+        if (self->front) {
+            if (!self->front->push(fr->samples, fr->sample_count, fr->sample_rate, fr->channels,
+                                   [&](const float* d, size_t n, std::string* e) { return feed_segmenter(self, em, d, n, e); }, &err)) return err_result(err);
+        } else if (!feed_segmenter(self, em, fr->samples, fr->sample_count, &err)) return err_result(err);
+        return ok_result();
+    });
 }
 
 CResult plugin_update_params(CPluginHandle handle, const char* params) {
     if (!handle) return err_result("Invalid handle (null)");
-    WhisperPlugin* self = (WhisperPlugin*)handle;
-    if (!params || !*params) return ok_result();
-    WhisperConfig nc;   // serde deserialises a fresh config from the new JSON (defaults for missing keys), lib.rs:498-499
-    std::string err;
-    if (!parse_config(params, &nc, &err)) return err_result(err);
-    if (nc.gpu_device_auto) nc.gpu_device = self->config.gpu_device;        // an "auto" instance stays on the device it was dealt
-    if (nc.model_path != self->config.model_path || nc.precision != self->config.precision || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
-        auto eng = get_engine(nc, &err);
-        if (!eng) return err_result("Failed to reload Whisper model: " + err);
-        self->engine = eng;
-    }
-    if (nc.vad_model_path != self->config.vad_model_path || nc.vad_threshold != self->config.vad_threshold || nc.vad_mode != self->config.vad_mode) {
-        auto v = make_vad(nc, self, &err);
-        if (!v) { const std::string pre = "Failed to initialize VAD: "; return err_result("Failed to reload VAD: " + (err.compare(0, pre.size(), pre) == 0 ? err.substr(pre.size()) : err)); }
-        self->vad = std::move(v);
-    }
-    if (nc.min_silence_duration_ms != self->config.min_silence_duration_ms) self->seg.set_min_silence_ms(nc.min_silence_duration_ms);
-    self->seg.set_threshold(nc.vad_threshold); self->seg.set_max_duration_secs(nc.max_segment_duration_secs);
-    self->config = nc;
-    return ok_result();
+    return guarded("Whisper plugin", [&]() -> CResult {
+        WhisperPlugin* self = (WhisperPlugin*)handle;
+        if (!params || !*params) return ok_result();
+        WhisperConfig nc;   // serde deserialises a fresh config from the new JSON (defaults for missing keys), lib.rs:498-499
+        std::string err;
+        if (!parse_config(params, &nc, &err)) return err_result(err);
+        if (nc.gpu_device_auto) nc.gpu_device = self->config.gpu_device;        // an "auto" instance stays on the device it was dealt
+        if (nc.model_path != self->config.model_path || nc.precision != self->config.precision || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
+            auto eng = get_engine(nc, &err);
+            if (!eng) return err_result("Failed to reload Whisper model: " + err);
+            self->engine = eng;
+        }
+        if (nc.vad_model_path != self->config.vad_model_path || nc.vad_threshold != self->config.vad_threshold || nc.vad_mode != self->config.vad_mode) {
+            auto v = make_vad(nc, self, &err);
+            if (!v) { const std::string pre = "Failed to initialize VAD: "; return err_result("Failed to reload VAD: " + (err.compare(0, pre.size(), pre) == 0 ? err.substr(pre.size()) : err)); }
+            self->vad = std::move(v);
+        }
+        if (nc.min_silence_duration_ms != self->config.min_silence_duration_ms) self->seg.set_min_silence_ms(nc.min_silence_duration_ms);
+        self->seg.set_threshold(nc.vad_threshold); self->seg.set_max_duration_secs(nc.max_segment_duration_secs);
+        nc.input_sample_rate = self->config.input_sample_rate; nc.input_resample_mode = self->config.input_resample_mode;   // the front end's rate is fixed at creation (a stream does not change rate)
+        self->config = nc;
+        return ok_result();
+    });
 }
 
 CResult plugin_flush(CPluginHandle handle, COutputCallback out_cb, void* out_ud, CTelemetryCallback tel_cb, void* tel_ud) {
     if (!handle) return err_result("Invalid handle (null)");
-    WhisperPlugin* self = (WhisperPlugin*)handle;
-    if (!self->config.flush_tail) return ok_result();   // trait default (sdk lib.rs:324-326): buffered tail is dropped
-    Emit em{out_cb, out_ud, tel_cb, tel_ud}; std::string err;
-    skw::SegmentCut cut;
-    if (self->seg.take_tail(&cut) && !transcribe_and_emit(self, em, cut, &err)) return err_result(err);
-    return ok_result();
+    return guarded("Whisper plugin", [&]() -> CResult {
+        WhisperPlugin* self = (WhisperPlugin*)handle;
+        Emit em{out_cb, out_ud, tel_cb, tel_ud}; std::string err;
+        // the resampler front end's remainder belongs to the stream whether or not the tail is then transcribed (resampler.rs:543-730 runs on input close)
+        if (self->front && !self->front->finish([&](const float* d, size_t n, std::string* e) { return feed_segmenter(self, em, d, n, e); }, &err)) return err_result(err);
+        if (!self->config.flush_tail) return ok_result();   // trait default (sdk lib.rs:324-326): buffered tail is dropped
+        skw::SegmentCut cut;
+        if (self->seg.take_tail(&cut) && !transcribe_and_emit(self, em, cut, &err)) return err_result(err);
+        return ok_result();
+    });
 }
 
-void plugin_destroy_instance(CPluginHandle handle) { if (handle) delete (WhisperPlugin*)handle; }
+void plugin_destroy_instance(CPluginHandle handle) { try { if (handle) delete (WhisperPlugin*)handle; } catch (...) {} }
 
 const CNativePluginAPI kApi = {STREAMKIT_NATIVE_PLUGIN_API_VERSION, plugin_get_metadata, plugin_create_instance, plugin_process_packet,
                                plugin_update_params, plugin_flush, plugin_destroy_instance};

@@ -74,7 +74,14 @@ inline bool parse_tensor(Buf b, Tensor* t, std::string* err) {
         else if (f.num == 10 && f.wt == 2) { const size_t n = (f.sub.e - f.sub.p) / 8; ddata.resize(n); memcpy(ddata.data(), f.sub.p, n * 8); }
         else if (f.num == 14 && f.val == 1) { *err = "tensor '" + t->name + "' uses external data"; return false; }
     }
-    const size_t n = t->numel();
+    // the dims come from the file: nothing is sized by them before they are known to be sane (a malformed or merely unusual .onnx must fail here
+    // with a message, not as std::length_error / bad_alloc somewhere below)
+    size_t n = 1;
+    for (int64_t d : t->dims) {
+        if (d < 0 || d > (int64_t)(64u << 20)) { *err = "tensor '" + t->name + "': implausible dimension"; return false; }
+        n *= (size_t)d;
+        if (n > (size_t)(64u << 20)) { *err = "tensor '" + t->name + "': more than 64M elements"; return false; }
+    }
     if (t->data_type == 1) { if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 4) { *err = "tensor '" + t->name + "': raw_data size"; return false; } t->data.resize(n); memcpy(t->data.data(), raw.p, n * 4); } else t->data = fdata; }
     else if (t->data_type == 10) { t->data.resize(raw.p ? n : hdata.size()); if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 2) { *err = "tensor '" + t->name + "': raw_data size"; return false; } for (size_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, raw.p + 2 * i, 2); t->data[i] = f16_bits_to_f32(h); } } else for (size_t i = 0; i < hdata.size(); ++i) t->data[i] = f16_bits_to_f32(hdata[i]); }
     else if (t->data_type == 11) { if (raw.p) { ddata.resize(n); if ((size_t)(raw.e - raw.p) != n * 8) { *err = "tensor '" + t->name + "': raw_data size"; return false; } memcpy(ddata.data(), raw.p, n * 8); } t->data.assign(ddata.begin(), ddata.end()); }
@@ -130,6 +137,7 @@ struct SileroWeights {
     std::vector<float> cw[4], cb[4];                // conv weights [co][ci][3], biases [co]
     std::vector<float> w_ih, w_hh, b_ih, b_hh;      // LSTMCell, PyTorch gate order i, f, g, o: [512][128], [512]
     std::vector<float> ow; float ob = 0.0f;         // final Conv1d(128 -> 1, k = 1)
+    std::string bound;                              // which tensors of the file were bound to which role (logged by the plugin at INFO)
 };
 static const int SILERO_CI[4] = {129, 128, 64, 64}, SILERO_CO[4] = {128, 64, 64, 128}, SILERO_STRIDE[4] = {1, 2, 2, 1};
 
@@ -147,7 +155,8 @@ inline bool silero_bind(const onnx::Model& m, SileroWeights* w, std::string* err
     };
     auto take = [&](std::initializer_list<int64_t> dims, const char* hint, size_t after, std::vector<float>* dst, const char* what, size_t* pos) -> bool {
         const int i = find(dims, hint, after); if (i < 0) { *err = std::string("Silero VAD model: missing tensor ") + what; return false; }
-        used[i] = 1; *dst = ts[i]->data; if (pos) *pos = (size_t)i; return true;
+        used[i] = 1; *dst = ts[i]->data; if (pos) *pos = (size_t)i;
+        w->bound += (w->bound.empty() ? "" : ", ") + std::string(what) + " <- '" + ts[i]->name + "'"; return true;
     };
     if (!take({258, 1, 256}, nullptr, 0, &w->basis, "STFT basis [258,1,256]", nullptr)) return false;
     for (int l = 0; l < 4; ++l) {
@@ -160,6 +169,7 @@ inline bool silero_bind(const onnx::Model& m, SileroWeights* w, std::string* err
     }
     if (find({512, 128}, nullptr, 0) >= 0) {         // LSTMCell as exported by tracing: weight_ih, weight_hh [4H, H], bias_ih, bias_hh [4H]
         size_t p0 = 0, p1 = 0;
+        // name hints first (PyTorch's weight_ih / weight_hh survive tracing), file order second
         if (!take({512, 128}, "ih", 0, &w->w_ih, "LSTM weight_ih [512,128]", &p0) || !take({512, 128}, "hh", p0, &w->w_hh, "LSTM weight_hh [512,128]", &p1)) return false;
         if (!take({512}, "ih", p0, &w->b_ih, "LSTM bias_ih [512]", nullptr) || !take({512}, "hh", p1, &w->b_hh, "LSTM bias_hh [512]", nullptr)) return false;
     } else {                                          // ONNX LSTM operator: W, R [1, 4H, H] and B [1, 8H], gate order i, o, f, c

@@ -42,7 +42,15 @@ class Result(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("mel_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32)]
+                ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32), ("n_row_steps", C.c_int32)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("n", C.c_int32), ("steps", C.c_void_p)]
+
+
+TRACE_DT = np.dtype([("chosen_id", "<i4"), ("forced_id", "<i4"), ("top1_id", "<i4"), ("top2_id", "<i4"),
+                     ("top1", "<f4"), ("top2", "<f4"), ("forced_logit", "<f4"), ("lse", "<f4")])      # skw_trace_step
 
 
 class ResamplerState(C.Structure):
@@ -80,6 +88,9 @@ def lib():
         L.skw_full_default_params.argtypes = [C.POINTER(FullParams)]
         L.skw_full_batch.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(Result)]
         L.skw_result_free.argtypes = [C.POINTER(Result)]
+        L.skw_full_batch_traced.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(Trace), C.POINTER(Result)]
+        L.skw_trace_free.argtypes = [C.POINTER(Trace)]
         L.skw_log_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.skw_conv_stem.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.skw_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -165,7 +176,8 @@ class Context:
     PRECISIONS = {"exact": 0, "f16_mfma": 1}
 
     def set_precision(self, name):
-        """'exact' (f32-chain contractions, bit-identical to the oracle) or 'f16_mfma' (f16 matrix cores, token-identical)."""
+        """'exact' (f32-chain contractions, bit-identical to the oracle) or 'f16_mfma' (f16 matrix cores: every greedy decision equals the exact
+        mode's given the same history unless that step was a near-tie; a free-running transcript is identical up to its first near-tie)."""
         self._check(lib().skw_ctx_set_precision(self.h, self.PRECISIONS[name]))
 
     def get_precision(self):
@@ -177,8 +189,10 @@ class Context:
         lib().skw_full_default_params(C.byref(p))
         return p
 
-    def full_batch(self, clips, params=None, device_ptrs=None, n_samples=None):
-        """clips: list of 1-D float32 numpy arrays (host), or device_ptrs + n_samples for HBM-resident PCM."""
+    def full_batch(self, clips, params=None, device_ptrs=None, n_samples=None, trace=False, forced=None):
+        """clips: list of 1-D float32 numpy arrays (host), or device_ptrs + n_samples for HBM-resident PCM.
+        trace=True (or forced=[per-clip int32 id sequences]): skw_full_batch_traced — returns (results, traces), traces[i] a structured
+        array (TRACE_DT) with one record per sampling decision of clip i; with `forced` the decoder is fed those ids (teacher forcing)."""
         p = params or self.default_params()
         if device_ptrs is not None:
             n = len(device_ptrs)
@@ -192,10 +206,26 @@ class Context:
             ns = (C.c_int32 * n)(*[c.size for c in clips])
             on_dev = 0
         res = (Result * n)()
-        self._check(lib().skw_full_batch(self.h, C.byref(p), ptrs, ns, n, on_dev, res))
+        if trace or forced is not None:
+            tr = (Trace * n)()
+            fptr = fn = None
+            if forced is not None:
+                keep = [np.ascontiguousarray(f, dtype=np.int32) for f in forced]
+                fptr = (C.c_void_p * n)(*[k.ctypes.data for k in keep])
+                fn = (C.c_int32 * n)(*[k.size for k in keep])
+            self._check(lib().skw_full_batch_traced(self.h, C.byref(p), ptrs, ns, n, on_dev, fptr, fn, tr, res))
+            traces = []
+            for i in range(n):
+                a = np.frombuffer((C.c_char * (tr[i].n * TRACE_DT.itemsize)).from_address(tr[i].steps), dtype=TRACE_DT).copy() if tr[i].n else np.zeros(0, TRACE_DT)
+                traces.append(a)
+                lib().skw_trace_free(C.byref(tr[i]))
+        else:
+            self._check(lib().skw_full_batch(self.h, C.byref(p), ptrs, ns, n, on_dev, res))
         out = [_result_to_dict(res[i]) for i in range(n)]
         for i in range(n):
             lib().skw_result_free(C.byref(res[i]))
+        if trace or forced is not None:
+            return out, traces
         return out
 
     def timing(self):

@@ -1,0 +1,53 @@
+"""Step-by-step comparison of the two precisions of the engine under teacher forcing (include/skw_engine.h, skw_full_batch_traced).
+
+The exact precision is the one a CPU restates bit for bit (tests/test_gpu_parity.py holds it to oracle/).  The f16_mfma precision sums its
+contractions in the matrix cores' order, so a free-running transcript can leave the exact one's at a near-tie of the greedy argmax and is then
+compared with nothing.  Here the f16_mfma decoder is FED the exact run's tokens, so every one of its decisions is made on the history the exact run
+had, and each is checked: same argmax, or the exact run's own top1 - top2 margin at that step is below MARGIN_BOUND; and the logits that decide
+(the fed token's, the winner's) agree within LOGIT_ERR_BOUND.  Used by tests/test_gpu_f16.py on every clip of BASELINE.json configs[1] and by
+bench.py, which prints the counts beside the headline number.  No oracle and no CPU path is involved: both runs are the HIP engine.
+"""
+import numpy as np
+
+# Logit units.  The synthetic models' logits span about +-500; the f16_mfma logits measured against the exact ones under teacher forcing on the
+# 64 x 30 s Whisper-small batch differ by at most ~0.1 (printed by the test); a flip needs margin <= err(top1) + err(top2).
+LOGIT_ERR_BOUND = 0.25
+MARGIN_BOUND = 2 * LOGIT_ERR_BOUND
+
+
+def teacher_forced_compare(ctx, clips=None, params=None, device_ptrs=None, n_samples=None):
+    """Runs the batch in the exact precision (free, traced), then in f16_mfma fed with the exact run's decisions.  Returns a dict of counts and
+    the two result lists; leaves the context in the precision it was in."""
+    was = ctx.get_precision()
+    kw = dict(device_ptrs=device_ptrs, n_samples=n_samples)
+    ctx.set_precision("exact")
+    res_e, tr_e = ctx.full_batch(clips, params, trace=True, **kw)
+    ctx.set_precision("f16_mfma")
+    res_f, tr_f = ctx.full_batch(clips, params, forced=[t["chosen_id"] for t in tr_e], **kw)
+    ctx.set_precision(was)
+    steps = disagree = 0
+    worst_margin = 0.0          # largest exact-mode margin at a step where the f16_mfma argmax differs
+    worst_err = 0.0             # largest |logit difference| seen (fed token; winner when both modes agree on it)
+    runner_up = 0               # disagreements where f16_mfma chose the exact mode's runner-up
+    per_clip = []
+    for c, (a, b) in enumerate(zip(tr_e, tr_f)):
+        if len(a) != len(b) or not np.array_equal(a["chosen_id"], b["forced_id"]) or not np.array_equal(a["chosen_id"], a["forced_id"]):
+            raise AssertionError("clip %d: the forced run did not follow the exact run's decisions (%d vs %d steps)" % (c, len(a), len(b)))
+        steps += len(a)
+        err = np.abs(a["forced_logit"].astype(np.float64) - b["forced_logit"])
+        same_top = a["top1_id"] == b["top1_id"]
+        err_top = np.abs(a["top1"].astype(np.float64) - b["top1"])[same_top]
+        e = float(max(err.max() if len(err) else 0.0, err_top.max() if len(err_top) else 0.0))
+        worst_err = max(worst_err, e)
+        diff = np.nonzero(a["chosen_id"] != b["chosen_id"])[0]
+        m = (a["top1"][diff] - a["top2"][diff]).astype(np.float64)
+        disagree += len(diff)
+        runner_up += int(np.sum(b["chosen_id"][diff] == a["top2_id"][diff]))
+        if len(diff):
+            worst_margin = max(worst_margin, float(m.max()))
+        per_clip.append(dict(steps=len(a), disagreements=len(diff), max_logit_err=e, margins=[round(float(x), 5) for x in m]))
+    return dict(steps_checked=steps, argmax_disagreements=disagree, disagreements_on_exact_runner_up=runner_up,
+                max_margin_at_disagreement=worst_margin if disagree else None, max_logit_err=worst_err,
+                logit_err_bound=LOGIT_ERR_BOUND, margin_bound=MARGIN_BOUND,
+                ok=bool(worst_err <= LOGIT_ERR_BOUND and (not disagree or worst_margin < MARGIN_BOUND)),
+                per_clip=per_clip, results_exact=res_e, results_forced=res_f, traces_exact=tr_e, traces_forced=tr_f)

@@ -58,7 +58,9 @@ def test_plugin_metadata_matches_reference_node(built):
     p = minihost.Plugin()
     md = p.metadata
     assert md["kind"] == "whisper" and md["registered_as"] == "plugin::native::whisper"
-    assert md["inputs"] == [{"name": "in", "accepts": [{"type": 0, "sample_rate": 16000, "channels": 1, "sample_format": 0}]}]
+    # the reference's accepted type first; (additive, for input_sample_rate) mono f32 at any rate second — 0 is the host's wildcard (packet_meta.rs:97-109)
+    assert md["inputs"] == [{"name": "in", "accepts": [{"type": 0, "sample_rate": 16000, "channels": 1, "sample_format": 0},
+                                                       {"type": 0, "sample_rate": 0, "channels": 1, "sample_format": 0}]}]
     assert md["outputs"] == [{"name": "out", "type": 3}]
     assert md["categories"] == ["ml", "speech", "transcription"]
     props = md["param_schema"]["properties"]
@@ -68,6 +70,7 @@ def test_plugin_metadata_matches_reference_node(built):
     for k, v in ref_defaults.items():
         assert props[k]["default"] == v, k
     assert props["precision"]["default"] == "exact" and props["vad_mode"]["default"] == "auto"      # additive params keep reference behaviour by default
+    assert props["input_sample_rate"]["default"] == 16000 and props["input_resample_mode"]["default"] == "linear"
     assert props["gpu_device"]["maximum"] == 7 and props["min_silence_duration_ms"]["minimum"] == 100
 
 
@@ -108,3 +111,24 @@ def test_plugin_rejects_bad_config_before_touching_the_gpu(built):
         p.create_node({"precision": "fp8"})
     with pytest.raises(RuntimeError, match="Invalid config: gpu_device"):
         p.create_node({"gpu_device": "first"})
+    with pytest.raises(RuntimeError, match="Invalid config: input_sample_rate"):
+        p.create_node({"input_sample_rate": 12.5})
+    with pytest.raises(RuntimeError, match="Invalid config: input_resample_mode"):
+        p.create_node({"input_resample_mode": "cubic"})
+
+
+def test_no_cpp_exception_crosses_the_abi(built):
+    """SURVEY.md section 8b "Errors": panics / C++ exceptions must not cross.  A packet whose sample_count cannot be buffered makes the node's
+    std::vector throw std::length_error inside process_packet; the entry point must hand the host a CResult error, not unwind into it.
+    (The resampler's pass-through branch needs no GPU; the Whisper node's same guard is exercised on the GPU box, tests/test_gpu_plugin.py.)"""
+    import numpy as np
+    p = minihost.Plugin(os.path.join(ROOT, "streamkit_amd", "libresampler.so"))
+    n = p.create_node({"target_sample_rate": 16000, "output_frame_size": 960})
+    small = np.zeros(16, np.float32)
+    rc = minihost.lib().mh_process_audio(n.h, small.ctypes.data, (1 << 61), 16000, 1)      # pass-through branch: output_buffer.insert(huge range) throws before it reads
+    assert rc != 0 and "resampler plugin:" in n.last_error()
+    assert n.process_audio(np.zeros(960, np.float32), 16000, 1) == -2                       # the host's rule: a node whose process failed is Failed (wrapper.rs:468-483)
+    n.destroy()                                                                              # ... and is destroyed cleanly
+    n2 = p.create_node({"target_sample_rate": 16000, "output_frame_size": 960})              # the library is intact: the next instance works
+    assert n2.process_audio(np.zeros(960, np.float32), 16000, 1) == 0 and len(n2.outputs()) == 1
+    n2.destroy()

@@ -67,11 +67,16 @@ def test_sharded_oneshot_rccl_all_visible_gpus(tiny_model_path, tmp_path):
     _check_tables(many, one, om, 8 * R, 10.0)
 
 
-def test_dynamic_sessions_eight_paced_streams(tiny_model_path):
+@pytest.mark.parametrize("size", ["tiny", "small"])
+def test_dynamic_sessions_eight_paced_streams(size):
     """configs[3]: 8 live 16 kHz streams fed in 960-sample packets at real time (60 ms), stream i on GPU i mod n_gpus, replicas only.
     Every stream's transcripts equal the oracle's on the segments the (energy) gate cut, and the segment-end -> transcript latency
-    stays under a stated bound."""
+    stays under a stated bound.  "small" is BASELINE.json's stated model for this config (Whisper-small streaming); there the oracle (5 s of
+    CPU per utterance) checks two of the eight streams and the other six are held to the engine's exact precision run directly on the same
+    utterances (itself oracle-checked in tests/test_gpu_parity.py)."""
     import torch
+    from conftest import synth_model
+    tiny_model_path = synth_model(size)      # (name kept: the model every stream runs)
     n_dev = max(1, torch.cuda.device_count())
     plug = minihost.Plugin(); L = minihost.lib()
     L.mh_run_paced.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_long, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -94,6 +99,16 @@ def test_dynamic_sessions_eight_paced_streams(tiny_model_path):
     assert L.mh_run_paced(hs, n, ptrs, ns, 960, 60000, lat, max_lat, nl, C.byref(wall)) == 0, [x.last_error() for x in nodes]
     om = OracleModel(tiny_model_path)
     po = om.default_params(); po.suppress_nst = 1
+    oracle_streams = range(n) if size == "tiny" else (0, 5)
+    direct = {}
+    if size != "tiny":
+        from streamkit_amd import engine
+        m = engine.Model(tiny_model_path); ctx = engine.Context(m, max_batch=16, max_samples=ut)
+        pe = ctx.default_params(); pe.suppress_nst = 1
+        flat = [(i, k) for i in range(n) for k in range(2)]
+        for (i, k), r in zip(flat, ctx.full_batch([utts[i][k] for i, k in flat], pe)):
+            direct[(i, k)] = r
+        ctx.close(); m.close()
     lats = []
     for i, nd in enumerate(nodes):
         outs = nd.outputs()
@@ -103,13 +118,13 @@ def test_dynamic_sessions_eight_paced_streams(tiny_model_path):
             frames = utts[i][k].reshape(-1, 512)                                 # the gate passes every 512-frame of the utterance (rms >> 0.01) and nothing else
             rms = np.sqrt((frames ** 2).sum(axis=1) / 512.0)
             assert ((rms / (rms + 0.01)) >= 0.5).all()
-            ro = om.full(utts[i][k], po)
+            ro = om.full(utts[i][k], po) if i in oracle_streams else direct[(i, k)]
             want = " ".join(s["text"].decode().strip() for s in ro["segments"] if s["text"].decode().strip())
             assert got["text"] == want, (i, k)
             assert got["segments"][0]["start_time_ms"] == k * (ut + gap) // 16 + ro["segments"][0]["t0"] * 10
         lats += [lat[i * max_lat + j] for j in range(nl[i])]
         nd.destroy()
-    print("configs[3]: 8 paced streams on %d GPU(s): segment-end -> transcript latency p50 %.1f ms, max %.1f ms; wall %.2f s for %.1f s of audio per stream"
-          % (n_dev, float(np.percentile(lats, 50)), max(lats), wall.value * 1e-3, pcms[0].size / 16000.0))
+    print("configs[3] Whisper-%s: 8 paced streams on %d GPU(s): segment-end -> transcript latency p50 %.1f ms, max %.1f ms; wall %.2f s for %.1f s of audio per stream"
+          % (size, n_dev, float(np.percentile(lats, 50)), max(lats), wall.value * 1e-3, pcms[0].size / 16000.0))
     assert max(lats) < 500.0                                                     # bound: well inside the reference's "min 700 ms" segmentation latency (README.md:180-186)
     assert wall.value * 1e-3 < pcms[0].size / 16000.0 + 1.0                      # paced: the run takes the audio's duration, the GPU keeps up

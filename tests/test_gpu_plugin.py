@@ -228,7 +228,16 @@ def test_precision_param_f16_mfma(plugin, tiny_model_path):
         o = node.outputs(); assert len(o) == 1
         outs[prec] = json.loads(o[0][2].decode()); node.destroy()
     a, b = outs["exact"], outs["f16_mfma"]
-    assert [s["start_time_ms"] for s in a["segments"]][:1] == [s["start_time_ms"] for s in b["segments"]][:1] and b["text"]
+    # the whole transcript: identical, or — the only excuse — the engine-level run of the same clip shows a near-tie of the exact argmax at the first differing token
+    if a != b:
+        from streamkit_amd import engine
+        from test_gpu_f16 import same_or_near_tie
+        m = engine.Model(tiny_model_path); ctx = engine.Context(m, max_batch=1, max_samples=16000 * 13)
+        pp = ctx.default_params(); pp.suppress_nst = 1                                  # the node's default (lib.rs:634)
+        re_ = ctx.full_batch([pcm], pp)[0]; ctx.set_precision("f16_mfma"); rf = ctx.full_batch([pcm], pp)[0]
+        assert not same_or_near_tie(rf, re_, "plugin precision param, clip 4")      # asserts the margin bound itself
+        ctx.close(); m.close()
+    assert b["text"] and b["segments"] and [s["start_time_ms"] for s in a["segments"]][:1] == [s["start_time_ms"] for s in b["segments"]][:1]
     with pytest.raises(RuntimeError):
         plugin.create_node({"model_path": tiny_model_path, "precision": "bf8"})
 
@@ -248,3 +257,70 @@ def test_gpu_device_auto_deals_instances_over_gpus(plugin, tiny_model_path):
         nd.destroy()
     with pytest.raises(RuntimeError):
         plugin.create_node({"model_path": tiny_model_path, "gpu_device": "first"})
+
+
+def test_input_sample_rate_48k_equals_resampler_node_then_whisper(plugin, tiny_model_path):
+    """(additive) input_sample_rate: 48 kHz packets straight into libwhisper.so give the Transcription the two-node chain gives —
+    libresampler.so (the audio::resampler node's arithmetic, R1-R3) -> libwhisper.so — and what the oracle's resampler + full() give.
+    (Opus decode always yields 48 kHz, crates/nodes/src/audio/codecs/opus.rs:70,103; SURVEY.md section 8b "Resampler boundary".)"""
+    import os
+    rs = minihost.Plugin(os.path.join(minihost.ROOT, "streamkit_amd", "libresampler.so"))
+    om = OracleModel(tiny_model_path)
+    n48 = 48000 * 9 + 1234                                                   # ragged: a remainder chunk at the end (R3)
+    t = np.arange(n48) / 48000.0
+    x48 = (0.3 * np.sin(2 * np.pi * 310.0 * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t)) + 0.2 * np.sin(2 * np.pi * 1270.0 * t)).astype(np.float32)
+    # (a) the chain of two plugins, 20 ms packets as the Opus decoder emits them
+    r = rs.create_node({"target_sample_rate": 16000, "chunk_frames": 960, "output_frame_size": 960})
+    w = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True})
+    for i in range(0, n48, 960):
+        assert r.process_audio(x48[i:i + 960], 48000, 1) == 0, r.last_error()
+    assert r.flush() == 0
+    chain16 = np.concatenate([np.frombuffer(o[2], dtype=np.float32) for o in r.outputs()])
+    for o in r.outputs():
+        assert w.process_audio(np.frombuffer(o[2], dtype=np.float32)) == 0, w.last_error()
+    assert w.flush() == 0
+    chain = [json.loads(o[2].decode()) for o in w.outputs()]
+    # (b) the one node
+    f = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True, "input_sample_rate": 48000})
+    for i in range(0, n48, 960):
+        assert f.process_audio(x48[i:i + 960], 48000, 1) == 0, f.last_error()
+    assert f.flush() == 0
+    fused = [json.loads(o[2].decode()) for o in f.outputs()]
+    assert fused == chain and len(fused) == 1
+    # (c) the oracle: rubato restatement, then full() on the whole 512-frames the segmenter hands over plus the flushed tail
+    orc = oracle_lib.OracleResampler(16000 / 48000, 960, 1)
+    parts = [orc.process(x48[i:i + 960])[0] for i in range(0, n48 - n48 % 960, 960)]
+    rem = n48 % 960
+    parts.append(oracle_lib.OracleResampler(16000 / 48000, rem, 1).process(x48[n48 - rem:])[0])      # the remainder through a fresh resampler (resampler.rs:564-570)
+    want16 = np.concatenate(parts)
+    assert np.array_equal(want16.view(np.uint32), chain16.view(np.uint32))
+    assert fused[0] == _expected_transcription(om, chain16, 0)
+    # a packet at the wrong rate names the configured one; 16 kHz instances keep the reference's message
+    assert f.process_audio(x48[:960], 16000, 1) != 0 and "configured for 48000Hz input" in f.last_error()
+    assert w.process_audio(x48[:960], 48000, 1) != 0 and "Whisper requires 16kHz audio, got 48000Hz" in w.last_error()
+    for nd in (r, w, f):
+        nd.destroy()
+
+
+def test_whisper_plugin_contains_cpp_exceptions(plugin, tiny_model_path):
+    """A packet whose sample_count cannot be buffered throws std::length_error inside the segmenter's buffer; process_packet returns it as a
+    CResult error (nothing unwinds into the host) and the next instance is unaffected."""
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always"})
+    small = np.zeros(16, np.float32)
+    rc = minihost.lib().mh_process_audio(node.h, small.ctypes.data, (1 << 61), 16000, 1)
+    assert rc != 0 and node.last_error().startswith("Whisper plugin: "), node.last_error()
+    node.destroy()
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True})
+    _feed(node, synth.clip(2, 16000 * 4)); assert node.flush() == 0 and len(node.outputs()) == 1
+    node.destroy()
+
+
+def test_engine_workspace_follows_max_segment_duration(plugin, tiny_model_path):
+    """The shared engine's workspace is sized from max_segment_duration_secs (31 s of samples by default, not the schema's 121 s) and grows when an
+    instance that allows longer segments hands one over."""
+    pcm = synth.clip(21, 16000 * 40)
+    node = plugin.create_node({"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True, "max_segment_duration_secs": 45.0, "precision": "f16_mfma", "max_batch": 3})
+    _feed(node, pcm); assert node.flush() == 0, node.last_error()
+    outs = [json.loads(o[2].decode()) for o in node.outputs()]
+    assert len(outs) == 1 and outs[0]["segments"][-1]["end_time_ms"] > 30000       # one 40 s segment, two Whisper windows
+    node.destroy()
