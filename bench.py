@@ -217,7 +217,7 @@ def main():
     if not args.no_other_mode:
         from streamkit_amd.parity import teacher_forced_compare
         tf = teacher_forced_compare(ctx, None, params, device_ptrs=ptrs, n_samples=ns)
-        parity = {k: tf[k] for k in ("steps_checked", "argmax_disagreements", "disagreements_on_exact_runner_up", "max_margin_at_disagreement", "max_logit_err", "logit_err_bound", "margin_bound", "ok")}
+        parity = {k: tf[k] for k in ("steps_checked", "sampled_steps", "sampled_draws_that_differ", "argmax_disagreements", "disagreements_on_exact_runner_up", "max_margin_at_disagreement", "max_logit_err", "logit_err_bound", "margin_bound", "ok")}
         parity["clips_checked"] = len(tf["per_clip"])
         parity["what"] = ("f16_mfma fed the exact precision's tokens: each of its greedy decisions, on every clip and step of this batch, equals the exact one "
                           "or sits where the exact top1 - top2 logit margin is below margin_bound; deciding logits agree within logit_err_bound")

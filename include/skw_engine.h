@@ -131,7 +131,9 @@ void skw_result_free(skw_result*);
  * compared step by step: chosen_id is what THIS precision's argmax picked, top1 / top2 the two largest admissible logits, forced_logit
  * the logit of the fed token.  A forced sequence that runs out before the decoder stops is an error (the runs' control flow diverged).
  * The decode steps are launched eagerly in this mode (same kernels as the captured step graph, plus the trace form of the sampler). */
-typedef struct { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; } skw_trace_step;
+typedef struct { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse;
+                 float temperature;   /* of the pass this decision belongs to; > 0: chosen_id is a std::discrete_distribution draw (not an argmax) and the logits here are the row's divided by it */
+                 int32_t pad; } skw_trace_step;
 typedef struct { int32_t n; skw_trace_step* steps; } skw_trace;
 int  skw_full_batch_traced(skw_ctx*, const skw_full_params*, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device,
                            const int32_t* const* forced_ids /* [n_clips] or NULL */, const int32_t* n_forced /* [n_clips] or NULL */,

@@ -128,7 +128,7 @@ struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum, margin; };
 // one sampling decision as the trace / teacher-forced mode records it (skw_full_batch_traced): what this precision would have chosen, what it was made to
 // feed instead (forced_id == chosen_id in a free run), the two largest admissible logits with their owners, the (filtered) logit of the fed token and the
 // log-sum-exp of the admissible logits.  Layout == skw_trace_step of include/skw_engine.h.
-struct SkwTraceStep { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; };
+struct SkwTraceStep { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; float temperature; int32_t pad; };      // temperature > 0: chosen_id is a draw, and the logits are the row's divided by it
 struct SkwLogitParams {
     int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
     int n_lang; int tok_space, tok_sp_dash, tok_sp_quote;

@@ -1350,11 +1350,11 @@ __device__ int discrete_draw(const float* probs, int n, uint32_t* mt) {
 // the state below then evolves exactly as in the run the forced tokens came from.  lg: the row's logits in memory (filtered in place by the streaming
 // kernel and by sampled passes; raw otherwise — the same number for an admissible token).
 __device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg, float lse, int i, int max_tok, long row, const int* forced, SkwTraceStep* trace,
-                                               int i1, int i2, float t1, float t2, const SkwLogitParams& p) {
+                                               int i1, int i2, float t1, float t2, const SkwLogitParams& p, float temperature) {
     if (!trace || i >= max_tok) return;
     int fid = forced ? forced[row * max_tok + i] : -1;
     if (fid < 0 || fid >= p.n_vocab) fid = tk.id;
-    SkwTraceStep ts; ts.chosen_id = tk.id; ts.forced_id = fid; ts.top1_id = i1; ts.top2_id = (t2 > -INFINITY) ? i2 : -1; ts.top1 = t1; ts.top2 = t2; ts.forced_logit = lg[fid]; ts.lse = lse;
+    SkwTraceStep ts; ts.chosen_id = tk.id; ts.forced_id = fid; ts.top1_id = i1; ts.top2_id = (t2 > -INFINITY) ? i2 : -1; ts.top1 = t1; ts.top2 = t2; ts.forced_logit = lg[fid]; ts.lse = lse; ts.temperature = temperature; ts.pad = 0;
     trace[row * max_tok + i] = ts;
     if (fid != tk.id) { tk.id = fid; tk.plog = lg[fid] - lse; tk.p = skw_expf(tk.plog); }
 }
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; }
     tk.plog = lg[tk.id] - lse;
     const int i = n_tok;
-    smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, best.i, -1, t1, t2, p);
+    smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, best.i, -1, t1, t2, p, temperature);
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
     tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = r.best_logit - lse;
     if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
     const int i = n_tok;
-    if (TRACE) smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, i1, i2, t1, t2, p);
+    if (TRACE) smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, i1, i2, t1, t2, p, temperature);
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
     if (tk.id >= p.tok_beg) { tk.tid = tk.id; tk.pt = tk.p; }
     tk.margin = (!sampled && t2 > -INFINITY) ? t1 - t2 : INFINITY;

@@ -10,6 +10,7 @@
 // Plain C API so pytest can drive it through ctypes.
 #include "../../include/streamkit_native_abi.h"
 #include "skw_segmenter.h"
+#include "skw_kokoro_text.h"
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
@@ -31,7 +32,7 @@ std::string jq(const std::string& s) {
 }  // namespace
 
 struct mh_plugin { void* lib = nullptr; const CNativePluginAPI* api = nullptr; std::string kind, meta_json; };
-struct mh_output { std::string pin; int packet_type; std::string payload; };
+struct mh_output { std::string pin; int packet_type; std::string payload; uint32_t sample_rate = 0; uint16_t channels = 0; };
 struct mh_telemetry { std::string event_type, json; };
 struct mh_node {
     mh_plugin* plugin = nullptr; CPluginHandle handle = nullptr; std::vector<mh_output> outputs; std::vector<mh_telemetry> telemetry; std::vector<std::string> logs;
@@ -89,7 +90,7 @@ static CResult out_shim(const char* pin, const CPacket* pk, void* ud) {
     mh_output o; o.pin = pin; o.packet_type = (int)pk->packet_type;
     if (pk->packet_type == SK_PACKET_TRANSCRIPTION || pk->packet_type == SK_PACKET_BINARY) o.payload.assign((const char*)pk->data, pk->len);
     else if (pk->packet_type == SK_PACKET_TEXT) o.payload = (const char*)pk->data;
-    else if (pk->packet_type == SK_PACKET_RAW_AUDIO) { const CAudioFrame* f = (const CAudioFrame*)pk->data; o.payload.assign((const char*)f->samples, f->sample_count * sizeof(float)); }
+    else if (pk->packet_type == SK_PACKET_RAW_AUDIO) { const CAudioFrame* f = (const CAudioFrame*)pk->data; o.payload.assign((const char*)f->samples, f->sample_count * sizeof(float)); o.sample_rate = f->sample_rate; o.channels = f->channels; }
     else { n->cb_error = "Failed to convert packet: Unsupported packet type"; r.success = false; return r; }
     n->outputs.push_back(std::move(o)); r.success = true; return r;
 }
@@ -126,6 +127,19 @@ int mh_process_text(mh_node* n, const char* text) {
     CPacket pk; pk.packet_type = SK_PACKET_TEXT; pk.data = text; pk.len = strlen(text) + 1;
     CResult res = n->plugin->api->process_packet(n->handle, "in", &pk, out_shim, n, tel_shim, n);
     if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; return -1; } return 0;
+}
+int mh_process_binary(mh_node* n, const void* data, size_t len) {
+    CPacket pk; pk.packet_type = SK_PACKET_BINARY; pk.data = data; pk.len = len;
+    CResult res = n->plugin->api->process_packet(n->handle, "in", &pk, out_shim, n, tel_shim, n);
+    if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; return -1; } return 0;
+}
+int mh_output_audio_format(mh_node* n, size_t i, uint32_t* rate, uint16_t* channels) { if (i >= n->outputs.size()) return -1; *rate = n->outputs[i].sample_rate; *channels = n->outputs[i].channels; return 0; }
+// The Transcription -> Text step of the voice-agent pipelines (samples/pipelines/dynamic/voice-agent-openai.yaml:86-95, a core::script node): output i of
+// `src` (a Transcription packet) becomes a Text packet into `dst`; an empty / missing text produces nothing (returns 1).  skw_kokoro_text.h.
+int mh_forward_transcription_as_text(mh_node* src, size_t i, mh_node* dst) {
+    if (i >= src->outputs.size() || src->outputs[i].packet_type != SK_PACKET_TRANSCRIPTION) { dst->last_error = "not a Transcription packet"; return -1; }
+    std::string text; if (!skw::kokoro::transcription_to_text(src->outputs[i].payload, &text)) return 1;
+    return mh_process_text(dst, text.c_str());
 }
 int mh_process_null(mh_node* n) { CResult res = n->plugin->api->process_packet(n->handle, nullptr, nullptr, out_shim, n, tel_shim, n); if (!res.success) { n->last_error = res.error_message ? res.error_message : "(null message)"; return -1; } return 0; }
 int mh_update_params(mh_node* n, const char* json) {
@@ -347,6 +361,15 @@ const char* mh_json_serialize(mh_node* n, int pretty, int newline_delimited, siz
     if (len) *len = r.size();
     return r.data();
 }
+// ---- the Kokoro node's text front end (skw_kokoro_text.h), exposed so that tests/test_cpu_kokoro.py can run the reference's own splitter vectors without a GPU
+const char* mh_kokoro_sanitize(const char* s) { static thread_local std::string r; r = skw::kokoro::sanitize_text(s); return r.c_str(); }
+// one extract_sentence call on *buffer (in/out, NUL-terminated, capacity cap): returns 1 and the sentence, or 0
+int mh_kokoro_extract_sentence(char* buffer, size_t cap, size_t min_length, char* sentence, size_t sentence_cap) {
+    std::string b = buffer, s; const bool got = skw::kokoro::SentenceSplitter(min_length).extract_sentence(&b, &s);
+    snprintf(buffer, cap, "%s", b.c_str()); if (got) snprintf(sentence, sentence_cap, "%s", s.c_str()); return got ? 1 : 0;
+}
+int mh_kokoro_flush(char* buffer, size_t cap, char* out, size_t out_cap) { std::string b = buffer, s; const bool got = skw::kokoro::SentenceSplitter::flush(&b, &s); snprintf(buffer, cap, "%s", b.c_str()); if (got) snprintf(out, out_cap, "%s", s.c_str()); return got ? 1 : 0; }
+const char* mh_kokoro_preview(const char* s, size_t max_chars) { static thread_local std::string r; if (!skw::kokoro::text_preview(s, max_chars, &r)) return nullptr; return r.c_str(); }
 const char* mh_json_quote(const char* s) { static thread_local std::string r; r = skw::json_quote(s); return r.c_str(); }
 const char* mh_json_f32(float f) { static thread_local std::string r; r = skw::json_f32(f); return r.c_str(); }
 const char* mh_utf8_trim(const char* s) { static thread_local std::string r; r = skw::utf8_trim(s); return r.c_str(); }

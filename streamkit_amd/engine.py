@@ -50,7 +50,7 @@ class Trace(C.Structure):
 
 
 TRACE_DT = np.dtype([("chosen_id", "<i4"), ("forced_id", "<i4"), ("top1_id", "<i4"), ("top2_id", "<i4"),
-                     ("top1", "<f4"), ("top2", "<f4"), ("forced_logit", "<f4"), ("lse", "<f4")])      # skw_trace_step
+                     ("top1", "<f4"), ("top2", "<f4"), ("forced_logit", "<f4"), ("lse", "<f4"), ("temperature", "<f4"), ("pad", "<i4")])      # skw_trace_step
 
 
 class ResamplerState(C.Structure):

@@ -1,0 +1,180 @@
+"""CPU tests of the Kokoro TTS node's boundary and text front end: libkokoro.so loads and describes itself as the
+reference's node does; the sentence splitter reproduces the REFERENCE'S OWN unit-test vectors (tests/golden/kokoro_splitter_vectors.json, from
+sentence_splitter.rs:65-95 — the only reference-held fixtures anywhere on this path); sanitize_text / punctuation / preview follow
+kokoro_node.rs:444-492, 546-559, 696-731; the oracle's synthesiser is sane.  The synthesiser itself needs the GPU: tests/test_gpu_kokoro.py."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kokoro_lib
+import minihost
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KOKORO = os.path.join(ROOT, "streamkit_amd", "libkokoro.so")
+
+
+def _L():
+    L = minihost.lib()
+    L.mh_kokoro_sanitize.restype = C.c_char_p; L.mh_kokoro_sanitize.argtypes = [C.c_char_p]
+    L.mh_kokoro_extract_sentence.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.mh_kokoro_flush.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.mh_kokoro_preview.restype = C.c_char_p; L.mh_kokoro_preview.argtypes = [C.c_char_p, C.c_size_t]
+    return L
+
+
+def sanitize(s):
+    return _L().mh_kokoro_sanitize(s.encode()).decode()
+
+
+def extract(buf, min_length):
+    b = C.create_string_buffer(buf.encode(), 4096); s = C.create_string_buffer(4096)
+    got = _L().mh_kokoro_extract_sentence(b, 4096, min_length, s, 4096)
+    return (s.value.decode() if got else None), b.value.decode()
+
+
+def flush(buf):
+    b = C.create_string_buffer(buf.encode(), 4096); s = C.create_string_buffer(4096)
+    got = _L().mh_kokoro_flush(b, 4096, s, 4096)
+    return (s.value.decode() if got else None), b.value.decode()
+
+
+def test_sentence_splitter_reproduces_the_references_own_vectors(built):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "kokoro_splitter_vectors.json")))
+    assert len(g["cases"]) == 3
+    for case in g["cases"]:
+        buf = case["buffer"]
+        for st in case["steps"]:
+            got, buf = extract(buf, case["min_length"]) if st["call"] == "extract_sentence" else flush(buf)
+            assert got == st["returns"] and buf == st["buffer_after"], (case["name"], st, got, buf)
+
+
+def test_sentence_splitter_rules_beyond_the_vectors(built):
+    # sentence_splitter.rs:22-33: boundaries are tried IN LIST ORDER, the first that occurs anywhere cuts: ". " beats an earlier "! "
+    assert extract("Hi! Hello there. Bye.", 5) == ("Hi! Hello there.", "Bye.")
+    assert extract("Wait! Now", 5) == ("Wait!", "Now")
+    assert extract("one?\ntwo", 3) == ("one?", "two")
+    # Chinese marks need no following space (:25); `len` is BYTES (:17): "你好。" is 9 bytes
+    assert extract("你好。再见", 9) == ("你好。", "再见")
+    assert extract("你好。", 10) == (None, "你好。")
+    # no boundary inside, but final punctuation at the end -> the whole buffer, untrimmed (:36-44)
+    assert extract("Hello world.How are you?", 5) == ("Hello world.How are you?", "")
+    assert extract("no end mark yet", 5) == (None, "no end mark yet")
+    assert extract("  padded. next", 5) == ("padded.", "next")                       # .trim() on the cut sentence (:32)
+    assert flush("") == (None, "")
+
+
+def test_sanitize_text_follows_the_reference(built):
+    # kokoro_node.rs:696-731
+    assert sanitize("Hello,   world!\n\nNew\tline") == "Hello, world! New line"           # white space collapses (split_whitespace + join)
+    assert sanitize("  trim me  ") == "trim me"
+    assert sanitize("emoji \U0001F600 and <tags> & [brackets] #") == "emoji and tags brackets"   # everything outside the allow-list is dropped
+    assert sanitize("café naïve À Ÿ Œ") == "café naïve À Ÿ Œ"   # U+00E0..U+00FF and U+00C0..U+0178
+    assert sanitize("x y　z w") == "x y z w"                                # other White_Space becomes ' '
+    assert sanitize("你好，世界。（ok）") == "你好，世界。（ok）"   # CJK + full-width marks
+    assert sanitize("it's \"quoted\" - a:b;c 1,000.5?") == "it's \"quoted\" - a:b;c 1,000.5?"
+    assert sanitize("Ź Āx¿") == "Āx"                                   # U+0179 is just past 'Ÿ'; U+00BF is below 'À'
+    assert sanitize("\U0001F600☃") == ""
+
+
+def test_text_preview(built):
+    L = _L()
+    assert L.mh_kokoro_preview("héllo wörld".encode(), 5).decode() == "héllo..."          # characters, not bytes (kokoro_node.rs:552-553)
+    assert L.mh_kokoro_preview(b"short", 80).decode() == "short"
+    assert L.mh_kokoro_preview(b"exact", 5).decode() == "exact"
+    assert L.mh_kokoro_preview(b"anything", 0) is None                                     # 0 = omit (JSON null)
+
+
+def test_kokoro_plugin_metadata_matches_reference_node(built):
+    # plugins/native/kokoro/src/kokoro_node.rs:178-256
+    p = minihost.Plugin(KOKORO)
+    md = p.metadata
+    assert md["kind"] == "kokoro" and md["registered_as"] == "plugin::native::kokoro"
+    assert md["description"].startswith("High-quality text-to-speech synthesis using the Kokoro TTS model.") and md["description"].endswith("further processing.")
+    assert md["inputs"] == [{"name": "in", "accepts": [{"type": 2}]}]                       # PacketType::Text
+    assert md["outputs"] == [{"name": "out", "type": 0}]                                    # RawAudio
+    assert md["categories"] == ["audio", "tts"]
+    sc = md["param_schema"]; props = sc["properties"]
+    assert sc["required"] == ["model_dir"] and sc["type"] == "object"
+    ref = {"model_dir": "./models/kokoro-multi-lang-v1_1", "speaker_id": 50, "speed": 1.0, "num_threads": 4, "min_sentence_length": 10,
+           "execution_provider": "cpu", "emit_telemetry": False, "telemetry_preview_chars": 80}
+    for k, v in ref.items():
+        assert props[k]["default"] == v, k
+    assert props["speaker_id"]["maximum"] == 102 and props["speed"]["minimum"] == 0.5 and props["speed"]["maximum"] == 2.0
+    assert props["execution_provider"]["enum"] == ["cpu", "cuda", "tensorrt"] and props["telemetry_preview_chars"]["maximum"] == 1000
+    assert set(props) - set(ref) == {"gpu_device"}                                           # the one additive key
+
+
+def test_kokoro_plugin_config_errors_before_the_gpu(built, tmp_path):
+    p = minihost.Plugin(KOKORO)
+    with pytest.raises(RuntimeError, match="Config parse error: missing field `model_dir`"):       # config.rs:10: the one field without a default
+        p.create_node({"speaker_id": 3})
+    with pytest.raises(RuntimeError, match="Config parse error: invalid type for `speed`"):
+        p.create_node({"model_dir": str(tmp_path), "speed": "fast"})
+    with pytest.raises(RuntimeError, match="Failed to canonicalize model dir '%s/nope'" % tmp_path):   # kokoro_node.rs:303-305
+        p.create_node({"model_dir": str(tmp_path / "nope")})
+    with pytest.raises(RuntimeError, match="model file not found: %s/model.onnx" % tmp_path):          # kokoro_node.rs:753-756
+        p.create_node({"model_dir": str(tmp_path)})
+    (tmp_path / "model.onnx").write_bytes(b"x")
+    with pytest.raises(RuntimeError, match="voices file not found: %s/voices.bin" % tmp_path):
+        p.create_node({"model_dir": str(tmp_path)})
+    with pytest.raises(RuntimeError, match="Failed to canonicalize model dir '%s/models/kokoro-multi-lang-v1_1'" % os.getcwd()):   # params None -> KokoroTtsConfig::default()
+        p.create_node(None)
+
+
+def test_tts_library_exports_its_abi_and_fails_loudly_without_a_gpu(built):
+    import re
+    hdr = open(os.path.join(ROOT, "include", "skw_tts.h")).read()
+    names = sorted(set(re.findall(r"\b(skw_tts_[a-z_]+)\s*\(", hdr)))
+    L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libskw_tts.so"))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), n
+    from conftest import HAVE_GPU
+    if not HAVE_GPU:
+        with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+            kokoro_lib.Tts(kokoro_lib.synth_kokoro_dir())
+
+
+def test_oracle_synthesiser_is_sane_and_deterministic(built):
+    d = kokoro_lib.synth_kokoro_dir()
+    o = kokoro_lib.OracleTts(d)
+    text = "Hello world. This is a test!"
+    r = o.synth(text, sid=50)
+    ids = kokoro_lib.tokenize(text, d)
+    assert ids[0] == 0 and ids[-1] == 0 and ids[1:5] == [20, 17, 24, 27]                      # "hello" through the lexicon: h e l o
+    F = int(r["dur"].sum())
+    assert (r["dur"] >= 1).all() and r["y"].size == 5 * (120 * F - 1) and np.isfinite(r["y"]).all()
+    assert 60.0 <= r["f0"].min() and r["f0"].max() <= 400.0
+    assert 1e-3 < float(np.sqrt((r["y"] ** 2).mean())) < 0.5 and float(np.abs(r["y"]).max()) < 4.0
+    # speed divides the durations; another speaker changes the voice
+    fast = o.synth(text, sid=50, speed=2.0)
+    assert fast["dur"].sum() < r["dur"].sum() and (fast["dur"] >= 1).all()
+    other = o.synth(text, sid=3)
+    assert not np.array_equal(other["f0"][:8], r["f0"][:8])
+    again = o.synth(text, sid=50)
+    assert np.array_equal(again["y"].view(np.uint32), r["y"].view(np.uint32))
+
+
+def test_text_front_end_equals_an_independent_restatement_on_random_strings(built):
+    """skw_kokoro_text.h (C++) against tests/kokoro_lib.py (Python, written separately from the same Rust source) on seeded random strings drawn
+    from an alphabet that exercises every class of the sanitiser and every boundary of the splitter."""
+    rng = np.random.default_rng(7)
+    alphabet = list("abc XYZ019 .,!?-'\":;\n\t") + ["é", "ÿ", "À", "Ÿ", "Ź", "¿", "。", "！", "？", "，", "（", "你", "好", " ", "　", " ", "\U0001F600", "<", "#", "~", "\r"]
+    for _ in range(400):
+        s = "".join(rng.choice(alphabet) for _ in range(int(rng.integers(0, 60))))
+        assert sanitize(s) == kokoro_lib.sanitize_text(s), repr(s)
+        buf = kokoro_lib.sanitize_text(s)
+        if "\x00" in buf:
+            continue
+        ml = int(rng.integers(1, 25))
+        for _ in range(8):
+            want, rest = kokoro_lib.extract_sentence(buf, ml)
+            got, rest_c = extract(buf, ml)
+            assert (got, rest_c) == (want, rest), (repr(buf), ml)
+            if want is None:
+                break
+            buf = rest
+    assert kokoro_lib.node_sentences(["Hello world", "how are you? fine. thanks"], 10) == ["Hello world.", "how are you? fine.", "thanks."]      # ". " is tried before "? " (list order)

@@ -185,9 +185,10 @@ def test_full_size_batch_tokens(eng, small_model_path):
 
 
 def _report(tag, r):
-    print("%s: %d decisions checked under teacher forcing, %d argmax disagreements (%d on the exact mode's runner-up), largest exact margin at one %s, "
-          "largest logit error %.4g (bounds: logit %.3g, margin %.3g)" % (tag, r["steps_checked"], r["argmax_disagreements"], r["disagreements_on_exact_runner_up"],
-                                                                          r["max_margin_at_disagreement"], r["max_logit_err"], LOGIT_ERR_BOUND, MARGIN_BOUND))
+    print("%s: %d decisions checked under teacher forcing (%d inside temperature passes, %d of those draws came out differently), %d argmax disagreements (%d on the exact mode's "
+          "runner-up), largest exact margin at one %s, largest logit error %.4g (bounds: logit %.3g, margin %.3g)"
+          % (tag, r["steps_checked"], r["sampled_steps"], r["sampled_draws_that_differ"], r["argmax_disagreements"], r["disagreements_on_exact_runner_up"],
+             r["max_margin_at_disagreement"], r["max_logit_err"], LOGIT_ERR_BOUND, MARGIN_BOUND))
 
 
 def test_teacher_forced_every_step_of_the_full_size_batch(eng, small_model_path):
