@@ -50,6 +50,7 @@ static void set_err(char* err, size_t n, const char* fmt, ...) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(errbuf, 512, "HIP error '%s' at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); return -1; } } while (0)
 
 struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0;
+                half_t* w_nat = nullptr;   // the same weight with the contraction axis in natural order (decoder projections fed by a LayerNorm: skw_gemm16_small_lnA)
                 // ggml's arithmetic for a block-quantised weight (skw_kernels_q8.hip): int8 [n_out][n_in], scales / offsets [n_in / 32][n_pad]; null for f16 weights
                 int8_t* qw = nullptr; float* dwT = nullptr; float* mwT = nullptr; int n_pad = 0, qform = 0; };
 struct HostQ { std::vector<int8_t> q; std::vector<float> d, m; int n_out = 0, K = 0; };      // a quantised weight in the common integer form, host side
@@ -104,7 +105,7 @@ static bool up_q(skw_model* m, const HostQ& h, int qtype, DevLin* L) {
     return L->qw && L->dwT && L->mwT;
 }
 // f16 weight [n_out][n_in] (or conv [oc][ic][kw]) -> device [n_out][k_pad] with the contraction axis in kperm order
-static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname, const char* bname, DevLin* L, char* err, size_t errlen) {
+static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname, const char* bname, DevLin* L, char* err, size_t errlen, bool want_nat = false) {
     RawT* w = find_t(ts, wname);
     if (!w) { set_err(err, errlen, "missing tensor %s", wname.c_str()); return false; }
     if (w->type != 1) { set_err(err, errlen, "tensor %s: only f16 matmul weights are supported (ggml type %d)", wname.c_str(), w->type); return false; }
@@ -123,6 +124,7 @@ static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname
     L->n_in = n_in; L->n_out = n_out; L->k_pad = k_pad;
     L->w = (half_t*)dev_upload(m, h.data(), h.size());
     if (!L->w) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; }
+    if (want_nat && w->n_dims == 2 && k_pad == n_in) { L->w_nat = (half_t*)dev_upload(m, src, (size_t)n_out * n_in); if (!L->w_nat) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
     if (m->quant && !w->qblk.empty()) { HostQ h; host_q(*w, &h); if (!up_q(m, h, w->qtype, L)) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
     L->b = nullptr;
     if (bname) {
@@ -290,17 +292,17 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     for (int l = 0; l < m->hp.n_text_layer && ok; ++l) {
         DecLayer& L = m->dec[l]; std::string p = "decoder.blocks." + std::to_string(l) + ".";
         ok = ok && up_ln(m, ts, p + "attn_ln.weight", p + "attn_ln.bias", &L.attn_ln, err, errlen);
-        ok = ok && up_lin(m, ts, p + "attn.query.weight", (p + "attn.query.bias").c_str(), &L.q, err, errlen);
-        ok = ok && up_lin(m, ts, p + "attn.key.weight", nullptr, &L.k, err, errlen);
-        ok = ok && up_lin(m, ts, p + "attn.value.weight", (p + "attn.value.bias").c_str(), &L.v, err, errlen);
+        ok = ok && up_lin(m, ts, p + "attn.query.weight", (p + "attn.query.bias").c_str(), &L.q, err, errlen, true);
+        ok = ok && up_lin(m, ts, p + "attn.key.weight", nullptr, &L.k, err, errlen, true);
+        ok = ok && up_lin(m, ts, p + "attn.value.weight", (p + "attn.value.bias").c_str(), &L.v, err, errlen, true);
         ok = ok && up_lin(m, ts, p + "attn.out.weight", (p + "attn.out.bias").c_str(), &L.o, err, errlen);
         ok = ok && up_ln(m, ts, p + "cross_attn_ln.weight", p + "cross_attn_ln.bias", &L.cross_ln, err, errlen);
-        ok = ok && up_lin(m, ts, p + "cross_attn.query.weight", (p + "cross_attn.query.bias").c_str(), &L.cq, err, errlen);
+        ok = ok && up_lin(m, ts, p + "cross_attn.query.weight", (p + "cross_attn.query.bias").c_str(), &L.cq, err, errlen, true);
         ok = ok && up_lin(m, ts, p + "cross_attn.key.weight", nullptr, &L.ck, err, errlen);
         ok = ok && up_lin(m, ts, p + "cross_attn.value.weight", (p + "cross_attn.value.bias").c_str(), &L.cv, err, errlen);
         ok = ok && up_lin(m, ts, p + "cross_attn.out.weight", (p + "cross_attn.out.bias").c_str(), &L.co, err, errlen);
         ok = ok && up_ln(m, ts, p + "mlp_ln.weight", p + "mlp_ln.bias", &L.mlp_ln, err, errlen);
-        ok = ok && up_lin(m, ts, p + "mlp.0.weight", (p + "mlp.0.bias").c_str(), &L.fc1, err, errlen);
+        ok = ok && up_lin(m, ts, p + "mlp.0.weight", (p + "mlp.0.bias").c_str(), &L.fc1, err, errlen, true);
         ok = ok && up_lin(m, ts, p + "mlp.2.weight", (p + "mlp.2.bias").c_str(), &L.fc2, err, errlen);
         if (ok) {   // fused q|k|v weight [3d][k_pad] and bias [3d] (k has no bias: zeros; adding 0.0f is exact)
             const int d = L.q.n_out, kp = L.q.k_pad; L.qkv.n_in = L.q.n_in; L.qkv.n_out = 3 * d; L.qkv.k_pad = kp;
@@ -311,6 +313,14 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
                 hipMemcpy(w, L.q.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)d * kp, L.k.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)2 * d * kp, L.v.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
                 hipMemset(b, 0, (size_t)3 * d * 4); hipMemcpy(b, L.q.b, (size_t)d * 4, hipMemcpyDeviceToDevice); hipMemcpy(b + 2 * d, L.v.b, (size_t)d * 4, hipMemcpyDeviceToDevice);
                 L.qkv.w = w; L.qkv.b = b;
+                if (L.q.w_nat && L.k.w_nat && L.v.w_nat) {      // the concatenation again in natural k order
+                    half_t* wn = nullptr;
+                    if (hipMalloc((void**)&wn, (size_t)3 * d * kp * 2) == hipSuccess) {
+                        m->allocs.push_back(wn);
+                        hipMemcpy(wn, L.q.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(wn + (size_t)d * kp, L.k.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(wn + (size_t)2 * d * kp, L.v.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                        L.qkv.w_nat = wn;
+                    }
+                }
             }
             if (ok && m->quant) {   // the same concatenation in the integer form
                 HostQ hq, hk, hv, all; host_q(*find_t(ts, p + "attn.query.weight"), &hq); host_q(*find_t(ts, p + "attn.key.weight"), &hk); host_q(*find_t(ts, p + "attn.value.weight"), &hv);
@@ -347,7 +357,7 @@ struct skw_ctx {
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     hipStream_t cur = nullptr;                       // stream the launch helpers enqueue on (== stream outside the decode groups)
     static const int MAX_GROUPS = 8; hipStream_t gstream[MAX_GROUPS] = {}; hipEvent_t gev[MAX_GROUPS] = {}; int n_groups = 1;
-    struct StepGraph { int g, r0, n, precision; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
+    struct StepGraph { int g, r0, n, precision, ln_stats; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
     char errbuf[512] = {0};
     std::vector<void*> allocs;
     // front end
@@ -359,7 +369,7 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr; int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;   // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
-    unsigned* ln_cnt = nullptr;
+    unsigned* ln_cnt = nullptr; double* ln_stats = nullptr;   // ln_stats: [(3 layers + 1)][max_batch][2] f64 row statistics of the residual stream, one table per LayerNorm site of a decode step (f16_mfma; skw_gemm16_small_lnA)
     half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;   // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
@@ -369,6 +379,7 @@ struct skw_ctx {
     int* h_row_live = nullptr; int* d_row_live = nullptr;      // per-row live flags in pinned host memory and their device-side address: k_dec_sample clears a row's flag itself,
                                                                // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
+    int ln_stats_on = 1;                             // LayerNorm folded into the decode GEMMs (f16_mfma); SKW_DEC_LN_STATS=0 or skw_debug_set_ln_stats(ctx, 0): LayerNorm kernels
     int live_rows_hint = -1;                         // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
     int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
     skw_timing timing{};
@@ -402,6 +413,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     // -1 = default (see skw_full_batch): one row group as a captured step graph in both precisions (dependent chains on two streams do
     // not overlap on this part: tools/probe/probe_stream_overlap.hip)
     { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : -1; }
+    { const char* e = getenv("SKW_DEC_LN_STATS"); c->ln_stats_on = e ? (atoi(e) != 0) : 1; }
     { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
     for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -415,7 +427,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
-    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
+    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true); WS(ln_stats, double, (size_t)(3 * hp.n_text_layer + 1) * B * 2, true);
     if (m->quant) {
         const int kmax = 4 * std::max(d, dt); const size_t rows = (size_t)B * nc; c->q8_kmax = kmax;
         WS(y32, float, rows * d, false); WS(h32, float, rows * 4 * d, false); WS(encq32, float, rows * d, false);
@@ -450,6 +462,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
 
 // ------------------------------------------------------------------ debug taps (encoder layer 0, natural layouts; enabled by skw_debug_enable)
 static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on = false;
+extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)
 extern "C" void skw_debug_enable(int on) { g_taps_on = on != 0; g_taps.clear(); }
 extern "C" long skw_debug_get(const char* name, float* out, size_t cap) {
     auto it = g_taps.find(name); if (it == g_taps.end()) return -1; if (out && cap >= it->second.size()) memcpy(out, it->second.data(), it->second.size() * 4); return (long)it->second.size();
@@ -722,34 +735,60 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     static const bool ln_tail_env = getenv("SKW_DEC_LN_TAIL") ? atoi(getenv("SKW_DEC_LN_TAIL")) != 0 : false;
     const bool tail = ln_tail_env && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
     const bool embed_ln = dt <= 1536;
+    // LayerNorm without a launch (f16_mfma): the GEMM that writes the residual row accumulates its sum / sum of squares, the GEMM that
+    // consumes LayerNorm(x) normalises its A operand as it loads it.  36 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
+    const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
+    const int n_sites = 3 * hp.n_text_layer + 1;
+    auto stats = [&](int site) { return c->ln_stats + ((size_t)site * c->max_batch + r0) * 2; };
     auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
-    if (embed_ln) skw_dec_embed_ln(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, m->dec[0].attn_ln.w, m->dec[0].attn_ln.b, dy16, s);
+    // a GEMM fed by LayerNorm(dx): the normalising form when the statistics of `site` were accumulated by dx's producer, else LayerNorm kernel + GEMM
+    auto gemm_ln = [&](SkwGemmArgs a, const DevLin& Lw, const DevLN& ln, int site, bool normalised) {
+        if (lnA && site >= 0) {
+            a.W = Lw.w_nat; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b; a.ln_stats = stats(site);
+            ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
+            if (skw_gemm16_small_lnA(a, c->cur)) return;
+            a.W = Lw.w; a.ln_x = nullptr; a.ln_stats = nullptr;
+        }
+        GEMM_LN(c, a, dx, ln, dy16, s, normalised);
+    };
+    if (embed_ln) skw_dec_embed_ln(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, m->dec[0].attn_ln.w, m->dec[0].attn_ln.b, dy16, s, lnA ? c->ln_stats : nullptr, lnA ? (long)n_sites * c->max_batch * 2 : 0);
     else skw_dec_embed(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); GEMM_LN(c, a, dx, L.attn_ln, dy16, s, tail || (l == 0 && embed_ln)); }
+          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); if (lnA) a.ln_stats = stats(3 * l); GEMM_S(c, a, a.K); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
-        if (!tail && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
+        if (!tail && !lnA && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
-            { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; GEMM_LN(c, a, dx, L.cross_ln, dy16, s, tail); }
+            { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; GEMM_LN(c, a, dx, L.mlp_ln, dy16, s, tail); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); if (lnA) a.ln_stats = stats(3 * l + 1); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
         { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;
           if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
+          if (lnA) a.ln_stats = stats(3 * l + 2);
           GEMM_S(c, a, a.K); }
     }
     if (want_logits) {
-        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
-        SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
+        SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32);
+        bool done = false;
+        if (lnA && hp.n_vocab >= 8192) {      // the vocabulary kernel stages A through LDS once per workgroup: it normalises while it does (the final LayerNorm's launch goes too)
+            a.ln_x = dx; a.ln_w = m->d_ln.w; a.ln_b = m->d_ln.b; a.ln_stats = stats(3 * (hp.n_text_layer - 1) + 2);
+            ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
+            done = skw_gemm16_small(a, c->cur);
+            if (!done) { a.ln_x = nullptr; a.ln_stats = nullptr; }
+        }
+        if (!done) {
+            if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
+            GEMM_S(c, a, a.K);
+        }
     }
     c->cur = c->stream;
 }
@@ -759,7 +798,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
 static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogitParams& lp) {
     for (size_t i = 0; i < c->step_graphs.size(); ++i) {
         auto& sg = c->step_graphs[i];
-        if (sg.g == g && sg.r0 == r0 && sg.n == n && sg.precision == c->precision && memcmp(&sg.lp, &lp, sizeof lp) == 0) {
+        if (sg.g == g && sg.r0 == r0 && sg.n == n && sg.precision == c->precision && sg.ln_stats == c->ln_stats_on && memcmp(&sg.lp, &lp, sizeof lp) == 0) {
             if (i + 1 != c->step_graphs.size()) { auto hit = sg; c->step_graphs.erase(c->step_graphs.begin() + i); c->step_graphs.push_back(hit); }   // most recently used last
             return c->step_graphs.back().exec;
         }
@@ -774,7 +813,7 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     if (exec) {
         // bounded: a long-lived server with ragged batches would otherwise keep one executable graph per (group, rows, params) forever
         if (c->step_graphs.size() >= 24) { hipGraphExecDestroy(c->step_graphs.front().exec); c->step_graphs.erase(c->step_graphs.begin()); }
-        skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.precision = c->precision; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg);
+        skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.precision = c->precision; sg.ln_stats = c->ln_stats_on; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg);
     }
     return exec;
 }

@@ -11,6 +11,8 @@ The f16 matrix cores do not sum in an order a CPU can restate (tools/probe/probe
     draw text tokens from 50 k random embeddings, so about one decision in a few hundred is a near-tie (a trained model is far more
     decided); the same holds between any two summation orders, the reference's ggml order included.
 The exact mode (tests/test_gpu_parity.py) stays the bit-for-bit checker of every kernel's data flow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -237,3 +239,31 @@ def test_teacher_forced_ragged_multi_window_batch(eng, tiny_model_path):
     with pytest.raises(RuntimeError):
         ctx.full_batch(pcms, p, forced=[t["chosen_id"][: max(0, len(t) - 3)] for t in r["traces_exact"]])
     ctx.close(); m.close()
+
+
+def test_layernorm_folded_into_the_decode_gemms(eng, tiny_model_path, small_model_path):
+    """f16_mfma decode without LayerNorm launches (row statistics accumulated by the GEMM that writes the residual row, applied by the GEMM that consumes
+    LayerNorm(x) on its operand load) against the same precision WITH the LayerNorm kernels: logits within the mode's tolerance,
+    and the step-by-step teacher-forced check against the exact precision holds in both forms (it is the default form that every other test here runs)."""
+    import ctypes as C
+    L = eng.lib(); L.skw_debug_set_ln_stats.argtypes = [C.c_void_p, C.c_int]
+    for path, clip in ((tiny_model_path, 3), (small_model_path, 5)):
+        m = eng.Model(path); ctx = eng.Context(m, max_batch=4, max_samples=480000)
+        ctx.set_precision("f16_mfma")
+        pcm = synth.clip(clip, 480000)
+        toks = [50258, 50259, 50359, 50364, 1234, 777, 31000, 50400, 50400, 9]
+        lg = {}
+        for on in (1, 0):
+            L.skw_debug_set_ln_stats(ctx.h, on)
+            ctx.encode(pcm)
+            lg[on] = ctx.decode_logits(toks)
+        err = float(np.abs(lg[1] - lg[0]).max()); rng = float(lg[0].max() - lg[0].min())
+        print("LayerNorm folded vs launched (%s): max abs logit difference %.3g on a range of %.3g" % (os.path.basename(path), err, rng))
+        assert err < LOGIT_ERR_BOUND and err < TOL_LOGIT_REL * rng
+        pcms = [synth.clip(c, n) for c, n in [(0, 480000), (2, 16000 * 7 + 123), (6, 16000 * 12)]]
+        for on in (0, 1):
+            L.skw_debug_set_ln_stats(ctx.h, on)
+            r = teacher_forced_compare(ctx, pcms)
+            _report("%s, LayerNorm %s" % (os.path.basename(path), "folded" if on else "launched"), r)
+            assert r["ok"], (on, r["max_logit_err"], r["max_margin_at_disagreement"])
+        ctx.close(); m.close()
