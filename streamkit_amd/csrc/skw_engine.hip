@@ -369,7 +369,7 @@ struct skw_ctx {
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
     float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr; int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;   // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
-    unsigned* ln_cnt = nullptr; double* ln_stats = nullptr;   // ln_stats: [(3 layers + 1)][max_batch][2] f64 row statistics of the residual stream, one table per LayerNorm site of a decode step (f16_mfma; skw_gemm16_small_lnA)
+    unsigned* ln_cnt = nullptr;
     half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;   // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
@@ -427,7 +427,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
-    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true); WS(ln_stats, double, (size_t)(3 * hp.n_text_layer + 1) * B * 2, true);
+    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     if (m->quant) {
         const int kmax = 4 * std::max(d, dt); const size_t rows = (size_t)B * nc; c->q8_kmax = kmax;
         WS(y32, float, rows * d, false); WS(h32, float, rows * 4 * d, false); WS(encq32, float, rows * d, false);
@@ -735,23 +735,21 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     static const bool ln_tail_env = getenv("SKW_DEC_LN_TAIL") ? atoi(getenv("SKW_DEC_LN_TAIL")) != 0 : false;
     const bool tail = ln_tail_env && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
     const bool embed_ln = dt <= 1536;
-    // LayerNorm without a launch (f16_mfma): the GEMM that writes the residual row accumulates its sum / sum of squares, the GEMM that
-    // consumes LayerNorm(x) normalises its A operand as it loads it.  36 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
+    // LayerNorm without a launch (f16_mfma): the GEMM that consumes LayerNorm(x) loads the f32 rows, takes their statistics from its own
+    // registers and normalises on the way into the MFMA.  35 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
     const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
-    const int n_sites = 3 * hp.n_text_layer + 1;
-    auto stats = [&](int site) { return c->ln_stats + ((size_t)site * c->max_batch + r0) * 2; };
     auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
-    // a GEMM fed by LayerNorm(dx): the normalising form when the statistics of `site` were accumulated by dx's producer, else LayerNorm kernel + GEMM
+    // a GEMM fed by LayerNorm(dx): the normalising form (site >= 0), else LayerNorm kernel + GEMM
     auto gemm_ln = [&](SkwGemmArgs a, const DevLin& Lw, const DevLN& ln, int site, bool normalised) {
         if (lnA && site >= 0) {
-            a.W = Lw.w_nat; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b; a.ln_stats = stats(site);
+            a.W = Lw.w_nat; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b;
             ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
             if (skw_gemm16_small_lnA(a, c->cur)) return;
-            a.W = Lw.w; a.ln_x = nullptr; a.ln_stats = nullptr;
+            a.W = Lw.w; a.ln_x = nullptr;
         }
         GEMM_LN(c, a, dx, ln, dy16, s, normalised);
     };
-    if (embed_ln) skw_dec_embed_ln(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, m->dec[0].attn_ln.w, m->dec[0].attn_ln.b, dy16, s, lnA ? c->ln_stats : nullptr, lnA ? (long)n_sites * c->max_batch * 2 : 0);
+    if (embed_ln) skw_dec_embed_ln(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, m->dec[0].attn_ln.w, m->dec[0].attn_ln.b, dy16, s);
     else skw_dec_embed(m->te.w, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
@@ -760,7 +758,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); if (lnA) a.ln_stats = stats(3 * l); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
         if (!tail && !lnA && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
@@ -769,26 +767,15 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); if (lnA) a.ln_stats = stats(3 * l + 1); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
         { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;
           if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
-          if (lnA) a.ln_stats = stats(3 * l + 2);
           GEMM_S(c, a, a.K); }
     }
     if (want_logits) {
-        SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32);
-        bool done = false;
-        if (lnA && hp.n_vocab >= 8192) {      // the vocabulary kernel stages A through LDS once per workgroup: it normalises while it does (the final LayerNorm's launch goes too)
-            a.ln_x = dx; a.ln_w = m->d_ln.w; a.ln_b = m->d_ln.b; a.ln_stats = stats(3 * (hp.n_text_layer - 1) + 2);
-            ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
-            done = skw_gemm16_small(a, c->cur);
-            if (!done) { a.ln_x = nullptr; a.ln_stats = nullptr; }
-        }
-        if (!done) {
-            if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
-            GEMM_S(c, a, a.K);
-        }
+        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }      // (the vocabulary kernel's 256 workgroups would each normalise all 64 rows: measured +6.4 us against this 5.0 us launch)
+        SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
     c->cur = c->stream;
 }

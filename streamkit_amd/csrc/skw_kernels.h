@@ -48,8 +48,6 @@ struct SkwGemmArgs {
     int epi;
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
-    double* ln_stats;               // f16_mfma decode, LayerNorm without a launch: [M][2] f64 (sum x, sum x^2) per row of the residual stream.  A GEMM with EPI_F32 that writes
-                                    // x adds its strip's share (f64 atomics); the GEMM that consumes LayerNorm(x) (ln_x set, skw_gemm16_small_lnA) reads them.  Zeroed once per step.
     half_t* ln_out; unsigned* ln_cnt;                          // skw_gemm16_small, EPI_F32 with N = ldc: the workgroup that completes a 16-row block of C also writes
                                                                // ln_out [M][N] = f16 kperm LayerNorm(C rows; ln_w, ln_b); ln_cnt: SKW_LN_CNT_STRIDE zeroed words per row block (needs N <= 16 * 8 * 15)
 };
@@ -59,7 +57,7 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
 // f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
 bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);
-bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);  // A = LayerNorm(ln_x; ln_w, ln_b) from the row statistics in ln_stats, applied to the operand as it is loaded; W in NATURAL k order
+bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);  // A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b), statistics and normalisation inside the kernel from the rows it holds in registers; W in NATURAL k order
 bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);   // the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
@@ -93,8 +91,7 @@ struct SkwQ8Args { const int8_t* qa; const float* dyT; const float* syT;        
 void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s);
 bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s);
 void skw_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
-void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s,
-                      double* zero = nullptr, long n_zero = 0);   // zero: the step's LayerNorm statistics (ln_stats), cleared here — the first kernel of a decode step
+void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s);
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null

@@ -826,9 +826,8 @@ __global__ void k_dec_embed(const half_t* te, const float* pe, const int* tok, c
 }
 // the same with the first layer's LayerNorm attached: one wave per row, x written in passing (d <= 1536)
 template <int NC, bool FULL>
-__global__ __launch_bounds__(256) void k_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, double* zero, long n_zero) {
+__global__ __launch_bounds__(256) void k_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_zero; i += (long)gridDim.x * 256) zero[i] = 0.0;
     if (row >= B) return;
     const int tk = tok[row * (int)(sizeof(SkwSeqState) / 4)], ps = pos[row * (int)(sizeof(SkwSeqState) / 4)];
     float v[1][NC], wv[NC], bv[NC];
@@ -844,10 +843,10 @@ __global__ __launch_bounds__(256) void k_dec_embed_ln(const half_t* te, const fl
 void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_embed, dim3(B), dim3(256), 0, s, te, pe, tok, pos, d, x);
 }
-void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s, double* zero, long n_zero) {
-    if (d == 768) hipLaunchKernelGGL((k_dec_embed_ln<12, true>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16, zero, n_zero);
-    else if (d <= 768) hipLaunchKernelGGL((k_dec_embed_ln<12, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16, zero, n_zero);
-    else hipLaunchKernelGGL((k_dec_embed_ln<24, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16, zero, n_zero);
+void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const int* pos, int B, int d, float* x, const float* w, const float* b, half_t* y16, hipStream_t s) {
+    if (d == 768) hipLaunchKernelGGL((k_dec_embed_ln<12, true>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
+    else if (d <= 768) hipLaunchKernelGGL((k_dec_embed_ln<12, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
+    else hipLaunchKernelGGL((k_dec_embed_ln<24, false>), dim3((B + 3) / 4), dim3(256), 0, s, te, pe, tok, pos, B, d, x, w, b, y16);
 }
 
 __device__ __forceinline__ float block_max(float v, float* sh) {
