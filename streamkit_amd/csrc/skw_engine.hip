@@ -859,9 +859,12 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
     bool same = true; for (int k = 0; k < R; ++k) same = same && old_slots[k] == k;
     if (same) return 0;
     const long ke = (long)hp.n_audio_ctx * hp.n_text_state, ve = (long)hp.n_text_head * 64 * c->Tpad;
-    if (!c->stageK) {
-        HIPCHK(hipMalloc((void**)&c->stageK, (size_t)L * c->max_batch * ke * 2)); HIPCHK(hipMalloc((void**)&c->stageV, (size_t)L * c->max_batch * ve * 2));
-        HIPCHK(hipMalloc((void**)&c->slot_map, sizeof(int) * 2 * c->max_batch));
+    if (!c->stageK || !c->stageV || !c->slot_map) {      // all three or none: a partial failure must not leave a later retry launching k_slot_copy on a null buffer
+        half_t *sk = nullptr, *sv = nullptr; int* sm = nullptr;
+        if (hipMalloc((void**)&sk, (size_t)L * c->max_batch * ke * 2) != hipSuccess || hipMalloc((void**)&sv, (size_t)L * c->max_batch * ve * 2) != hipSuccess || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
+            hipFree(sk); hipFree(sv); hipFree(sm); snprintf(errbuf, 512, "temperature retry: staging buffers for the cross K/V move could not be allocated"); return -1;
+        }
+        hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); c->stageK = sk; c->stageV = sv; c->slot_map = sm;
     }
     std::vector<int> h(2 * (size_t)c->max_batch, 0);
     for (int k = 0; k < R; ++k) { h[k] = old_slots[k]; h[c->max_batch + k] = k; }
@@ -1344,6 +1347,7 @@ extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_fra
     if (dsp_reserve(d, (size_t)n_in_frames * channels, (size_t)n_out * channels)) return -1;
     HIPCHK(hipMemcpyAsync(d->d_in, in, sizeof(float) * (size_t)n_in_frames * channels, hipMemcpyHostToDevice, d->stream));
     skw_resample_polyphase_launch(d->d_in, 0, n_in_frames, n_in_frames, channels, d->d_coef, L, M, T, d->d_out, 0, n_out, d->stream);
+    HIPCHK(hipGetLastError());      // a refused launch (LDS request) must surface as an error, not as stale output
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n_out * channels, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     *out_frames = n_out; return 0;
 }
@@ -1382,6 +1386,7 @@ extern "C" int skw_polyphase_stream_push(skw_pp_stream* p, const float* in, long
         if (n_new > out_cap_frames) { snprintf(errbuf, 512, "resampler: output capacity too small"); return -1; }
         if ((size_t)n_new > p->cap_o) { hipFree(p->d_o); p->cap_o = (size_t)n_new * 2; HIPCHK(hipMalloc((void**)&p->d_o, p->cap_o * ch * sizeof(float))); }
         skw_resample_polyphase_launch(p->d_buf, p->base, p->total - p->base, final_call ? p->total : p->total, (int)ch, d->d_coef, L, M, T, p->d_o, p->next, n_new, d->stream);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, p->d_o, (size_t)n_new * ch * sizeof(float), hipMemcpyDeviceToHost, d->stream));
         p->next = m_hi; *out_frames = n_new;
     }

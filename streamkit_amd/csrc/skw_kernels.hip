@@ -9,6 +9,7 @@
 //   k_attn_encoder     KQ = mul_mat(K,Q); soft_max_ext; mul_mat(V, KQ_soft_max) (K4)
 //   k_dec_*            whisper_decode_internal pieces (K7-K9), whisper_process_logits + greedy (K11)
 #include "skw_kernels.h"
+#include <atomic>
 #include <cstring>
 #include "../../include/skw_math.h"
 
@@ -1911,6 +1912,10 @@ void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, lon
     const int span_max = (int)(((long)(L - 1) + (long)(PP_TILE - 1) * M) / L) + T;
     const size_t x_bytes = (size_t)span_max * channels * 4, h_bytes = (size_t)L * (T | 1) * 4;
     const int coef_in_lds = (x_bytes + h_bytes <= 96 * 1024) ? 1 : 0;
+    if (x_bytes + (coef_in_lds ? h_bytes : 0) > 64 * 1024) {      // more dynamic LDS than the default limit: raise it on this device (per device: several GPUs may run in one process)
+        static std::atomic<bool> raised[64]; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!raised[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_resample_polyphase, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised[dev].store(true, std::memory_order_release); }
+    }
     hipLaunchKernelGGL(k_resample_polyphase, dim3((unsigned)((n_out + PP_TILE - 1) / PP_TILE)), dim3(256), x_bytes + (coef_in_lds ? h_bytes : 0), s,
                        in, in_base, n_in, n_total, channels, coef, L, M, T, coef_in_lds, out, out_first, n_out);
 }

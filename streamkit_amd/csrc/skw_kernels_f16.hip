@@ -13,6 +13,7 @@
 // Reference call site of everything here: /root/reference/plugins/native/whisper/src/lib.rs:644-646 (`whisper_state.full`).
 #include "skw_dev_common.h"
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -295,10 +296,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     }
 }
 
+// per-device state (a host with gpu_device "auto" runs one engine worker thread per GPU in one process): CU count and "dynamic LDS limit raised" flags are keyed by
+// the current device; the atomics make the lazy initialisation safe from several threads (the worst case is the same value written twice)
+static int skw_cur_device() { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0; return dev; }
 static int skw_cu_count() {
-    static int n = 0;
-    if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; if (n <= 0) n = 256; }
-    return n;
+    static std::atomic<int> n[64];
+    const int dev = skw_cur_device(); int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) { hipDeviceProp_t p; v = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; n[dev].store(v, std::memory_order_relaxed); }
+    return v;
 }
 template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves, one workgroup per CU) when both extents fill it, 128 x 128 (4 waves, two per CU) otherwise;
@@ -982,8 +987,8 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
 }
 template <int MT, int RD, int NWV> static void launch_gemm16_vocab_n(const SkwGemmArgs& a, hipStream_t s) {
     const int lds = 16 * MT * (a.K * 2 + 16);
-    static bool once = false;
-    if (!once) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+    static std::atomic<bool> once[64];      // the attribute is per device
+    { const int dev = skw_cur_device(); if (!once[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once[dev].store(true, std::memory_order_release); } }
     const int n_strips = (a.N + 15) / 16, rows = (a.M + 16 * MT - 1) / (16 * MT);
     const int slots = std::max(1, skw_cu_count() / rows);
     const int spw = (n_strips + slots - 1) / slots;
