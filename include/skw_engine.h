@@ -174,8 +174,9 @@ void skw_resampler_init(skw_resampler_state*, double ratio /* out/in */, int chu
 /* n_chunks full chunks of interleaved f32 input -> interleaved output (host pointers); bit-exact with rubato's Linear interpolation */
 int skw_resample_linear(skw_dsp*, skw_resampler_state*, const float* in, int n_chunks, float* out, int out_cap_frames, int* out_frames);
 /* how the last skw_resample_linear obtained its index sequence: 0 = the closed-form per-chunk proposal was proven equal to rubato's
- * sequential f64 walk on the device (48 / 32 / 96 kHz sources), 1 = the binade-stepping proposal was (44.1 kHz family and every other
- * ratio met so far), 2 = neither: the single-lane walk ran */
+ * sequential f64 walk on the device (48 / 32 / 96 kHz sources), 1 = a second proposal was (44.1 kHz family and every other ratio met so
+ * far: chunk starts walked by the host for long calls, stepped binade by binade on the device for short ones), 2 = neither: the
+ * single-lane walk ran */
 int skw_dsp_last_scan_fallback(const skw_dsp*);
 /* additive quality mode: polyphase Kaiser-windowed sinc (32 taps/phase), whole buffer */
 int skw_resample_polyphase(skw_dsp*, const float* in, long n_in_frames, int channels, int in_rate, int out_rate, float* out, long out_cap_frames, long* out_frames);

@@ -1263,7 +1263,7 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
 // ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
 struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
                  size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0;
-                 double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flags[2] = {0, 0}; };
+                 double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flags[2] = {0, 0}; bool host_walk_last = false; };
 extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
     int ndev = skw_device_count();
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: the resampler kernels require an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
@@ -1297,8 +1297,25 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
         HIPCHK(hipMalloc((void**)&d->d_start, d->cap_chunks * sizeof(double))); HIPCHK(hipMalloc((void**)&d->d_count, d->cap_chunks * sizeof(int))); HIPCHK(hipMalloc((void**)&d->d_offset, d->cap_chunks * sizeof(int)));
         if (!d->d_flag) HIPCHK(hipMalloc((void**)&d->d_flag, 2 * sizeof(int)));
     }
-    skw_resample_linear_launch(d->d_in, ch, st->last_index, 1.0 / st->ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames,
-                               d->d_start, d->d_count, d->d_offset, d->d_flag, d->stream);
+    // The chunk starts are one sequential f64 recurrence over the whole call (rubato's idx += t_ratio).  When every addition of it is exact (48 / 32 / 96 / 8 kHz
+    // sources: t_ratio has a handful of mantissa bits) a closed form gives them on the device.  When it is not (the 44.1 kHz family) and the call is long, the
+    // recurrence is what a CPU core is for — ~480 k dependent additions per 30 s, 0.6 ms at four cycles each, against 7.5 ms for one GPU lane stepping binades —
+    // so the host walks it, the device proves every chunk against it in parallel (k_resample_walk) and does the data path.  Short calls (a streaming packet or
+    // two) keep the device's own proposals.  Same IEEE additions either way: the result is rubato's, bit for bit.
+    const double t_ratio = 1.0 / st->ratio;
+    const bool t_exact = chunk <= 4096 && ldexp(t_ratio, 36) == floor(ldexp(t_ratio, 36));
+    const bool host_walk = !t_exact && n_chunks >= 8 && !getenv("SKW_RESAMPLE_NO_HOST_WALK");
+    if (host_walk) {
+        std::vector<double> hs((size_t)n_chunks + 1); std::vector<int> hc((size_t)n_chunks + 1, 0), ho((size_t)n_chunks + 1);
+        const double end_idx = (double)(chunk - 9) - ceil(t_ratio); double s = st->last_index; int off = 0;
+        for (int cix = 0; cix < n_chunks; ++cix) { double x = s; int n = 0; while (x < end_idx) { x += t_ratio; n++; } hs[cix] = s; hc[cix] = n; ho[cix] = off; off += n; s = x - (double)chunk; }
+        hs[n_chunks] = s; ho[n_chunks] = off;
+        HIPCHK(hipMemcpyAsync(d->d_start, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipMemcpyAsync(d->d_count, hc.data(), sizeof(int) * hc.size(), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->d_offset, ho.data(), sizeof(int) * ho.size(), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));      // (the vectors are locals)
+    }
+    d->host_walk_last = host_walk;
+    skw_resample_linear_launch(d->d_in, ch, st->last_index, t_ratio, chunk, n_chunks, d->d_pos, d->d_frac, d->d_n, d->d_li, d->d_out, out_cap_frames,
+                               d->d_start, d->d_count, d->d_offset, d->d_flag, d->stream, host_walk);
     int n = 0; double li = 0;
     HIPCHK(hipMemcpyAsync(&n, d->d_n, sizeof(int), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipMemcpyAsync(&li, d->d_li, sizeof(double), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipMemcpyAsync(d->last_flags, d->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
@@ -1351,7 +1368,7 @@ extern "C" int skw_resample_polyphase(skw_dsp* d, const float* in, long n_in_fra
     HIPCHK(hipMemcpyAsync(out, d->d_out, sizeof(float) * (size_t)n_out * channels, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     *out_frames = n_out; return 0;
 }
-extern "C" int skw_dsp_last_scan_fallback(const skw_dsp* d) { return d->last_flags[1] ? 2 : (d->last_flags[0] ? 1 : 0); }
+extern "C" int skw_dsp_last_scan_fallback(const skw_dsp* d) { return d->last_flags[1] ? 2 : ((d->last_flags[0] || d->host_walk_last) ? 1 : 0); }
 
 // streaming polyphase: the input tail the later outputs still need stays on the device; a push uploads only the new frames and
 // computes only the outputs whose filter support has arrived (all remaining ones when `final`).  Identical to the whole-buffer result.

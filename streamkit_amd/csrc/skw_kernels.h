@@ -153,5 +153,5 @@ void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   /
 // ---------------- resampler (R1) ----------------
 // start / count / offset: [n_chunks + 1] scratch for the per-chunk proposal; flag: 1 int (set when the proposal had to be redone sequentially)
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
-                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s);
+                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal = false);   // host_proposal: start / count / offset already hold the first proposal
 void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out, long out_first, long n_out, hipStream_t s);

@@ -1007,8 +1007,12 @@ struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_
 template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
                                                            const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq) {
-    if (active && !active[blockIdx.y * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
-    const int probe = f32_out >> 8; f32_out &= 1;      // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
+    // XCD-aware placement (bit 16 of f32_out; SKW_XATTN_XCD=1, measured: no effect, 54.5 - 55.2 us against 54.3): workgroups are dealt to the 8 XCDs round-robin by linear id, so the (H / HPW) workgroups of one sequence — which together
+    // read every 1536-byte K row of that sequence, a 384-byte piece each — land on different XCDs; remapped, the pieces of a row are requested through one XCD's L2
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((f32_out >> 16) & 1) { const int G = gridDim.x, Lid = by * G + bx, j = Lid & 7, k = Lid >> 3; by = j + 8 * (k / G); bx = k % G; }
+    if (active && !active[by * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
+    const int probe = (f32_out >> 8) & 0xff; f32_out &= 1;      // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
     __shared__ float smax[HPW][WPH];
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     __shared__ double lnred[HPW * WPH];
     __shared__ __attribute__((aligned(16))) half_t p16[PV16 ? HPW : 1][PV16 ? MAXT * 64 : 8];      // PV16: the probabilities as f16 in kperm order, the f16 MFMA's second operand
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
-    const int hraw = blockIdx.x * HPW + hs, b = blockIdx.y;
+    const int hraw = bx * HPW + hs, b = by;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
     const half_t* K = kbase + (long)b * k_batch_stride + h * 64;
@@ -1134,8 +1138,13 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     // one pass = 64 keys: refill the free ring slot with pass t+2 first, then consume `cur`.  Roles rotate by name (three passes per
     // loop trip) so no register copies force early waits, and the scheduling barriers keep the loads where they are written.
     auto pass = [&](int t, u32x4 (&cur)[8], u32x4 (&fill)[8]) {
+        // (wave-uniform) no refill past this wave's key range: the two passes after it belong to the next wave of the head, which fetches them itself — unconditional
+        // refills were a third more K requests per wave (8 passes fetched for 6 consumed), and the PMC pass showed them arriving from memory, not from a cache:
+        // 338 MB read per 64-row launch against 295 MB algorithmic
+        if (t + 2 < t_hi) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fill[i] = ldk16(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+            for (int i = 0; i < 8; ++i) fill[i] = ldk16(K + (long)min((t + 2) * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (t < t_hi) {       // wave-uniform
             const int key = t * 64 + lane;
@@ -1258,6 +1267,8 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     // heads per workgroup: 3 (256 workgroups of 12 waves at 64 rows x 12 heads: every CU)
     static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
+    static const int xcd_env = getenv("SKW_XATTN_XCD") ? atoi(getenv("SKW_XATTN_XCD")) : 0;
+    if (xcd_env && (B & 7) == 0) f32_out |= 1 << 16;
     if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
     else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
     else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
@@ -1855,14 +1866,15 @@ __global__ void k_resample_lerp(const float* in, int channels, const int* pos, c
     }
 }
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
-                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s) {
+                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal) {
     static const bool force_scan = getenv("SKW_RESAMPLE_SCAN") != nullptr;     // measurement switch: the single-lane walk only
     if (force_scan) hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
     else {
         // flag[0]: 0 = first proposal stands, 1 = it failed, 2 = second proposal to be checked; flag[1]: the second one failed too
         int* fail2 = flag + 1;
         hipMemsetAsync(flag, 0, 2 * sizeof(int), s);
-        hipLaunchKernelGGL(k_resample_starts_simple, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
+        // first proposal: the closed form on the device, or — an inexact step over many chunks — the chunk starts the host walked and uploaded (skw_resample_linear)
+        if (!host_proposal) hipLaunchKernelGGL(k_resample_starts_simple, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
         hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag, flag, 1);
         hipLaunchKernelGGL(k_resample_starts, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, start, count, offset, flag);
         hipLaunchKernelGGL(k_resample_walk, dim3((n_chunks + 63) / 64), dim3(64), 0, s, start, count, offset, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, flag, fail2, 2);

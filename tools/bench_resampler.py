@@ -21,7 +21,7 @@ for in_rate in (48000, 44100):
     for it in range(6):
         st = dsp.linear_stream(16000 / in_rate, 960, 1)
         t0 = time.perf_counter(); y = dsp.resample_linear(st, x, n_chunks); dt = time.perf_counter() - t0
-    print("linear    %5d -> 16000 Hz, 30 s mono: %7.3f ms per call, %d frames out, index walk: %s" % (in_rate, dt * 1e3, y.size, ("per-chunk parallel, closed-form proposal proven", "per-chunk parallel, binade-stepping proposal proven", "single lane (fallback)")[dsp.last_scan_fallback()]))
+    print("linear    %5d -> 16000 Hz, 30 s mono: %7.3f ms per call, %d frames out, index walk: %s" % (in_rate, dt * 1e3, y.size, ("per-chunk parallel, closed-form proposal proven", "per-chunk parallel, second proposal proven (host-walked chunk starts for long calls, binade stepping for short ones)", "single lane (fallback)")[dsp.last_scan_fallback()]))
     for it in range(6):
         t0 = time.perf_counter(); y = dsp.resample_polyphase(x, 1, in_rate, 16000); dt = time.perf_counter() - t0
     print("polyphase %5d -> 16000 Hz, 30 s mono: %7.3f ms per call, %d frames out" % (in_rate, dt * 1e3, y.size))
