@@ -379,6 +379,8 @@ struct skw_ctx {
     int* h_row_live = nullptr; int* d_row_live = nullptr;      // per-row live flags in pinned host memory and their device-side address: k_dec_sample clears a row's flag itself,
                                                                // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
+    int prompt_pass_on = 1;                          // the prompt ([prev] + past text + sot / language / task) in one multi-row pass instead of one token per step; SKW_PROMPT_PASS=0 or skw_debug_set_prompt_pass(ctx, 0)
+    int rows_cap = 0; SkwSeqState* pf_st = nullptr;  // decode-step scratch rows (>= max_batch: the prompt pass runs one row per prompt token) and the prompt pass's per-token pseudo-states
     int ln_stats_on = 1;                             // LayerNorm folded into the decode GEMMs (f16_mfma); SKW_DEC_LN_STATS=0 or skw_debug_set_ln_stats(ctx, 0): LayerNorm kernels
     int live_rows_hint = -1;                         // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
     int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
@@ -414,6 +416,8 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     // not overlap on this part: tools/probe/probe_stream_overlap.hip)
     { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : -1; }
     { const char* e = getenv("SKW_DEC_LN_STATS"); c->ln_stats_on = e ? (atoi(e) != 0) : 1; }
+    { const char* e = getenv("SKW_PROMPT_PASS"); c->prompt_pass_on = e ? (atoi(e) != 0) : 1; }
+    c->rows_cap = std::max(max_batch, std::min(max_batch * (SKW_PROMPT_CAP - 1), 4096));
     { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
     for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -425,13 +429,14 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
-    WS(dx, float, (size_t)B * dt, false); WS(dy16, half_t, (size_t)B * dt, false); WS(dq16, half_t, (size_t)B * dt, false); WS(datt16, half_t, (size_t)B * dt, false); WS(dh16, half_t, (size_t)B * 4 * dt, false);
+    { const size_t R = (size_t)c->rows_cap;
+      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     if (m->quant) {
         const int kmax = 4 * std::max(d, dt); const size_t rows = (size_t)B * nc; c->q8_kmax = kmax;
         WS(y32, float, rows * d, false); WS(h32, float, rows * 4 * d, false); WS(encq32, float, rows * d, false);
-        WS(dy32, float, (size_t)B * dt, false); WS(datt32, float, (size_t)B * dt, false); WS(dh32, float, (size_t)B * 4 * dt, false);
+        WS(dy32, float, (size_t)c->rows_cap * dt, false); WS(datt32, float, (size_t)c->rows_cap * dt, false); WS(dh32, float, (size_t)c->rows_cap * 4 * dt, false);
         WS(q8_a, int8_t, rows * kmax, false); WS(q8_d, float, rows * (kmax / 32), false); WS(q8_s, float, rows * (kmax / 32), false);
     }
     c->max_tok = hp.n_text_ctx / 2;
@@ -462,6 +467,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
 
 // ------------------------------------------------------------------ debug taps (encoder layer 0, natural layouts; enabled by skw_debug_enable)
 static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on = false;
+extern "C" void skw_debug_set_prompt_pass(skw_ctx* c, int on) { c->prompt_pass_on = on != 0; }     // tests: the prompt as one pass / one token per step
 extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)
 extern "C" void skw_debug_enable(int on) { g_taps_on = on != 0; g_taps.clear(); }
 extern "C" long skw_debug_get(const char* name, float* out, size_t cap) {
@@ -691,13 +697,17 @@ __global__ void k_lang_argmax(const float* logits, int n_vocab, int tok_sot, int
     if (threadIdx.x == 0) out[blockIdx.x] = bi;
 }
 // rows [r0, r0 + Bw) of the window batch on stream s: sequences are independent, so groups of rows can run on their own streams
-static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logits, hipStream_t s) {
+// prefill: the rows are prompt tokens (c->pf_st, scratch from row 0), several per sequence: the K / V caches are addressed through the row's sequence (pad) and cache row (seek)
+static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logits, hipStream_t s, bool prefill = false) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int dt = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, ntc = hp.n_text_ctx;
     const float KQscale = (float)pow((double)((float)dt / H), -0.25);
     const int live = c->live_rows_hint >= 0 ? std::min(c->live_rows_hint, Bw) : Bw;      // rows whose attention kernels do work (algorithmic-byte booking of the profile)
     c->cur = s;
     float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
-    half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = c->st + r0;
+    half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = prefill ? c->pf_st : c->st + r0;
+    const int* seqp = prefill ? &st[0].pad : nullptr;                                  // row -> sequence for the attention kernels
+    const int* kvpos = prefill ? &st[0].seek : &st[0].cur_pos;                          // where the QKV epilogue appends a row's K / V: absolute cache row (prefill) or position inside the row's own cache
+    const long kv_ld = prefill ? 0 : (long)ntc * dt;
     if (use_q8(c)) {   // quantised file, exact precision: ggml's arithmetic (see run_encoder); the row group's q8 scratch starts at its first row
         float* dy32 = c->dy32 + (size_t)r0 * dt; float* datt32 = c->datt32 + (size_t)r0 * dt; float* dh32 = c->dh32 + (size_t)r0 * 4 * dt;
         skw_dec_embed_f32(m->te32, m->d_pe, &st[0].cur_token, &st[0].cur_pos, Bw, dt, dx, s);
@@ -706,14 +716,14 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
             half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
             Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
-            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
             { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
               SkwQ8Out qo{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), Bw};
-              skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo); }
+              skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo, seqp); }
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.cross_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0, true); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1, 0, seqp); }
             Q8_ROWS(c, datt32, dt, Bw, dt, r0);
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.mlp_ln, r0, dy32);
@@ -733,7 +743,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     // launch boundary (3 us) is cheaper on this part than what the hand-over costs inside a kernel (write-through stores, two counter
     // round trips and the read-back, each ~2 us across XCDs): 15.6 us for GEMM + tail against 5.1 + 5.0 for the two launches.  Off by default.
     static const bool ln_tail_env = getenv("SKW_DEC_LN_TAIL") ? atoi(getenv("SKW_DEC_LN_TAIL")) != 0 : false;
-    const bool tail = ln_tail_env && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
+    const bool tail = ln_tail_env && !prefill && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
     const bool embed_ln = dt <= 1536;
     // LayerNorm without a launch (f16_mfma): the GEMM that consumes LayerNorm(x) loads the f32 rows, takes their statistics from its own
     // registers and normalises on the way into the MFMA.  35 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
@@ -756,16 +766,16 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk; a.C3 = sv; a.ldc2 = (long)ntc * dt; a.pos_ptr = &st[0].cur_pos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s); }
+          a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
-        if (!tail && !lnA && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
+        if (!tail && !lnA && !prefill && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
@@ -983,6 +993,33 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
             s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = np_row[j]; s.min_margin = INFINITY; s.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP]; s.cur_pos = 0;
             s.temperature = temps[tidx[act[j]]];
         }
+        // The prompt in one pass (whisper.cpp evaluates it in one whisper_decode call): every prompt token but a row's last becomes a row of ONE decoder pass —
+        // the step's own kernels, a row per (sequence, position), the caches addressed through the row's sequence — which fills the self-attention K / V
+        // of those positions in every layer; the rows then start at their last prompt token, whose logits the first sampling step needs.  A window of a long
+        // file carries up to 224 tokens of previous text in its prompt: 225 steps of 1.4 ms become one pass.  Per-row arithmetic does not depend on what else is
+        // in the batch, so the results are the stepped ones, bit for bit (tests/test_gpu_parity.py).
+        int prefill_passes = 0;
+        if (c->prompt_pass_on) {
+            const int ntc = hp.n_text_ctx;
+            std::vector<SkwSeqState> pf; std::vector<int> row_end;      // row_end: cumulative rows after each sequence (chunks are whole sequences)
+            for (int j = 0; j < Bw; ++j) {
+                for (int k = 0; k + 1 < np_row[j]; ++k) { SkwSeqState t; memset(&t, 0, sizeof t); t.active = 1; t.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP + k]; t.cur_pos = k; t.pad = j; t.seek = j * ntc + k; pf.push_back(t); }
+                row_end.push_back((int)pf.size());
+                c->h_st[j].cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP + np_row[j] - 1]; c->h_st[j].cur_pos = np_row[j] - 1;
+            }
+            size_t lo = 0; int jlo = 0;
+            while (lo < pf.size()) {
+                int jhi = jlo; while (jhi < Bw && row_end[jhi] - (int)lo <= c->rows_cap) ++jhi;      // sequences jlo .. jhi-1 fit (a prompt is at most SKW_PROMPT_CAP - 1 <= rows_cap rows)
+                const size_t hi = row_end[jhi - 1]; const int n = (int)(hi - lo);
+                if (n > 0) {
+                    HIPCHK(hipMemcpyAsync(c->pf_st, pf.data() + lo, sizeof(SkwSeqState) * n, hipMemcpyHostToDevice, c->stream));
+                    run_decoder_step(c, 0, n, 0, false, c->stream, true);
+                    HIPCHK(hipStreamSynchronize(c->stream));      // (pf is a host vector and pf_st is reused by the next chunk)
+                    ++prefill_passes;
+                }
+                lo = hi; jlo = jhi;
+            }
+        }
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
@@ -1044,7 +1081,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         }
         { float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[2], c->ev[3]); hipEventElapsedTime(&b, c->ev[3], c->ev[4]); enc_ms += a; dec_ms += b; }
         tot_windows += Bw;
-        { int mx = 0; for (int j = 0; j < Bw; ++j) { const int rs = c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens; mx = std::max(mx, rs); tot_row_steps += rs; } tot_steps += mx; }   // decoder steps until the last row finished; row-steps: steps a row was live in
+        { int mx = 0; for (int j = 0; j < Bw; ++j) { const int rs = c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens; mx = std::max(mx, c->prompt_pass_on ? c->h_st[j].n_tokens : rs); tot_row_steps += rs; } tot_steps += mx + prefill_passes; }   // decoder passes until the last row finished (the prompt pass counts as one); row-steps: (row, token) pairs that streamed cross K / V, prompt tokens included
         // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];

@@ -95,12 +95,13 @@ void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const i
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0});
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0},
+                       const int* seq = nullptr);   // seq (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0);
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr);
 // the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
 bool skw_dec_cross_attn_vt_q_ok(int H, int d);
 bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
@@ -121,6 +122,8 @@ struct SkwSeqState {
     float temperature;     // 0: argmax; > 0: logits / t, then a std::discrete_distribution draw from the clip's mt19937
     int32_t pad;
 };
+// The prompt pass (skw_engine.hip, prefill): one SkwSeqState per PROMPT TOKEN, so every kernel of the decode step takes it as a row —
+//   active = 1, cur_token / cur_pos = the token and its position, pad = the sequence (window slot) it belongs to, seek = slot * n_text_ctx + position (its K / V cache row).
 // whisper_full_with_state: `const int delta_min = 10` mel frames (100 ms) - shortest input transcribed, the loop's stop rule and the decoder's end-of-audio test
 #define SKW_DELTA_MIN 10
 #define SKW_PROMPT_CAP 240   // [prev] + n_text_ctx/2 past tokens + sot, language, task, notimestamps

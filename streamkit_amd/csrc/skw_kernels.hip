@@ -876,13 +876,15 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // A block is 4 waves = 4 heads of one sequence.
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
-                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwQ8Out q8) {
+                                                  const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwQ8Out q8,
+                                                  const int* seq) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
     const int act = active ? active[b * active_stride] : 1;   // (tested after the prefetches below are on their way: one round trip for all of them)
-    const half_t* K = kbase + (long)b * batch_stride + h * 64;
-    const half_t* V = vbase + (long)b * batch_stride + h * 64;
+    const int bs = seq ? seq[b * active_stride] : b;          // the prompt pass: row b is one prompt token of sequence seq[b] (one more round trip there; the step has seq == null)
+    const half_t* K = kbase + (long)bs * batch_stride + h * 64;
+    const half_t* V = vbase + (long)bs * batch_stride + h * 64;
     // Everything whose address depends on nothing loaded is requested before the first wait, in the order it is needed (a wave's loads return in
     // order): q and the first 64 K rows, which the score chains start on, then the V rows of the first NPRE keys, which arrive under them (rows
     // past n_kv exist in the cache and are simply not used): the short-context steps pay one round trip, not one per 16 keys after the softmax.
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
 template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
-                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq) {
+                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq, const int* seq) {
     // XCD-aware placement (bit 16 of f32_out; SKW_XATTN_XCD=1, measured: no effect, 54.5 - 55.2 us against 54.3): workgroups are dealt to the 8 XCDs round-robin by linear id, so the (H / HPW) workgroups of one sequence — which together
     // read every 1536-byte K row of that sequence, a 384-byte piece each — land on different XCDs; remapped, the pieces of a row are requested through one XCD's L2
     int bx = blockIdx.x, by = blockIdx.y;
@@ -1026,7 +1028,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     const int hraw = bx * HPW + hs, b = by;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
-    const half_t* K = kbase + (long)b * k_batch_stride + h * 64;
+    const int bs = seq ? seq[b * active_stride] : b;          // the prompt pass: row b attends over the cross K / V of sequence seq[b]
+    const half_t* K = kbase + (long)bs * k_batch_stride + h * 64;
     auto ldk16 = [&](const half_t* p) -> u32x4 { return *(const u32x4*)p; };   // (non-temporal loads of the once-read K / V^T bytes measured 2 us slower per launch: 62.7 vs 60.4)
     H8v qh[8];                                  // q stays packed (32 VGPRs instead of 64); converted in the chain's shadow
     const int nt = (n_ctx + 63) >> 6, nth = (nt + WPH - 1) / WPH;
@@ -1174,7 +1177,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     for (int t = t_lo; t < t_hi; t += 3) { pass(t, k0, k2); pass(t + 1, k1, k0); pass(t + 2, k2, k1); }
     // V^T ring: start the first loads before the softmax so they fly during it
     const int r16 = lane & 15, g = lane >> 4;
-    const long bh = (long)b * H + h;
+    const long bh = (long)bs * H + h;
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vtbase + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     constexpr int CT = 4 / WPH;                                                   // channel tiles per wave
     const unsigned vo = (unsigned)(((half * CT * 16 + r16) * Tpad + g * 8) * 2);
@@ -1260,7 +1263,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
             for (int r = 0; r < 4; ++r) att_store(out, (long)b * ldo, h * 64 + (half * CT + ct) * 16 + 4 * g + r, oacc[ct][r], f32_out);
     }
 }
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16) {
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16, const int* seq) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     const SkwXQ none{};
@@ -1269,10 +1272,10 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
     static const int xcd_env = getenv("SKW_XATTN_XCD") ? atoi(getenv("SKW_XATTN_XCD")) : 0;
     if (xcd_env && (B & 7) == 0) f32_out |= 1 << 16;
-    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
-    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
-    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none);
+    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
 }
 // LayerNorm + query projection + cross attention in one launch (k_dec_cross_attn<.., FQ>): x f32 [B][d] residual rows, Wq f16 [d][ldw] kperm.
 // Returns false (nothing launched) for geometries the fused prologue does not cover; the caller then runs the three launches.
@@ -1289,17 +1292,17 @@ bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_
     if (!skw_dec_cross_attn_vt_q_ok(H, d)) return false;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     const SkwXQ xq{x, ln_w, ln_b, Wq, ldw, bq, scale, d};
-    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, 0, xq);
+    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, 0, xq, (const int*)nullptr);
     return true;
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq) {
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8);
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq);
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0});
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, (const int*)nullptr);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

@@ -382,3 +382,31 @@ def test_no_speech_middle_window_keeps_the_carried_prompt(eng, tiny_model_path):
         ro = om.full(pcm, po)
         assert _same(rg, ro) and rg["n_decode_steps"] == ro["n_decode_steps"]
     ctx.close(); m.close()
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16_mfma"])
+def test_prompt_in_one_pass_equals_one_token_per_step(eng, tiny_model_path, precision):
+    """The prompt of a window ([prev] + up to 224 tokens of the clip's earlier text + sot / language / task) as ONE multi-row decoder pass, the way
+    whisper.cpp evaluates it in one whisper_decode call, against feeding it a token per step: the same kernels run a row per (sequence, position), and a
+    row's arithmetic does not depend on its batch mates, so tokens, log-probs and timestamps are identical bit for bit in both precisions — and the number of
+    decoder passes of a multi-window batch drops by the prompt lengths.  (Every other multi-window test in this file runs the one-pass form against the oracle.)"""
+    import ctypes as C
+    L = eng.lib(); L.skw_debug_set_prompt_pass.argtypes = [C.c_void_p, C.c_int]
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=6, max_samples=16000 * 95)
+    ctx.set_precision(precision)
+    clips = [(11, 16000 * 75), (12, 16000 * 8), (13, 16000 * 47 + 123), (14, 16000 * 93), (5, 1500), (9, 488000)]
+    pcms = [synth.clip(c, n) for c, n in clips]
+    out = {}
+    for on in (0, 1):
+        L.skw_debug_set_prompt_pass(ctx.h, on)
+        res = ctx.full_batch(pcms)
+        out[on] = (res, ctx.timing())
+    for (c, n), a, b in zip(clips, out[0][0], out[1][0]):
+        assert a["tokens"] == b["tokens"] and [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]], (c, n)
+        assert a["n_windows"] == b["n_windows"] and a["n_decode_steps"] == b["n_decode_steps"]       # (whisper.cpp's own count: one decode call for the prompt either way)
+    stepped, one_pass = out[0][1]["n_decode_steps"], out[1][1]["n_decode_steps"]
+    print("prompt pass (%s): %d decoder passes for the batch with the prompt in one pass, %d with one prompt token per step; decode %.1f ms vs %.1f ms"
+          % (precision, one_pass, stepped, out[1][1]["decode_ms"], out[0][1]["decode_ms"]))
+    assert any(r["n_windows"] >= 3 for r in out[1][0])                                              # later windows carry their clip's earlier text
+    assert one_pass < stepped - 40, (one_pass, stepped)
+    ctx.close(); m.close()
