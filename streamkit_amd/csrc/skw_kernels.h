@@ -145,8 +145,9 @@ struct SkwLogitParams {
 // static_mask buffer = n_vocab bytes (1 = always suppressed), padded to 16, followed by the same bits transposed for the sampling
 // kernel's thread layout (two 64-bit words per thread); build it on the host with skw_static_mask_pack
 size_t skw_static_mask_bytes(int n_vocab);
+__host__ __device__ inline size_t skw_probs_row_floats(int n_vocab) { return (size_t)3 * ((n_vocab + 1) & ~1); }
 void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
-// probs: [B][n_vocab] workspace (written only by rows with temperature > 0); rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
+// probs: [B][skw_probs_row_floats(n_vocab)] workspace (written only by rows with temperature > 0): n_vocab f32 probabilities, then n_vocab f64 normalised ones; rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
 // n_active: [B] live flags (1 while the row decodes; the kernel stores 0 when it completes or fails) — host-mapped memory in the engine
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s,

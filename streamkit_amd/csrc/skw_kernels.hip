@@ -1373,6 +1373,70 @@ __device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg,
     trace[row * max_tok + i] = ts;
     if (fid != tk.id) { tk.id = fid; tk.plog = lg[fid] - lse; tk.p = skw_expf(tk.plog); }
 }
+// The same draw by the whole workgroup.  What libstdc++ defines is sequential — sum = p_0 + p_1 + ... in f64, q_i = p_i / sum, cp_i = q_0 + ... + q_i, the first
+// cp_i >= u — and the two sums stay one lane's k-ascending chains (their roundings ARE the definition).  But one lane fetching 51 865 floats from memory one at
+// a time and dividing each by the sum inside the chain made a sampled step 5.8 ms (a long-form batch with temperature fall-backs: 4.5 s of a 6.4 s call).  Here
+// the workgroup stages the row through LDS (64 KB at a time), the divisions — independent — are done by all threads, and the second chain stops at the hit.
+// Same bits as discrete_draw (oracle/skw_oracle.c), ~0.5 ms.  lds: 8 192 floats (static LDS stays under 64 KB).
+// S + p == S under round-to-nearest whenever 0 <= p < ulp(S) / 2: a 64-element block whose largest element is below that bound cannot move the running sum,
+// whatever the order inside it, and since the sum never decreases it stays immovable — such blocks are skipped WITHOUT changing a bit of the sequential result.
+// (Peaked distributions — most real steps — leave a few dozen elements in the chain; a flat one keeps all 51 865.)
+__device__ __forceinline__ double half_ulp_f64(double s) { const int e = (int)((__double_as_longlong(s) >> 52) & 0x7ff); return e == 0 ? 0.0 : __longlong_as_double((long long)max(e - 53, 1) << 52); }   // 2^(exponent(s) - 53); 0 for s == 0 / subnormal: nothing is skipped then
+__device__ int block_discrete_draw(const float* probs, double* q, int n, uint32_t* mt, float* lds, double* s_sum, int* s_hit) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double bmax[128];                                 // per 64-element block of the staged chunk
+    double sum = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 8192) {
+        const int m = min(8192, n - c0);
+        for (int i = tid; i < m; i += nt) lds[i] = probs[c0 + i];
+        __syncthreads();
+        if (tid < 128) { float mx = 0.0f; for (int i = tid * 64; i < min(tid * 64 + 64, m); ++i) mx = fmaxf(mx, lds[i]); bmax[tid] = (double)mx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int b0 = 0; b0 < m; b0 += 64) {
+                if (bmax[b0 >> 6] < half_ulp_f64(sum)) continue;
+                const int e = min(b0 + 64, m); int i = b0;
+                for (; i + 4 <= e; i += 4) { const f32x4 v = *(const f32x4*)(lds + i); sum += (double)v[0]; sum += (double)v[1]; sum += (double)v[2]; sum += (double)v[3]; }
+                for (; i < e; ++i) sum += (double)lds[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double cs = 0.0, tmp = 1.0;
+        for (int k = 0; k < 2; ++k) { cs += (double)mt_next(mt) * tmp; tmp *= 4294967296.0; }
+        double u = cs / tmp; if (u >= 1.0) u = 0.99999999999999988897769753748;   // nextafter(1.0, 0.0)
+        s_sum[0] = sum; s_sum[1] = u; *s_hit = -1;
+    }
+    __syncthreads();
+    sum = s_sum[0]; const double u = s_sum[1];
+    for (int i = tid; i < n; i += nt) q[i] = (double)probs[i] / sum;
+    __threadfence_block();
+    __syncthreads();
+    double* ldsd = (double*)lds; double cp = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 4096) {
+        const int m = min(4096, n - c0);
+        for (int i = tid; i < m; i += nt) ldsd[i] = q[c0 + i];
+        __syncthreads();
+        if (tid < 64) { double mx = 0.0; for (int i = tid * 64; i < min(tid * 64 + 64, m); ++i) mx = fmax(mx, ldsd[i]); bmax[tid] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            int hit = -1;
+            for (int b0 = 0; b0 < m && hit < 0; b0 += 64) {
+                const int e = min(b0 + 64, m);
+                if (c0 + e != n && bmax[b0 >> 6] < half_ulp_f64(cp)) continue;      // (the block that holds the last element is walked: cp = 1 there by definition)
+                for (int i = b0; i < e; ++i) { cp += ldsd[i]; if (c0 + i == n - 1) cp = 1.0; if (!(cp < u)) { hit = c0 + i; break; } }
+            }
+            *s_hit = hit;
+        }
+        __syncthreads();
+        if (*s_hit >= 0) break;      // (uniform)
+        __syncthreads();
+    }
+    const int h = *s_hit;
+    return h >= 0 ? h : n - 1;
+}
+
 __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
                                                      int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf,
                                                      const int* forced, SkwTraceStep* trace) {
@@ -1433,7 +1497,7 @@ __global__ __launch_bounds__(1024) void k_dec_sample_stream(float* logits_all, c
     ArgBest best = {0.0f, 0}, bts = {0.0f, 0x7fffffff};
     double sum_ts = 0.0; float top1 = -INFINITY, top2 = -INFINITY;
     const bool sampled = temperature > 0.0f;
-    float* probs = probs_all + (long)b * NV;
+    float* probs = probs_all + (long)b * skw_probs_row_floats(NV);
     if (sampled) { for (int i = tid; i < NV; i += nt) probs[i] = 0.0f; __syncthreads(); }   // (the loop below starts at lo: another thread owns the entry)
     for (int i = lo + tid; i < NV; i += nt) {
         float v = lg[i];
@@ -1637,7 +1701,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     // the largest logit, and the only exponentials the step still needs are the timestamp stripes' (their sum and their best).  Otherwise —
     // a near-tie, or a temperature pass that needs every probability — the whole row goes through the pass, as before.  Same bits either way.
     const bool sampled = temperature > 0.0f;
-    float* probs = probs_all + (long)b * NV;
+    float* probs = probs_all + (long)b * skw_probs_row_floats(NV);
     float t1 = -INFINITY, t2 = -INFINITY; int i1 = 0;
     SMP_PASS_BEGIN
 #pragma unroll
@@ -1704,11 +1768,16 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     if (lane == 0) sh_m[w] = r;
     if (sampled) __threadfence_block();
     __syncthreads();
+    int drawn = -1;
+    if (sampled) {      // (uniform) every thread takes part in the draw
+        __shared__ __attribute__((aligned(16))) float draw_lds[8192]; __shared__ double draw_s[2]; __shared__ int draw_hit;
+        drawn = block_discrete_draw(probs, (double*)(probs + ((NV + 1) & ~1)), NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS, draw_lds, draw_s, &draw_hit);
+    }
     if (tid != 0) return;
     r = sh_m[0]; for (int k = 1; k < SMP_NT / 64; ++k) r = comb(r, sh_m[k]);
     const ArgBest best = r.best, bts = r.bts; const double sum_ts = r.sum_ts;
     SkwTokenOut tk; tk.id = best.i; tk.p = best.v; tk.plog = r.best_logit - lse;
-    if (sampled) { tk.id = discrete_draw(probs, NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS); tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
+    if (sampled) { tk.id = drawn; tk.p = probs[tk.id]; tk.plog = lg[tk.id] - lse; }
     const int i = n_tok;
     if (TRACE) smp_trace_step(tk, lg, lse, i, max_tok, b, forced, trace, i1, i2, t1, t2, p, temperature);
     tk.tid = (bts.v > 0.0f) ? bts.i : 0; tk.pt = (float)((double)bts.v / (sum_ts + 1e-10)); tk.ptsum = (float)sum_ts;
