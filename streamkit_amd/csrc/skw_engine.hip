@@ -977,6 +977,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
             np_row[j] = n;
         }
         HIPCHK(hipMemcpyAsync(c->prompt_buf, pbuf.data(), sizeof(int) * pbuf.size(), hipMemcpyHostToDevice, c->stream));
+        lp.any_sampled = 0; for (int j = 0; j < Bw; ++j) if (temps[tidx[act[j]]] > 0.0f) lp.any_sampled = 1;      // (part of the step graph's key: greedy passes run the lean sampler)
         std::vector<int> fbuf;
         if (tracing) {      // this pass's forced tokens per row: the clip's sequence from its cursor on (-1 = none: the row feeds its own choices)
             fbuf.assign((size_t)Bw * c->max_tok, -1);

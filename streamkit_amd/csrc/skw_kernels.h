@@ -139,6 +139,7 @@ struct SkwLogitParams {
     int suppress_blank, suppress_nst, no_timestamps, single_segment, max_tokens;
     int tid0_initial;   // round(max_initial_ts / precision), <0 disables
     int n_max;          // n_text_ctx/2 - 4
+    int any_sampled;    // some row of this pass decodes at a temperature > 0 (host knowledge: the ladder's position per clip): the sampler's draw form (64 KB of LDS staging) is launched only then
 };
 // whisper_process_logits + whisper_sample_token(best) + the per-token state update of whisper_full_with_state.
 // logits: [B][n_vocab] (modified in place), static_mask: [n_vocab] bytes (1 = always suppressed: specials, langs, nst list when enabled)

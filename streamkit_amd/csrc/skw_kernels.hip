@@ -1563,7 +1563,7 @@ struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; flo
 #define SMP_PASS_BEGIN { int tq = tid; asm volatile("" : "+v"(tq));
 #define SMP_PASS_END }
 #define SMP_IDX(c) (tq + SMP_NT * (c))
-template <bool TRACE>      // TRACE: the trace / teacher-forced form (one more pass for the runner-up's index); the decode step's graph holds <false>
+template <bool TRACE, bool DRAW>      // TRACE: the trace / teacher-forced form (one more pass for the runner-up's index); DRAW: rows at a temperature > 0 may be present (the workgroup-wide draw and its LDS staging are compiled in); the greedy step's graph holds <false, false>
 __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
                                                        int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf,
                                                        const int* forced, SkwTraceStep* trace) {
@@ -1700,7 +1700,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     // of the ratio): when the runner-up is that far down, the winner of "largest probability, first index on ties" is the owner of
     // the largest logit, and the only exponentials the step still needs are the timestamp stripes' (their sum and their best).  Otherwise —
     // a near-tie, or a temperature pass that needs every probability — the whole row goes through the pass, as before.  Same bits either way.
-    const bool sampled = temperature > 0.0f;
+    const bool sampled = DRAW && temperature > 0.0f;
     float* probs = probs_all + (long)b * skw_probs_row_floats(NV);
     float t1 = -INFINITY, t2 = -INFINITY; int i1 = 0;
     SMP_PASS_BEGIN
@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     if (sampled) __threadfence_block();
     __syncthreads();
     int drawn = -1;
-    if (sampled) {      // (uniform) every thread takes part in the draw
+    if constexpr (DRAW) if (sampled) {      // (uniform) every thread takes part in the draw
         __shared__ __attribute__((aligned(16))) float draw_lds[8192]; __shared__ double draw_s[2]; __shared__ int draw_hit;
         drawn = block_discrete_draw(probs, (double*)(probs + ((NV + 1) & ~1)), NV, rng_all + (long)clip_idx[b] * SKW_RNG_WORDS, draw_lds, draw_s, &draw_hit);
     }
@@ -1816,8 +1816,9 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s, const int* forced, SkwTraceStep* trace) {
     if (p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) {
-        if (trace) hipLaunchKernelGGL(k_dec_sample<true>, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
-        else hipLaunchKernelGGL(k_dec_sample<false>, dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
+        if (trace) hipLaunchKernelGGL((k_dec_sample<true, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
+        else if (p.any_sampled) hipLaunchKernelGGL((k_dec_sample<false, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
+        else hipLaunchKernelGGL((k_dec_sample<false, false>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
     } else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
 }
 
