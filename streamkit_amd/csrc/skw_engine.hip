@@ -380,6 +380,7 @@ struct skw_ctx {
                                                                // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
     int prompt_pass_on = 1;                          // the prompt ([prev] + past text + sot / language / task) in one multi-row pass instead of one token per step; SKW_PROMPT_PASS=0 or skw_debug_set_prompt_pass(ctx, 0)
+    int* pf_meta = nullptr; int pf_nseq = 0, pf_nq_max = 0;      // the pass's sequences on the device: [row0 | nq | slot] x max_batch (the multi-query cross attention of the f16_mfma prompt pass)
     int rows_cap = 0; SkwSeqState* pf_st = nullptr;  // decode-step scratch rows (>= max_batch: the prompt pass runs one row per prompt token) and the prompt pass's per-token pseudo-states
     int ln_stats_on = 1;                             // LayerNorm folded into the decode GEMMs (f16_mfma); SKW_DEC_LN_STATS=0 or skw_debug_set_ln_stats(ctx, 0): LayerNorm kernels
     int live_rows_hint = -1;                         // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
@@ -430,7 +431,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
-      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); }
+      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     if (m->quant) {
@@ -775,6 +776,13 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
+            static const bool xp_mq = getenv("SKW_PROMPT_XATTN_MQ") ? atoi(getenv("SKW_PROMPT_XATTN_MQ")) != 0 : true;
+            if (prefill && xp_mq && c->precision == SKW_PRECISION_F16_MFMA && c->pf_nseq > 0) {
+                // the prompt pass in the tolerance precision: one read of a sequence's cross K / V^T for up to 128 of its prompt tokens (the encoder attention kernel with the
+                // prompt tokens as queries) instead of one per token — 4.6 MB per row per layer otherwise.  The exact precision keeps the single-query kernel: bit-identical to stepping.
+                ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * 64.0 * H, 4.0 * c->pf_nseq * (double)nc * dt);
+                skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s);
+            } else
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
@@ -1014,7 +1022,13 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
                 const size_t hi = row_end[jhi - 1]; const int n = (int)(hi - lo);
                 if (n > 0) {
                     HIPCHK(hipMemcpyAsync(c->pf_st, pf.data() + lo, sizeof(SkwSeqState) * n, hipMemcpyHostToDevice, c->stream));
+                    std::vector<int> meta((size_t)3 * c->max_batch, 0); int ns = 0, nqmax = 0;
+                    for (int j = jlo; j < jhi; ++j) { const int r0j = (j ? row_end[j - 1] : 0) - (int)lo, nqj = row_end[j] - (j ? row_end[j - 1] : 0); if (nqj <= 0) continue;
+                        meta[ns] = r0j; meta[c->max_batch + ns] = nqj; meta[2 * c->max_batch + ns] = j; nqmax = std::max(nqmax, nqj); ++ns; }
+                    HIPCHK(hipMemcpyAsync(c->pf_meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, c->stream));
+                    c->pf_nseq = ns; c->pf_nq_max = nqmax;
                     run_decoder_step(c, 0, n, 0, false, c->stream, true);
+                    c->pf_nseq = 0;
                     HIPCHK(hipStreamSynchronize(c->stream));      // (pf is a host vector and pf_st is reused by the next chunk)
                     ++prefill_passes;
                 }

@@ -60,6 +60,10 @@ bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);
 bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);  // A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b), statistics and normalisation inside the kernel from the rows it holds in registers; W in NATURAL k order
 bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);   // the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
+// cross attention of the prompt pass (f16_mfma): the encoder attention kernel with a sequence's prompt tokens as the queries — one read of the sequence's cross K / V^T per 128 of them.
+// q: [rows][d] f16 plain (scaled); sequence i: rows row0[i] .. + nq[i], cross K / V^T of window slot slot[i]; out: [rows][kperm(d)] f16
+void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
 

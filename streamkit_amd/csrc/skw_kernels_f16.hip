@@ -341,24 +341,33 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // S^T accumulators (MFMA row rho of a 16-key tile holds key 4 * (rho & 3) + (rho >> 2), which is the order the kperm'ed V^T rows
 // store their keys in).  Normalisation by the row sum happens once, on O.
 #define A16_QB 128
+// XP — the prompt pass's cross attention (skw_engine.hip, prefill): the same kernel with the queries of a SEQUENCE'S prompt tokens (rows row0 .. row0 + nq of the pass, plain
+// [row][d] f16 in natural k order, as the cross-query GEMM leaves them) against that sequence's cross K (plain rows [key][d], natural order: both operands of the score MFMA
+// then agree on which k sits in which slot) and V^T (already this kernel's layout).  One read of a sequence's K / V^T serves up to 128 of its prompt tokens instead of one.
+struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; };      // per sequence of the pass: first row, rows, window slot
+template <bool XP>
 __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks) {
+                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
     __shared__ __attribute__((aligned(1024))) char lds[2][2][64 * 128];   // [buffer][K | V^T][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = gridDim.x; int bid = blockIdx.x;
     { int q = nblk >> 3, r = nblk & 7, x = bid & 7, y = bid >> 3; bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y; }   // the query blocks of one (batch, head) share an XCD's L2
-    const long bh = bid / qblocks; const int qb = bid % qblocks;
+    long bh = bid / qblocks; const int qb = bid % qblocks;
     const int b = (int)(bh / H), h = (int)(bh % H);
+    int n_q = n_ctx; long qrow0 = 0;
+    if (XP) { n_q = xp.nq[b]; qrow0 = xp.row0[b]; if (qb * A16_QB >= n_q) return; bh = (long)xp.slot[b] * H + h; }      // (uniform per workgroup)
     const int q0 = qb * A16_QB + wave * 32;
     const int r16 = lane & 15, g = lane >> 4;
     f16x8 qf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        int qi = q0 + qt * 16 + r16; if (qi > n_ctx - 1) qi = n_ctx - 1;
-        const half_t* qp = Qh + (bh * Tpad + qi) * 64 + g * 8;
+        int qi = q0 + qt * 16 + r16; if (qi > n_q - 1) qi = n_q - 1;
+        const half_t* qp = XP ? Qh + (qrow0 + qi) * xp.ldq + h * 64 + g * 8 : Qh + (bh * Tpad + qi) * 64 + g * 8;
         qf[qt][0] = *(const f16x8*)qp; qf[qt][1] = *(const f16x8*)(qp + 32);
     }
-    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
+    const long krow = XP ? xp.ldk : 64;                                  // halves between consecutive keys of this head
+    __amdgpu_buffer_rsrc_t rk = XP ? __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long)xp.slot[b] * xp.k_seq_stride + h * 64), 0, (unsigned)((((long)n_ctx - 1) * krow + 64) * 2), 0x00020000)
+                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     // staging: chunk id c = tid + 256 i -> row c >> 3, 16-byte chunk c & 7
     // bank swizzles: a ds_read_b128 is served eight lanes at a time (8 x 16 B = the 32 banks), so eight lanes are conflict-free when their stored chunk
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         const int c = tid + 256 * i, row = c >> 3, pos = c & 7;
         st_lds[i] = (unsigned)(row * 128 + ((pos ^ (row & 7)) << 4));
         st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (((row & 1) << 2) | ((row >> 2) & 3))) << 4));
-        st_k[i] = (unsigned)((row * 64 + pos * 8) * 2);              // + kb * 64 rows; rows past Tpad fall outside the descriptor: zeros
+        st_k[i] = (unsigned)((row * krow + pos * 8) * 2);            // + kb * 64 rows; rows past Tpad (XP: past n_ctx) fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
         st_vkey[i] = pos * 8;
     }
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * 8192u, 0, 0);
+        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * (unsigned)(krow * 128), 0, 0);      // (keys past the end lie outside the descriptor: zeros, masked below)
     };
     auto load_v = [&](int kb) {
 #pragma unroll
@@ -466,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int qi = q0 + qt * 16 + r16;
-        if (qi < n_ctx) {
-            half_t* op = out + ((long)b * n_ctx + qi) * ld_out;
+        if (qi < n_q) {
+            half_t* op = XP ? out + (qrow0 + qi) * ld_out : out + ((long)b * n_ctx + qi) * ld_out;
             const float inv = qt ? inv1 : inv0;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
@@ -478,7 +487,14 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 }
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s) {
     const int qblocks = (n_ctx + A16_QB - 1) / A16_QB;
-    hipLaunchKernelGGL(k_attn_encoder16, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks);
+    hipLaunchKernelGGL(k_attn_encoder16<false>, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{});
+}
+// the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
+void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s) {
+    const int qblocks = (nq_max + A16_QB - 1) / A16_QB;
+    const SkwXPrefill xp{row0, nq, slot, (long)d, (long)n_ctx * d, (long)d};
+    hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp);
 }
 
 // what a wave does with a finished 16 x 16 tile: lane (r16, g) holds rows-of-W 4g .. 4g+3 (four adjacent outputs) of row m

@@ -11,9 +11,10 @@ import numpy as np
 
 # Logit units.  The synthetic models' logits span about +-500.  Measured under teacher forcing on the 64 x 30 s Whisper-small batch (6 473 decisions,
 # profiles/r03a): the deciding logits of the two precisions differ by at most 0.264 (5e-4 of the range: eleven f16 roundings per layer through 12 layers; 0.298 on the tiny model with temperature passes),
-# and the 21 decisions that differ all sit where the exact mode's own top1 - top2 margin is <= 0.099 and pick the exact mode's runner-up.  A flip needs
+# and the 21 - 23 decisions that differ all sit where the exact mode's own top1 - top2 margin is <= 0.099 and pick the exact mode's runner-up (multi-window tiny-model
+# batches whose prompt pass uses the multi-query cross attention: logit difference <= 0.33).  A flip needs
 # margin <= err(top1) + err(top2), so the margin bound is held below twice the measured logit error.
-LOGIT_ERR_BOUND = 0.35
+LOGIT_ERR_BOUND = 0.40
 MARGIN_BOUND = 0.5
 
 

@@ -388,8 +388,8 @@ def test_no_speech_middle_window_keeps_the_carried_prompt(eng, tiny_model_path):
 def test_prompt_in_one_pass_equals_one_token_per_step(eng, tiny_model_path, precision):
     """The prompt of a window ([prev] + up to 224 tokens of the clip's earlier text + sot / language / task) as ONE multi-row decoder pass, the way
     whisper.cpp evaluates it in one whisper_decode call, against feeding it a token per step: the same kernels run a row per (sequence, position), and a
-    row's arithmetic does not depend on its batch mates, so tokens, log-probs and timestamps are identical bit for bit in both precisions — and the number of
-    decoder passes of a multi-window batch drops by the prompt lengths.  (Every other multi-window test in this file runs the one-pass form against the oracle.)"""
+    row's arithmetic does not depend on its batch mates, so tokens, log-probs and timestamps are identical bit for bit in the exact precision (f16_mfma's pass uses a
+    multi-query cross attention and is held to the teacher-forced bound instead) — and the number of decoder passes of a multi-window batch drops by the prompt lengths.  (Every other multi-window test in this file runs the one-pass form against the oracle.)"""
     import ctypes as C
     L = eng.lib(); L.skw_debug_set_prompt_pass.argtypes = [C.c_void_p, C.c_int]
     m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=6, max_samples=16000 * 95)
@@ -401,9 +401,24 @@ def test_prompt_in_one_pass_equals_one_token_per_step(eng, tiny_model_path, prec
         L.skw_debug_set_prompt_pass(ctx.h, on)
         res = ctx.full_batch(pcms)
         out[on] = (res, ctx.timing())
+    n_same = 0
     for (c, n), a, b in zip(clips, out[0][0], out[1][0]):
-        assert a["tokens"] == b["tokens"] and [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]], (c, n)
-        assert a["n_windows"] == b["n_windows"] and a["n_decode_steps"] == b["n_decode_steps"]       # (whisper.cpp's own count: one decode call for the prompt either way)
+        same = a["tokens"] == b["tokens"] and [(s["t0"], s["t1"], s["text"]) for s in a["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in b["segments"]]
+        n_same += same
+        if precision == "exact":
+            assert same, (c, n)
+            assert a["n_windows"] == b["n_windows"] and a["n_decode_steps"] == b["n_decode_steps"]   # (whisper.cpp's own count: one decode call for the prompt either way)
+    if precision == "f16_mfma":
+        # the tolerance precision's prompt pass reads a sequence's cross K / V^T once for all of its prompt tokens (multi-query attention on the matrix cores), so
+        # its bits are not the stepped form's; what it is held to is what the precision is held to everywhere: every decision, under teacher forcing, against the exact precision
+        from streamkit_amd.parity import teacher_forced_compare
+        L.skw_debug_set_prompt_pass(ctx.h, 1)
+        r = teacher_forced_compare(ctx, pcms)
+        print("prompt pass (f16_mfma): %d decisions under teacher forcing, %d differ, max margin there %s, max logit error %.3g; %d of %d clips identical to the stepped form"
+              % (r["steps_checked"], r["argmax_disagreements"], r["max_margin_at_disagreement"], r["max_logit_err"], n_same, len(clips)))
+        assert r["ok"], (r["max_logit_err"], r["max_margin_at_disagreement"])
+        # (free-running, a multi-window clip's later windows are prompted with its own earlier text, so one near-tie early in a clip changes everything after it:
+        #  how many clips stay identical to the stepped form is reported, not required)
     stepped, one_pass = out[0][1]["n_decode_steps"], out[1][1]["n_decode_steps"]
     print("prompt pass (%s): %d decoder passes for the batch with the prompt in one pass, %d with one prompt token per step; decode %.1f ms vs %.1f ms"
           % (precision, one_pass, stepped, out[1][1]["decode_ms"], out[0][1]["decode_ms"]))
