@@ -750,8 +750,16 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     // registers and normalises on the way into the MFMA.  35 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
     const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
     auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
+    // the prompt pass of a long-form batch is thousands of rows: there the projections are the encoder's big-tile GEMM (f16_mfma; the small-M kernels stream the
+    // weights once per 16 rows and reach ~50 TF/s at M = 4096, the big kernel 600).  The QKV product keeps the decode form: its epilogue appends to the K / V caches.
+    const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !getenv("SKW_PROMPT_SMALL_GEMM");
+    auto gemm_s = [&](const SkwGemmArgs& a) { if (bigM) GEMM(c, a, a.K); else GEMM_S(c, a, a.K); };
     // a GEMM fed by LayerNorm(dx): the normalising form (site >= 0), else LayerNorm kernel + GEMM
     auto gemm_ln = [&](SkwGemmArgs a, const DevLin& Lw, const DevLN& ln, int site, bool normalised) {
+        if (bigM && a.epi != EPI_DEC_QKV && !normalised) {
+            { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * a.M * a.K); skw_layernorm(dx, a.M, a.K, ln.w, ln.b, dy16, nullptr, s); }
+            GEMM(c, a, a.K); return;
+        }
         if (lnA && site >= 0) {
             a.W = Lw.w_nat; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b;
             ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
@@ -769,7 +777,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); gemm_s(a); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
         if (!tail && !lnA && !prefill && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
@@ -785,11 +793,11 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             } else
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp); }
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); GEMM_S(c, a, a.K); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); gemm_s(a); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
         { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;
           if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
-          GEMM_S(c, a, a.K); }
+          gemm_s(a); }
     }
     if (want_logits) {
         if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }      // (the vocabulary kernel's 256 workgroups would each normalise all 64 rows: measured +6.4 us against this 5.0 us launch)

@@ -1377,27 +1377,29 @@ __device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg,
 // cp_i >= u — and the two sums stay one lane's k-ascending chains (their roundings ARE the definition).  But one lane fetching 51 865 floats from memory one at
 // a time and dividing each by the sum inside the chain made a sampled step 5.8 ms (a long-form batch with temperature fall-backs: 4.5 s of a 6.4 s call).  Here
 // the workgroup stages the row through LDS (64 KB at a time), the divisions — independent — are done by all threads, and the second chain stops at the hit.
-// Same bits as discrete_draw (oracle/skw_oracle.c), ~0.5 ms.  lds: 8 192 floats (static LDS stays under 64 KB).
+// Same bits as discrete_draw (oracle/skw_oracle.c).  lds: 8 192 floats = 4 096 doubles (static LDS stays under 64 KB).
 // S + p == S under round-to-nearest whenever 0 <= p < ulp(S) / 2: a 64-element block whose largest element is below that bound cannot move the running sum,
 // whatever the order inside it, and since the sum never decreases it stays immovable — such blocks are skipped WITHOUT changing a bit of the sequential result.
 // (Peaked distributions — most real steps — leave a few dozen elements in the chain; a flat one keeps all 51 865.)
 __device__ __forceinline__ double half_ulp_f64(double s) { const int e = (int)((__double_as_longlong(s) >> 52) & 0x7ff); return e == 0 ? 0.0 : __longlong_as_double((long long)max(e - 53, 1) << 52); }   // 2^(exponent(s) - 53); 0 for s == 0 / subnormal: nothing is skipped then
 __device__ int block_discrete_draw(const float* probs, double* q, int n, uint32_t* mt, float* lds, double* s_sum, int* s_hit) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ double bmax[128];                                 // per 64-element block of the staged chunk
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ double bmax[64];                                  // per 64-element block of the staged chunk
+    double* ldsd = (double*)lds;                                 // the chunk as doubles: 4 096 per stage (the serial lane then issues one LDS read and two adds per two elements)
     double sum = 0.0;
-    for (int c0 = 0; c0 < n; c0 += 8192) {
-        const int m = min(8192, n - c0);
-        for (int i = tid; i < m; i += nt) lds[i] = probs[c0 + i];
+    for (int c0 = 0; c0 < n; c0 += 4096) {
+        const int m = min(4096, n - c0);
+        for (int i = tid; i < m; i += nt) ldsd[i] = (double)probs[c0 + i];
         __syncthreads();
-        if (tid < 128) { float mx = 0.0f; for (int i = tid * 64; i < min(tid * 64 + 64, m); ++i) mx = fmaxf(mx, lds[i]); bmax[tid] = (double)mx; }
+        if (tid < 64) { double mx = 0.0; for (int i = tid * 64; i < min(tid * 64 + 64, m); ++i) mx = fmax(mx, ldsd[i]); bmax[tid] = mx; }
         __syncthreads();
         if (tid == 0) {
             for (int b0 = 0; b0 < m; b0 += 64) {
                 if (bmax[b0 >> 6] < half_ulp_f64(sum)) continue;
                 const int e = min(b0 + 64, m); int i = b0;
-                for (; i + 4 <= e; i += 4) { const f32x4 v = *(const f32x4*)(lds + i); sum += (double)v[0]; sum += (double)v[1]; sum += (double)v[2]; sum += (double)v[3]; }
-                for (; i < e; ++i) sum += (double)lds[i];
+                for (; i + 2 <= e; i += 2) { const f64x2 v = *(const f64x2*)(ldsd + i); sum += v[0]; sum += v[1]; }
+                for (; i < e; ++i) sum += ldsd[i];
             }
         }
         __syncthreads();
@@ -1413,7 +1415,7 @@ __device__ int block_discrete_draw(const float* probs, double* q, int n, uint32_
     for (int i = tid; i < n; i += nt) q[i] = (double)probs[i] / sum;
     __threadfence_block();
     __syncthreads();
-    double* ldsd = (double*)lds; double cp = 0.0;
+    double cp = 0.0;
     for (int c0 = 0; c0 < n; c0 += 4096) {
         const int m = min(4096, n - c0);
         for (int i = tid; i < m; i += nt) ldsd[i] = q[c0 + i];
@@ -1423,8 +1425,14 @@ __device__ int block_discrete_draw(const float* probs, double* q, int n, uint32_
         if (tid == 0) {
             int hit = -1;
             for (int b0 = 0; b0 < m && hit < 0; b0 += 64) {
-                const int e = min(b0 + 64, m);
-                if (c0 + e != n && bmax[b0 >> 6] < half_ulp_f64(cp)) continue;      // (the block that holds the last element is walked: cp = 1 there by definition)
+                const int e = min(b0 + 64, m); const bool last_block = c0 + e == n;
+                if (!last_block && bmax[b0 >> 6] < half_ulp_f64(cp)) continue;      // (the block that holds the last element is walked: cp = 1 there by definition)
+                if (!last_block) {      // cp never decreases: a block whose END is still below u holds no hit — one compare per block instead of one per element
+                    double c2 = cp; int i = b0;
+                    for (; i + 2 <= e; i += 2) { const f64x2 v = *(const f64x2*)(ldsd + i); c2 += v[0]; c2 += v[1]; }
+                    for (; i < e; ++i) c2 += ldsd[i];
+                    if (c2 < u) { cp = c2; continue; }
+                }
                 for (int i = b0; i < e; ++i) { cp += ldsd[i]; if (c0 + i == n - 1) cp = 1.0; if (!(cp < u)) { hit = c0 + i; break; } }
             }
             *s_hit = hit;
