@@ -296,6 +296,7 @@ def main():
                                        "frac": round(full_bytes / us.value / 1e3 / HBM_PEAK_GBS, 4)}
             roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * 4.0 * B * hp.n_audio_ctx * hp.n_text_state), 4)
             roof["booking"] = "algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state per launch (K and V^T, f16), live rows counted per step on the host"
+            roof["timing"] = "per launch, HIP events stamped at the kernel's own begin and end (hipExtLaunchKernelGGL) on the engine's stream: the duration rocprofv3 reports for the same kernel"
         # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times
         nwin, nsteps, nrow = timing["n_windows"], timing["n_decode_steps"], timing["n_row_steps"]
         d, dt_, nc, L = hp.n_audio_state, hp.n_text_state, hp.n_audio_ctx, hp.n_text_layer

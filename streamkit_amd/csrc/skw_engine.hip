@@ -500,24 +500,27 @@ struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
 struct ProfState { bool on = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t next = 0; double ms[PC_COUNT] = {}, flops[PC_COUNT] = {}, bytes[PC_COUNT] = {}; long count[PC_COUNT] = {}; };
 static void prof_free(skw_ctx* c) { if (!c->prof) return; for (hipEvent_t e : c->prof->pool) hipEventDestroy(e); delete c->prof; c->prof = nullptr; }
 struct ProfScope {
-    ProfState* ps; skw_ctx* c; size_t idx;
-    ProfScope(skw_ctx* c_, int cls, double flops, double bytes);
+    ProfState* ps; skw_ctx* c; size_t idx; bool ext;      // ext: the launch stamps the two events itself (hipExtLaunchKernelGGL: kernel begin / end, what rocprofv3 calls the duration)
+    ProfScope(skw_ctx* c_, int cls, double flops, double bytes, bool ext_ = false);
     ~ProfScope();
+    hipEvent_t ev_a() const; hipEvent_t ev_b() const;
 };
 
 // ------------------------------------------------------------------ GEMM helpers
-ProfScope::ProfScope(skw_ctx* c_, int cls, double flops, double bytes) : ps(nullptr), c(c_), idx(0) {
+ProfScope::ProfScope(skw_ctx* c_, int cls, double flops, double bytes, bool ext_) : ps(nullptr), c(c_), idx(0), ext(ext_) {
     if (!c_->prof || !c_->prof->on) return;
     ps = c_->prof;
     auto get = [&]() { if (ps->next == ps->pool.size()) { hipEvent_t e; hipEventCreate(&e); ps->pool.push_back(e); } return ps->pool[ps->next++]; };
     ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get(); idx = ps->recs.size(); ps->recs.push_back(r);
-    hipEventRecord(r.a, c->cur);
+    if (!ext) hipEventRecord(r.a, c->cur);
 }
-ProfScope::~ProfScope() { if (ps) hipEventRecord(ps->recs[idx].b, c->cur); }
+ProfScope::~ProfScope() { if (ps && !ext) hipEventRecord(ps->recs[idx].b, c->cur); }
+hipEvent_t ProfScope::ev_a() const { return (ps && ext) ? ps->recs[idx].a : nullptr; }
+hipEvent_t ProfScope::ev_b() const { return (ps && ext) ? ps->recs[idx].b : nullptr; }
 static void prof_collect(skw_ctx* c) {
     if (!c->prof || !c->prof->on) return; ProfState& ps = *c->prof;
     hipStreamSynchronize(c->stream);
-    for (auto& r : ps.recs) { float ms = 0; hipEventElapsedTime(&ms, r.a, r.b); ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
+    for (auto& r : ps.recs) { float ms = 0; if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue; ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
     ps.recs.clear(); ps.next = 0;
 }
 extern "C" void skw_ctx_profile(skw_ctx* c, int on) { if (!c->prof) c->prof = new ProfState(); ProfState& ps = *c->prof; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0; ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
@@ -791,7 +794,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
                 ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * 64.0 * H, 4.0 * c->pf_nseq * (double)nc * dt);
                 skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s);
             } else
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b()); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); gemm_s(a); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
@@ -1312,10 +1315,23 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     const int pv16 = c->precision == SKW_PRECISION_F16_MFMA;
     for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
-    HIPCHK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
-    HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_per_launch = 1000.0f * ms / iters;
+    // every launch stamped at its own begin and end (hipExtLaunchKernelGGL): the kernel's duration as rocprofv3 reports it, without the dispatch gap between launches.
+    // SKW_XATTN_PROBE_WALL=1: one event pair around the whole run instead (launch-to-launch time, what round 2's figures were)
+    float ms = 0;
+    if (getenv("SKW_XATTN_PROBE_WALL")) {
+        HIPCHK(hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
+        HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+        hipEventElapsedTime(&ms, e0, e1);
+    } else {
+        std::vector<hipEvent_t> ev(2 * (size_t)iters);
+        for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+        for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16, nullptr, ev[2 * i], ev[2 * i + 1]);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < iters; ++i) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) ms += t; }
+        for (auto& e : ev) hipEventDestroy(e);
+    }
+    *us_per_launch = 1000.0f * ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(K); hipFree(V); hipFree(q); hipFree(out);
     return 0;
 }

@@ -105,7 +105,8 @@ void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, cons
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr);
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // events: stamped at the kernel's own begin / end (the engine's per-kernel profile)
 // the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
 bool skw_dec_cross_attn_vt_q_ok(int H, int d);
 bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
