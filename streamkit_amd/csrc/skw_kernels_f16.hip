@@ -167,12 +167,21 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     };
     auto stage = [&](int buf, int kb) {
         char* base = lds + buf * (BM + BN) * 128;
+        // (a.probe bits 5 / 6, measurement only: the non-temporal policy on the A / W stream)
+        if (a.probe & 32) {
 #pragma unroll
-        for (int i = 0; i < A_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 0);
+            for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 2);
+        } else {
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 0);
+            for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 0);
+        }
+        if (a.probe & 64) {
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 0);
+        }
     };
     // fragment read offsets inside a buffer: row * 128 + ((chunk ^ (row & 7)) << 4), chunk = 4 * khalf + g; row & 7 == r16 & 7
     const int fo0 = ((g ^ (r16 & 7)) << 4), fo1 = fo0 ^ 64;
