@@ -18,9 +18,10 @@ LOGIT_ERR_BOUND = 0.40
 MARGIN_BOUND = 0.5
 
 
-def teacher_forced_compare(ctx, clips=None, params=None, device_ptrs=None, n_samples=None):
+def teacher_forced_compare(ctx, clips=None, params=None, device_ptrs=None, n_samples=None, logit_err_bound=LOGIT_ERR_BOUND, margin_bound=MARGIN_BOUND):
     """Runs the batch in the exact precision (free, traced), then in f16_mfma fed with the exact run's decisions.  Returns a dict of counts and
-    the two result lists; leaves the context in the precision it was in."""
+    the two result lists; leaves the context in the precision it was in.  The bounds are in logit units and belong to a model's logit scale (the
+    defaults: the benchmark's synthetic models, +-500); a model with another scale passes its own (tests/test_gpu_f16.py: 7e-4 of the range)."""
     was = ctx.get_precision()
     kw = dict(device_ptrs=device_ptrs, n_samples=n_samples)
     ctx.set_precision("exact")
@@ -59,6 +60,6 @@ def teacher_forced_compare(ctx, clips=None, params=None, device_ptrs=None, n_sam
         per_clip.append(dict(steps=len(a), disagreements=len(diff), max_logit_err=e, margins=[round(float(x), 5) for x in m]))
     return dict(steps_checked=steps, sampled_steps=n_sampled, sampled_draws_that_differ=draws_differ, argmax_disagreements=disagree, disagreements_on_exact_runner_up=runner_up,
                 max_margin_at_disagreement=worst_margin if disagree else None, max_logit_err=worst_err,
-                logit_err_bound=LOGIT_ERR_BOUND, margin_bound=MARGIN_BOUND,
-                ok=bool(worst_err <= LOGIT_ERR_BOUND and (not disagree or worst_margin < MARGIN_BOUND)),
+                logit_err_bound=logit_err_bound, margin_bound=margin_bound,
+                ok=bool(worst_err <= logit_err_bound and (not disagree or worst_margin < margin_bound)),
                 per_clip=per_clip, results_exact=res_e, results_forced=res_f, traces_exact=tr_e, traces_forced=tr_f)

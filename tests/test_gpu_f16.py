@@ -267,3 +267,34 @@ def test_layernorm_folded_into_the_decode_gemms(eng, tiny_model_path, small_mode
             _report("%s, LayerNorm %s" % (os.path.basename(path), "folded" if on else "launched"), r)
             assert r["ok"], (on, r["max_logit_err"], r["max_margin_at_disagreement"])
         ctx.close(); m.close()
+
+
+@pytest.mark.parametrize("size", ["w512", "w1024", "w1280"])
+def test_f16_mfma_other_widths(eng, size):
+    """One-layer models of Whisper's other widths in f16_mfma: the kernels whose shape depends on d — the LayerNorm-folding decode GEMMs (K / 128 = 4, 8, 10 k-blocks per
+    wave: the 6- and 12-block register forms), the prompt pass, the vocabulary kernel's ring depth — within the precision's logit tolerance of the oracle and through the
+    teacher-forced check."""
+    import ctypes as C
+    from conftest import synth_model
+    path = synth_model(size)
+    m = eng.Model(path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path)
+    ctx.set_precision("f16_mfma")
+    pcm = synth.clip(5, 16000 * 9)
+    mel_o, _ = om.log_mel(pcm)
+    _, ck, cv = om.encode(mel_o)
+    ctx.encode(pcm)
+    toks = [50258, 50259, 50359, 50364, 1234, 777]
+    lo = om.decoder(ck, cv).step(toks, 0); lg = ctx.decode_logits(toks)
+    err = float(np.abs(lg - lo).max())
+    print("f16_mfma %s: max abs logit error %.3g on a range of %.3g" % (size, err, float(lo.max() - lo.min())))
+    rng = float(lo.max() - lo.min())
+    assert err < TOL_LOGIT_REL * rng
+    # these one-layer models' logits span 2 - 3 times the benchmark model's range: the bounds scale with it (the error is relative: eleven f16 roundings per layer)
+    eb = max(LOGIT_ERR_BOUND, 7e-4 * rng)
+    L = eng.lib(); L.skw_debug_set_ln_stats.argtypes = [C.c_void_p, C.c_int]
+    for on in (1, 0):
+        L.skw_debug_set_ln_stats(ctx.h, on)
+        r = teacher_forced_compare(ctx, [pcm, synth.clip(6, 16000 * 4), synth.clip(7, 16000 * 11)], logit_err_bound=eb, margin_bound=2 * eb)
+        print("  LayerNorm %s: %d decisions, %d differ, max logit error %.3g (bound %.3g)" % ("folded" if on else "launched", r["steps_checked"], r["argmax_disagreements"], r["max_logit_err"], eb))
+        assert r["ok"] and r["steps_checked"] > 20, (size, on, r["max_logit_err"], r["max_margin_at_disagreement"])
+    ctx.close(); m.close()

@@ -425,3 +425,26 @@ def test_prompt_in_one_pass_equals_one_token_per_step(eng, tiny_model_path, prec
     assert any(r["n_windows"] >= 3 for r in out[1][0])                                              # later windows carry their clip's earlier text
     assert one_pass < stepped - 40, (one_pass, stepped)
     ctx.close(); m.close()
+
+
+def test_prompt_pass_in_chunks_and_for_a_single_row(eng, tiny_model_path):
+    """The prompt pass where its bookkeeping is exercised: (i) more prompt rows than the pass's scratch holds (24 multi-window clips: later windows carry ~225-token prompts,
+    24 x 225 > 4096 rows), so the pass runs in chunks of whole sequences; (ii) a context of one row (scratch for exactly one prompt).  Exact precision: identical to
+    one prompt token per step, bit for bit."""
+    import ctypes as C
+    L = eng.lib(); L.skw_debug_set_prompt_pass.argtypes = [C.c_void_p, C.c_int]
+    m = eng.Model(tiny_model_path)
+    for B, secs in ((24, 70), (1, 95)):
+        ctx = eng.Context(m, max_batch=B, max_samples=16000 * secs + 16)
+        pcms = [synth.clip(300 + c, 16000 * secs - 37 * c) for c in range(B)]
+        out = {}
+        for on in (0, 1):
+            L.skw_debug_set_prompt_pass(ctx.h, on)
+            out[on] = (ctx.full_batch(pcms), ctx.timing())
+        for c, (a, b) in enumerate(zip(out[0][0], out[1][0])):
+            assert a["tokens"] == b["tokens"] and a["n_windows"] == b["n_windows"] and a["fallback_requested"] == b["fallback_requested"], (B, c)
+        assert max(r["n_windows"] for r in out[1][0]) >= 3
+        assert out[1][1]["n_decode_steps"] < out[0][1]["n_decode_steps"]
+        print("prompt pass, %d clip(s) of %d s: %d decoder passes against %d stepped" % (B, secs, out[1][1]["n_decode_steps"], out[0][1]["n_decode_steps"]))
+        ctx.close()
+    m.close()
