@@ -352,6 +352,9 @@ extern "C" void skw_full_default_params(skw_full_params* p) {
 struct ProfState;
 struct skw_ctx {
     int precision = SKW_PRECISION_EXACT;             // SKW_PRECISION_*: which form of the contractions runs (skw_ctx_set_precision)
+    int kv_frag_on = 1;                              // f16_mfma: cross K / V^T as fragment-order images (skw_kernels.h, skw_kfrag_off); SKW_XATTN_FRAG=0 keeps the row layouts
+    bool kv_frag() const { return kv_frag_on && precision == SKW_PRECISION_F16_MFMA; }
+    size_t kclip() const { return (size_t)(kv_frag() ? Tpad : m->hp.n_audio_ctx) * m->hp.n_text_state; }      // cross-K elements per window slot (the buffer is sized for the larger: Tpad rows)
     ProfState* prof = nullptr;                       // per-kernel-class event timing (skw_ctx_profile); per context: contexts run on different host threads
     skw_model* m = nullptr; int max_batch = 0, max_samples = 0, n_len_max = 0, Tpad = 0;
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
@@ -409,6 +412,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     c->n_len_max = (max_samples + WHISPER_SAMPLE_RATE * 30 + 2 * (WHISPER_N_FFT / 2) - WHISPER_N_FFT) / WHISPER_HOP + 1;
     const skw_hparams& hp = m->hp; const int B = max_batch, nc = hp.n_audio_ctx, T = 2 * nc, d = hp.n_audio_state, dt = hp.n_text_state;
     c->Tpad = (nc + 31) & ~31;
+    if (getenv("SKW_XATTN_FRAG")) c->kv_frag_on = atoi(getenv("SKW_XATTN_FRAG")) != 0;
     bool ok = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     c->cur = c->stream;
@@ -429,7 +433,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
-    WS(crossK, half_t, (size_t)hp.n_text_layer * B * nc * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
+    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
       WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
@@ -468,6 +472,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
 
 // ------------------------------------------------------------------ debug taps (encoder layer 0, natural layouts; enabled by skw_debug_enable)
 static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on = false;
+extern "C" void skw_debug_set_kv_frag(skw_ctx* c, int on) { c->kv_frag_on = on != 0; }                // tests: f16_mfma cross K / V^T as fragment-order images (one-pass cross attention) / as rows (two-phase kernel); takes effect at the next encoder pass
 extern "C" void skw_debug_set_prompt_pass(skw_ctx* c, int on) { c->prompt_pass_on = on != 0; }     // tests: the prompt as one pass / one token per step
 extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)
 extern "C" void skw_debug_enable(int on) { g_taps_on = on != 0; g_taps.clear(); }
@@ -608,7 +613,7 @@ static void run_conv(skw_ctx* c, int Bw_all, int row0 = 0) {
 // encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
 static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, int row0 = 0) {
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int nc = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head; const int Bw = Bw_all - row0, M = Bw * nc;
-    const size_t xk0 = (size_t)row0 * nc * hp.n_text_state, xv0 = (size_t)row0 * hp.n_text_head * 64 * c->Tpad;      // cross K / V of the computed windows land in slots row0 ..
+    const size_t xk0 = (size_t)row0 * c->kclip(), xv0 = (size_t)row0 * hp.n_text_head * 64 * c->Tpad;      // cross K / V of the computed windows land in slots row0 ..
     if (use_q8(c)) {
         // Quantised file, exact precision: every weight product is ggml's (rows -> q8 blocks, integer block dots), so what feeds a
         // projection stays f32 and unrounded — LayerNorm, attention and GELU write f32 here — and only the attention operands
@@ -635,7 +640,7 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
             Q8_ROWS(c, c->encq32, d, M, d, 0);
             for (int l = 0; l < hp.n_text_layer; ++l) {
                 const DecLayer& L = m->dec[l];
-                half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
+                half_t* ck = c->crossK + (size_t)l * c->max_batch * c->kclip() + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
                 { SkwGemmArgs a = q8_args(M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; Q8_GEMM(c, a, L.ck, 0); }
                 { SkwGemmArgs a = q8_args(M, cv, 0, EPI_VT_F16); a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; Q8_GEMM(c, a, L.cv, 0); }
             }
@@ -679,11 +684,11 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
         const int dt = hp.n_text_state; const float Kscale = (float)pow((double)((float)dt / hp.n_text_head), -0.25);
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
-            half_t* ck = c->crossK + (size_t)l * c->max_batch * nc * dt + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
-            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; GEMM(c, a, d); }
+            half_t* ck = c->crossK + (size_t)l * c->max_batch * c->kclip() + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; if (c->kv_frag()) { a.frag = 1; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; } GEMM(c, a, d); }
             { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
                 SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv; a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
-                if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; }
+                if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; a.frag = c->kv_frag(); }
                 GEMM(c, a, d);
             }
         }
@@ -718,7 +723,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
             half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
-            half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
+            half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
             Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
             { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
@@ -776,14 +781,14 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     for (int l = 0; l < hp.n_text_layer; ++l) {
         const DecLayer& L = m->dec[l];
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
-        half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * nc * dt; half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
+        half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); gemm_s(a); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
-        if (!tail && !lnA && !prefill && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
+        if (!tail && !lnA && !prefill && !c->kv_frag() && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
@@ -792,9 +797,9 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
                 // the prompt pass in the tolerance precision: one read of a sequence's cross K / V^T for up to 128 of its prompt tokens (the encoder attention kernel with the
                 // prompt tokens as queries) instead of one per token — 4.6 MB per row per layer otherwise.  The exact precision keeps the single-query kernel: bit-identical to stepping.
                 ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * 64.0 * H, 4.0 * c->pf_nseq * (double)nc * dt);
-                skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s);
+                skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s, c->kv_frag());
             } else
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b()); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b()); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); gemm_s(a); }
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
@@ -887,10 +892,10 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
     char* errbuf = c->errbuf; const skw_hparams& hp = c->m->hp; const int R = (int)old_slots.size(), L = hp.n_text_layer;
     bool same = true; for (int k = 0; k < R; ++k) same = same && old_slots[k] == k;
     if (same) return 0;
-    const long ke = (long)hp.n_audio_ctx * hp.n_text_state, ve = (long)hp.n_text_head * 64 * c->Tpad;
+    const long ke = (long)c->kclip(), ka = (long)c->Tpad * hp.n_text_state, ve = (long)hp.n_text_head * 64 * c->Tpad;      // ka: the staging buffer is sized like crossK (Tpad rows per slot)
     if (!c->stageK || !c->stageV || !c->slot_map) {      // all three or none: a partial failure must not leave a later retry launching k_slot_copy on a null buffer
         half_t *sk = nullptr, *sv = nullptr; int* sm = nullptr;
-        if (hipMalloc((void**)&sk, (size_t)L * c->max_batch * ke * 2) != hipSuccess || hipMalloc((void**)&sv, (size_t)L * c->max_batch * ve * 2) != hipSuccess || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
+        if (hipMalloc((void**)&sk, (size_t)L * c->max_batch * ka * 2) != hipSuccess || hipMalloc((void**)&sv, (size_t)L * c->max_batch * ve * 2) != hipSuccess || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
             hipFree(sk); hipFree(sv); hipFree(sm); snprintf(errbuf, 512, "temperature retry: staging buffers for the cross K/V move could not be allocated"); return -1;
         }
         hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); c->stageK = sk; c->stageV = sv; c->slot_map = sm;
@@ -1223,6 +1228,9 @@ extern "C" int skw_conv_stem(skw_ctx* c, const float* pcm_host, int n_samples, i
 }
 // cross V^T [(h*64 + c)][Tpad kperm] of batch slot 0 -> natural [key][d] f32
 __global__ void k_vt2f_copy(const half_t* src, float* dst, int nc, int dt, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[(long)n * Tpad + skw_kperm(key)]; }
+// the same exports from the fragment-order images
+__global__ void k_kfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[skw_kfrag_off(0, H, Tpad, key, n & ~7) + (n & 7)]; }
+__global__ void k_vtfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); const int p = skw_kperm(key); dst[i] = (float)src[skw_vtfrag_off(0, H, Tpad, n, p & ~7) + (p & 7)]; }
 __global__ void k_h2f_copy(const half_t* src, float* dst, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = (float)src[i]; }
 extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int seek, float* enc_out, float* cross_k, float* cross_v) {
     char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
@@ -1232,8 +1240,11 @@ extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int 
     if (cross_k && cross_v) {
         const long n = (long)nc * dt; float* tmp = nullptr; HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
         for (int l = 0; l < hp.n_text_layer; ++l) for (int kv = 0; kv < 2; ++kv) {
-            if (kv) hipLaunchKernelGGL(k_vt2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad, tmp, nc, dt, c->Tpad);
-            else hipLaunchKernelGGL(k_h2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->crossK + (size_t)l * c->max_batch * nc * dt, tmp, n);
+            const half_t* vsrc = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad; const half_t* ksrc = c->crossK + (size_t)l * c->max_batch * c->kclip();
+            if (kv && c->kv_frag()) hipLaunchKernelGGL(k_vtfrag2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, vsrc, tmp, nc, dt, hp.n_text_head, c->Tpad);
+            else if (kv) hipLaunchKernelGGL(k_vt2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, vsrc, tmp, nc, dt, c->Tpad);
+            else if (c->kv_frag()) hipLaunchKernelGGL(k_kfrag2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ksrc, tmp, nc, dt, hp.n_text_head, c->Tpad);
+            else hipLaunchKernelGGL(k_h2f_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ksrc, tmp, n);
             HIPCHK(hipMemcpyAsync((kv ? cross_v : cross_k) + (size_t)l * n, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
         }
         hipFree(tmp);
@@ -1306,14 +1317,14 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
 extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int iters, float* us_per_launch) {
     char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
     const skw_hparams& hp = c->m->hp; const int d = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, Tpad = c->Tpad;
-    const size_t kn = (size_t)B * nc * d, vn = (size_t)B * H * 64 * Tpad;
+    const size_t kn = (size_t)B * Tpad * d, vn = (size_t)B * H * 64 * Tpad;
     half_t *K = nullptr, *V = nullptr, *q = nullptr, *out = nullptr;
     HIPCHK(hipMalloc((void**)&K, kn * 2 * layers)); HIPCHK(hipMalloc((void**)&V, vn * 2 * layers)); HIPCHK(hipMalloc((void**)&q, (size_t)B * d * 2)); HIPCHK(hipMalloc((void**)&out, (size_t)B * d * 4));
     { std::vector<uint16_t> h(std::max(kn, vn)); uint32_t x = 777; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16((((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.25f); }
       for (int l = 0; l < layers; ++l) { HIPCHK(hipMemcpy(K + kn * l, h.data(), kn * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(V + vn * l, h.data(), vn * 2, hipMemcpyHostToDevice)); }
       HIPCHK(hipMemcpy(q, h.data(), (size_t)B * d * 2, hipMemcpyHostToDevice)); }
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    const int pv16 = c->precision == SKW_PRECISION_F16_MFMA;
+    const int pv16 = c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA;       // (timing only: the images are random bytes in either layout; Tpad * d elements per slot are allocated below)
     for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
     // every launch stamped at its own begin and end (hipExtLaunchKernelGGL): the kernel's duration as rocprofv3 reports it, without the dispatch gap between launches.
     // SKW_XATTN_PROBE_WALL=1: one event pair around the whole run instead (launch-to-launch time, what round 2's figures were)
@@ -1326,7 +1337,13 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
     } else {
         std::vector<hipEvent_t> ev(2 * (size_t)iters);
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-        for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16, nullptr, ev[2 * i], ev[2 * i + 1]);
+        // SKW_XATTN_PROBE_TOUCH_K / _V = megabytes of the launch's K / V^T image read (and discarded) by k_touch in front of it, untimed: what the launch gains from bytes waiting in the Infinity Cache
+        const size_t tk = getenv("SKW_XATTN_PROBE_TOUCH_K") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_K")) * 1000000 : 0, tv = getenv("SKW_XATTN_PROBE_TOUCH_V") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_V")) * 1000000 : 0;
+        for (int i = 0; i < iters; ++i) {
+            if (tk) skw_touch(K + kn * (i % layers), std::min(tk, kn * 2) & ~(size_t)15, 256, nullptr, c->stream);
+            if (tv) skw_touch(V + vn * (i % layers), std::min(tv, vn * 2) & ~(size_t)15, 256, nullptr, c->stream);
+            skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16, nullptr, ev[2 * i], ev[2 * i + 1]);
+        }
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < iters; ++i) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) ms += t; }
         for (auto& e : ev) hipEventDestroy(e);

@@ -15,6 +15,20 @@ typedef _Float16 half_t;
 // position (in memory) of logical contraction index k: within each aligned block of 32,
 // the 8 values with k % 4 == q are contiguous at [8q, 8q+8).
 __host__ __device__ __forceinline__ int skw_kperm(int k) { return (k & ~31) | ((k & 3) << 3) | ((k >> 2) & 7); }
+// Fragment-order cross K / V^T (f16_mfma precision).  The decode step's cross attention streams 295 MB per launch; read as rows, one wave-instruction fetches 16 rows x 64 B
+// (an MFMA operand tile) — twice the requests per byte of a full-line stream.  Stored in the order the matrix core takes them, every load instruction is one contiguous KiB:
+//   K    per (slot, head): Tpad / 16 key tiles x 2 KiB = [d half kk][lane i + 16 g][8 halves]: lane row i holds key 16 T + 4 (i & 3) + (i >> 2) (so that the score MFMA's
+//        accumulators come out in V^T's key order), the halves are d = 32 kk + 8 g .. + 7 of that head, natural order (as the query)
+//   V^T  per (slot, head): Tpad / 32 key blocks x 4 KiB = [channel tile ct][lane i + 16 g][8 halves]: channel 16 ct + i, memory positions 8 g .. 8 g + 7 of the block (kperm order, as before)
+// Both are permutations of the 16-byte chunks of the row layouts.  Offsets in halves; feat / pos multiples of 8.
+__host__ __device__ __forceinline__ long skw_kfrag_off(int slot, int H, int Tpad, int key, int feat) {
+    const int h = feat >> 6, c = (feat >> 3) & 7, r = key & 15, i = 4 * (r & 3) + (r >> 2);
+    return (((long)slot * H + h) * (Tpad >> 4) + (key >> 4)) * 1024 + (c >> 2) * 512 + (i + 16 * (c & 3)) * 8;
+}
+__host__ __device__ __forceinline__ long skw_vtfrag_off(int slot, int H, int Tpad, int feat, int pos) {
+    const int h = feat >> 6, ch = feat & 63;
+    return (((long)slot * H + h) * (Tpad >> 5) + (pos >> 5)) * 2048 + (ch >> 4) * 512 + ((ch & 15) + 16 * ((pos >> 3) & 3)) * 8;
+}
 
 enum SkwEpi : int {
     EPI_F32 = 0,        // C f32 [m][n] = (acc + bias[n]) (+ res[m][n])
@@ -46,6 +60,7 @@ struct SkwGemmArgs {
     const float* pe; int n_ctx;     // EPI_CONV2: pe [n_ctx][N]; EPI_HEADS/VT: rows per batch item
     int H; int Tpad;                // EPI_HEADS / EPI_VT
     int epi;
+    int frag;                       // skw_gemm16, EPI_F16_PLAIN / EPI_VT_F16 with n_ctx, H, Tpad set: C is the fragment-order cross K / V^T image (skw_kfrag_off / skw_vtfrag_off) instead of rows
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
     half_t* ln_out; unsigned* ln_cnt;                          // skw_gemm16_small, EPI_F32 with N = ldc: the workgroup that completes a 16-row block of C also writes
@@ -63,7 +78,7 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
 // cross attention of the prompt pass (f16_mfma): the encoder attention kernel with a sequence's prompt tokens as the queries — one read of the sequence's cross K / V^T per 128 of them.
 // q: [rows][d] f16 plain (scaled); sequence i: rows row0[i] .. + nq[i], cross K / V^T of window slot slot[i]; out: [rows][kperm(d)] f16
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
-                         int H, int d, int n_ctx, int Tpad, hipStream_t s);
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag = 0);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
 
@@ -108,6 +123,7 @@ void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // events: stamped at the kernel's own begin / end (the engine's per-kernel profile)
 // the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
+void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s);     // read and discard: warms the Infinity Cache
 bool skw_dec_cross_attn_vt_q_ok(int H, int d);
 bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
                              const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s);

@@ -1264,6 +1264,130 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
             for (int r = 0; r < 4; ++r) att_store(out, (long)b * ldo, h * 64 + (half * CT + ct) * 16 + 4 * g + r, oacc[ct][r], f32_out);
     }
 }
+// ------------------------------------------------------------------ decoder cross-attention (K9), f16_mfma precision: one streaming pass
+// The tolerance precision owes the oracle no summation order, so the two-phase form above (all scores, a workgroup-wide softmax, then P.V — a barrier with the HBM
+// stream drained in the middle of a 50 us launch) becomes one pass per wave with a running maximum.  Four waves per (row, head), each a contiguous quarter of the
+// 32-key blocks; per block a wave takes 4 KB of K rows and 4 KB of V^T straight from memory into MFMA operands — no LDS, no transposes, no conversions:
+//   scores   S[key][*] = K[key][:] . q on the f16 matrix cores: A = 16 K rows x 32 d (one 16-byte load per lane), B = q broadcast to every column; two d halves chain;
+//            A row i of tile j is key 16 j + 4 (i & 3) + (i >> 2), so that lane group g ends up holding keys 4 e + g (e = 4 j + r) — the order V^T's 32-key blocks
+//            are stored in (skw_kperm): the probabilities go into the next MFMA as its B operand as they stand
+//   softmax  block maximum across the wave's four lane groups (two DPP-free shuffles per 8 KB), rescale of the 16 accumulators only when the maximum grows,
+//            p = exp2((s - m) log2 e) rounded to f16 unnormalised (<= 1: no subnormal loss that 1 / sum would add), per-lane partial sums
+//   P.V      O^T[c][*] += V^T[c][keys] . p, four 16-channel tiles, one MFMA each
+// and the four partial (m, l, O) meet in LDS at the end (one barrier).  RD blocks (8 KB each) are in flight per wave, 12 waves per CU.
+template <int HPW, int RD, bool FRAG = false>
+__global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cross_attn16(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk, const half_t* vtbase,
+                                                                                         int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, const int* seq) {
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    const int b = blockIdx.y;
+    if (active && !active[b * active_stride]) return;
+    __shared__ float cmb[HPW][4][66];                                   // per wave: m, l, O[64]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w >> 2, part = w & 3;
+    const int hraw = blockIdx.x * HPW + hs;
+    const bool valid = hraw < H;
+    const int h = valid ? hraw : H - 1;
+    const int bs = seq ? seq[b * active_stride] : b;
+    const int r16 = lane & 15, g = lane >> 4;
+    // a wave's blocks: a contiguous quarter (first + n), or every fourth block (f32_out bit 1: the four waves of a head then walk one sequential stream together)
+    const int il = (f32_out >> 1) & 1; f32_out &= 1;
+    const int nkb = Tpad >> 5, per = (nkb + 3) >> 2;
+    const int first = il ? part : part * per, step = il ? 4 : 1, cnt = il ? (nkb - part + 3) >> 2 : max(0, min(nkb, part * per + per) - part * per);
+    f16x8_t qb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qb[kk] = *(const f16x8_t*)(q + (long)b * ldq + h * 64 + kk * 32 + g * 8);
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + (long)bs * k_batch_stride), 0, (unsigned)((long)(FRAG ? Tpad : n_ctx) * ldk * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vtbase + ((long)bs * H + h) * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
+    const int krow = 4 * (r16 & 3) + (r16 >> 2);
+    const unsigned ko = (unsigned)((h * 64 + g * 8) * 2), kstride = (unsigned)(ldk * 2);
+    const unsigned vo = (unsigned)((r16 * Tpad + g * 8) * 2), vstride = (unsigned)(16 * Tpad * 2);
+    u32x4 ring[RD][8];
+    // one block's loads: K rows of the two score tiles (per-lane row offset — clamped to the last real key —, the d half as the instruction's immediate), then the four V^T tiles
+    // (per-lane offset + block, the channel tile in the scalar offset)
+    auto issue = [&](u32x4 (&slot)[8], int kb) {
+        if constexpr (FRAG) {      // fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB; pad keys of the last tile hold whatever memory held (masked below)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)((kb * 4 + ct) * 1024 + lane * 16), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = (unsigned)min(kb * 32 + 16 * j + krow, n_ctx - 1) * kstride + ko;
+            slot[j * 2] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
+            slot[j * 2 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rk, off + 64, 0, 0);
+        }
+        const unsigned voff = vo + (unsigned)kb * 64;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff, ct * vstride, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int j = 0; j < RD; ++j) if (j < cnt) issue(ring[j], first + j * step);
+    constexpr float LOG2E = 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.0f;
+    f32x4 o[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < cnt; n0 += RD) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) {
+            const int n = n0 + j, kb = first + n * step;
+            if (n < cnt) {                                              // wave-uniform
+                f32x4 sc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ring[j][t * 2]), qb[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ring[j][t * 2 + 1]), qb[1], sc[t], 0, 0, 0);
+                }
+                if (kb * 32 + 32 > n_ctx) {                             // the block with the pad keys (their K rows were read from the last real key)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (kb * 32 + 4 * (4 * t + r) + g >= n_ctx) sc[t][r] = -INFINITY;
+                }
+                float bm = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+                bm = fmaxf(bm, __shfl_xor(bm, 16)); bm = fmaxf(bm, __shfl_xor(bm, 32));
+                if (bm > m) {                                           // wave-uniform (every lane holds the same bm and m)
+                    const float a = __builtin_amdgcn_exp2f((m - bm) * LOG2E);       // first block: exp2(-inf) = 0 on empty accumulators
+                    l = l * a;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) { o[ct][0] *= a; o[ct][1] *= a; o[ct][2] *= a; o[ct][3] *= a; }
+                    m = bm;
+                }
+                const float mc = m * LOG2E;
+                f16x8_t pb;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const half_t ph = f2h(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -mc))); pb[4 * t + r] = ph; l = l + h2f(ph); }      // masked keys: exp2(-inf) = 0; the sum is of the rounded values the MFMA multiplies
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ring[j][4 + ct]), pb, o[ct], 0, 0, 0);
+                if (n + RD < cnt) issue(ring[j], kb + RD * step);              // the slot's next block (RD - 1 blocks stay in flight while one is consumed)
+            }
+        }
+    }
+    l = l + __shfl_xor(l, 16); l = l + __shfl_xor(l, 32);
+    float* cw = cmb[hs][part];
+    if (lane == 0) { cw[0] = m; cw[1] = l; }
+    if (r16 == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cw[2 + ct * 16 + 4 * g + r] = o[ct][r];
+    }
+    __syncthreads();
+    if (part == 0 && valid) {
+        float M = cmb[hs][0][0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) M = fmaxf(M, cmb[hs][i][0]);
+        float num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float a = __builtin_amdgcn_exp2f((cmb[hs][i][0] - M) * LOG2E); num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }   // an empty quarter: m = -inf, a = 0
+        att_store(out, (long)b * ldo, h * 64 + lane, num / den, f32_out);
+    }
+}
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16, const int* seq,
                            hipEvent_t ev_start, hipEvent_t ev_stop) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
@@ -1274,6 +1398,24 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
     static const int xcd_env = getenv("SKW_XATTN_XCD") ? atoi(getenv("SKW_XATTN_XCD")) : 0;
     if (xcd_env && (B & 7) == 0) f32_out |= 1 << 16;
+    // f16_mfma precision, pv16 == 2: cross K / V^T are fragment-order images and the launch is the one-pass streaming kernel (interleaved block assignment: SKW_XATTN16_IL=0 for quarters).
+    // pv16 == 1 (row layouts): the two-phase kernel with the f16 P.V below; SKW_XATTN16=1 runs the one-pass kernel on the row layouts instead (measured slower: 55.0 vs 53.6 us — an MFMA
+    // operand tile read from rows is 16 x 64 B per instruction, twice the requests per byte; that is what the fragment order removes: 49.5 us)
+    static const int x16 = getenv("SKW_XATTN16") ? atoi(getenv("SKW_XATTN16")) : 0, x16il = getenv("SKW_XATTN16_IL") ? atoi(getenv("SKW_XATTN16_IL")) : 1;
+    if ((pv16 == 2 || (pv16 && x16)) && !(f32_out >> 8)) {
+        const int fo = (f32_out & 1) | (x16il ? 2 : 0);
+        const dim3 grid((H + 2) / 3, B), blk(768);
+        const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
+        if (pv16 == 2) {
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+        } else {
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+        }
+        return;
+    }
+    if (pv16 == 2) pv16 = 1;       // (probe launches with parts switched off exist for the two-phase kernel only)
     if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
     // (profiling: hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end — the duration rocprofv3 reports — instead of an event pair around the launch, which adds the dispatch gap)
     else if (wph == 4 && pv16 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
@@ -1281,6 +1423,27 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
     else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
     else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
     else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+}
+// ------------------------------------------------------------------ cache warming: read `bytes` of a buffer and keep nothing.  The decode step's small launches leave HBM idle
+// (16.5 MB of weights per layer in ~58 us); a reader that runs beside them moves the next cross attention's K rows into the Infinity Cache (memory side, 256 MiB), from
+// where that launch then streams them faster than from HBM.  One wave per SIMD at most, <= 56 registers, no LDS: it fits beside every decode kernel's workgroups.
+__global__ __launch_bounds__(256) void k_touch(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    u32x4 acc = (u32x4){0u, 0u, 0u, 0u};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < n16; i += stride) acc ^= p[i];
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) *sink = 1u;     // (never true in practice: keeps the loads)
+}
+void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s) {
+    if (!bytes) return;
+    hipLaunchKernelGGL(k_touch, dim3(n_wg), dim3(256), 0, s, (const u32x4*)p, bytes / 16, sink);
 }
 // LayerNorm + query projection + cross attention in one launch (k_dec_cross_attn<.., FQ>): x f32 [B][d] residual rows, Wq f16 [d][ldw] kperm.
 // Returns false (nothing launched) for geometries the fused prologue does not cover; the caller then runs the three launches.

@@ -120,7 +120,8 @@ __device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, in
         if (EPI == EPI_HEADS_F16) return ((long)(b * a.H + (px >> 6)) * a.Tpad + i) * 64 + (px & 63);
         return ((long)b * (a.n_ctx + 2) + i + 1) * a.ldc + px;
     }
-    if (EPI == EPI_VT_F16) { int kp = rb + dx, b = qb; if (kp >= a.Tpad) { kp -= a.Tpad; b += 1; } return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
+    if (EPI == EPI_VT_F16) { int kp = rb + dx, b = qb; if (kp >= a.Tpad) { kp -= a.Tpad; b += 1; } if (a.frag) return skw_vtfrag_off(b, a.H, a.Tpad, y, kp); return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
+    if (EPI == EPI_F16_PLAIN) { if (a.frag) { int i = rb + dy, b = qb; if (i >= a.n_ctx) { i -= a.n_ctx; b += 1; } return skw_kfrag_off(b, a.H, a.Tpad, i, px); } }
     return (long)y * a.ldc + px;
 }
 
@@ -353,7 +354,7 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // XP — the prompt pass's cross attention (skw_engine.hip, prefill): the same kernel with the queries of a SEQUENCE'S prompt tokens (rows row0 .. row0 + nq of the pass, plain
 // [row][d] f16 in natural k order, as the cross-query GEMM leaves them) against that sequence's cross K (plain rows [key][d], natural order: both operands of the score MFMA
 // then agree on which k sits in which slot) and V^T (already this kernel's layout).  One read of a sequence's K / V^T serves up to 128 of its prompt tokens instead of one.
-struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; };      // per sequence of the pass: first row, rows, window slot
+struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; };   // frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
 template <bool XP>
 __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
                                                            int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
@@ -375,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         qf[qt][0] = *(const f16x8*)qp; qf[qt][1] = *(const f16x8*)(qp + 32);
     }
     const long krow = XP ? xp.ldk : 64;                                  // halves between consecutive keys of this head
-    __amdgpu_buffer_rsrc_t rk = XP ? __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long)xp.slot[b] * xp.k_seq_stride + h * 64), 0, (unsigned)((((long)n_ctx - 1) * krow + 64) * 2), 0x00020000)
+    const bool frag = XP && xp.frag;
+    __amdgpu_buffer_rsrc_t rk = frag ? __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long)xp.slot[b] * xp.k_seq_stride + (long)h * (Tpad >> 4) * 1024), 0, (unsigned)((Tpad >> 4) * 2048), 0x00020000)
+                              : XP ? __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long)xp.slot[b] * xp.k_seq_stride + h * 64), 0, (unsigned)((((long)n_ctx - 1) * krow + 64) * 2), 0x00020000)
                                    : __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + bh * Tpad * 64), 0, (unsigned)(Tpad * 64 * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + bh * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
     // staging: chunk id c = tid + 256 i -> row c >> 3, 16-byte chunk c & 7
@@ -392,6 +395,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (((row & 1) << 2) | ((row >> 2) & 3))) << 4));
         st_k[i] = (unsigned)((row * krow + pos * 8) * 2);            // + kb * 64 rows; rows past Tpad (XP: past n_ctx) fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
+        if (frag) {      // the same 16-byte chunks at their fragment-order addresses: a 64-key block is 8 KiB of either image (K: key tile row >> 4 of the block, row 4 (r & 3) + (r >> 2), d half pos >> 2; V^T: 32-key block pos >> 2, channel tile row >> 4)
+            const int r = row & 15;
+            st_k[i] = (unsigned)((((row >> 4) * 2 + (pos >> 2)) * 1024) + (4 * (r & 3) + (r >> 2) + 16 * (pos & 3)) * 16);
+            st_v[i] = (unsigned)((((pos >> 2) * 4 + (row >> 4)) * 1024) + (r + 16 * (pos & 3)) * 16);
+        }
         st_vkey[i] = pos * 8;
     }
     const int nkb = (Tpad + 63) >> 6;
@@ -400,11 +408,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * (unsigned)(krow * 128), 0, 0);      // (keys past the end lie outside the descriptor: zeros, masked below)
+        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * (frag ? 8192u : (unsigned)(krow * 128)), 0, 0);      // (keys past the end lie outside the descriptor: zeros, masked below)
     };
     auto load_v = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (kb * 64 + st_vkey[i] < Tpad) ? st_v[i] + (unsigned)kb * 128u : 0x7fffff00u, 0, 0);
+        for (int i = 0; i < 2; ++i) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (kb * 64 + st_vkey[i] < Tpad) ? st_v[i] + (unsigned)kb * (frag ? 8192u : 128u) : 0x7fffff00u, 0, 0);
     };
     auto store_k = [&](int buf) {
 #pragma unroll
@@ -500,9 +508,9 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
 }
 // the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
-                         int H, int d, int n_ctx, int Tpad, hipStream_t s) {
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag) {
     const int qblocks = (nq_max + A16_QB - 1) / A16_QB;
-    const SkwXPrefill xp{row0, nq, slot, (long)d, (long)n_ctx * d, (long)d};
+    const SkwXPrefill xp{row0, nq, slot, (long)d, (long)(frag ? Tpad : n_ctx) * d, (long)d, frag};
     hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp);
 }
 

@@ -298,3 +298,27 @@ def test_f16_mfma_other_widths(eng, size):
         print("  LayerNorm %s: %d decisions, %d differ, max logit error %.3g (bound %.3g)" % ("folded" if on else "launched", r["steps_checked"], r["argmax_disagreements"], r["max_logit_err"], eb))
         assert r["ok"] and r["steps_checked"] > 20, (size, on, r["max_logit_err"], r["max_margin_at_disagreement"])
     ctx.close(); m.close()
+
+
+def test_cross_kv_layouts_agree(eng, tiny_model_path, small_model_path):
+    """f16_mfma keeps the cross K / V^T as fragment-order images (every load of the decode step's cross attention one contiguous KiB, one streaming pass with a running
+    maximum; skw_kernels.h skw_kfrag_off) — the default — or as rows (the two-phase kernel): the same products in two summation orders.  Their exports (skw_encode un-permutes
+    either image) must be the same f16 values bit for bit — the layout changes where the GEMM epilogue puts a chunk, not what it holds — and the logits they lead to agree
+    within the precision's logit tolerance."""
+    import ctypes as C
+    L = eng.lib(); L.skw_debug_set_kv_frag.argtypes = [C.c_void_p, C.c_int]
+    for path, n in ((tiny_model_path, 480000), (small_model_path, 16000 * 11 + 77)):
+        m = eng.Model(path); ctx = eng.Context(m, max_batch=1); ctx.set_precision("f16_mfma")
+        pcm = synth.clip(21, n)
+        toks = [50258, 50259, 50359, 50364, 1234, 777, 31000, 50400]
+        out = {}
+        for frag in (1, 0):
+            L.skw_debug_set_kv_frag(ctx.h, frag)
+            _, ck, cv = ctx.encode(pcm)
+            out[frag] = (np.array(ck, copy=True), np.array(cv, copy=True), np.array(ctx.decode_logits(toks), copy=True))
+        assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+        lg1, lg0 = out[1][2], out[0][2]
+        err = float(np.abs(lg1 - lg0).max()); rng = float(lg0.max() - lg0.min())
+        print("cross K/V as fragment images vs rows, %s: max logit difference %.3g (range %.3g)" % (os.path.basename(path), err, rng))
+        assert err < TOL_LOGIT_REL * rng and err < LOGIT_ERR_BOUND
+        ctx.close(); m.close()
