@@ -1406,7 +1406,12 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         const int fo = (f32_out & 1) | (x16il ? 2 : 0);
         const dim3 grid((H + 2) / 3, B), blk(768);
         const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
-        if (pv16 == 2) {
+        static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;      // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
+        if (pv16 == 2 && x16hpw == 1) {
+            const dim3 grid1(H, B), blk1(256);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+        } else if (pv16 == 2) {
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
         } else {

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
-            int gm = m0 + c;
+            int gm = m0 + c; if (a.probe & 256) gm = c;      // (measurement only: every tile reads the first A panel — what the loop would take with the A operand always in L2)
             if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
             if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
             const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;

@@ -19,8 +19,8 @@ shapes = [("Q/K proj", 96000, 768, 768, "HEADS"), ("cross K", 96000, 768, 768, "
 print("%-10s %-28s %9s %9s %9s %9s %9s %9s %9s" % ("", "M x N x K / epilogue", "full us", "TF/s", "no DMA", "no MFMA", "no epi", "no store", "no math"))
 for name, M, N, K, epi in shapes:
     t = {}
-    for probe in (0, 1, 2, 4, 8, 16, 32, 64, 4 | 32, 4 | 64):
+    for probe in (0, 1, 2, 4, 8, 16, 32, 64, 4 | 32, 4 | 64, 256, 256 | 4):
         ms = C.c_float()
         assert L.skw_debug_gemm16(ctx.h, M, N, K, EPI[epi], probe, 10, C.byref(ms)) == 0
         t[probe] = ms.value * 1e3
-    print("%-10s %-28s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   nt A %6.1f  nt W %6.1f  loop only: nt A %6.1f  nt W %6.1f" % (name, "%d x %d x %d / %s" % (M, N, K, epi), t[0], 2.0 * M * N * K / t[0] / 1e6, t[1], t[2], t[4], t[8], t[16], t[32], t[64], t[36], t[68]))
+    print("%-10s %-28s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   nt A %6.1f  nt W %6.1f  loop only: nt A %6.1f  nt W %6.1f" % (name, "%d x %d x %d / %s" % (M, N, K, epi), t[0], 2.0 * M * N * K / t[0] / 1e6, t[1], t[2], t[4], t[8], t[16], t[32], t[64], t[36], t[68]) + "   A from L2: %6.1f  loop only %6.1f" % (t[256], t[260]))
