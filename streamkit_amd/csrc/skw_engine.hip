@@ -472,6 +472,11 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
 
 // ------------------------------------------------------------------ debug taps (encoder layer 0, natural layouts; enabled by skw_debug_enable)
 static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on = false;
+// host-side view of the fragment-order layouts (tests/test_cpu_layouts.py checks them without a GPU): element offset of the 16-byte chunk that holds (key, feat .. feat + 7) of cross K /
+// (feat, positions pos .. pos + 7) of cross V^T
+extern "C" long skw_layout_kfrag_off(int slot, int H, int Tpad, int key, int feat) { return skw_kfrag_off(slot, H, Tpad, key, feat); }
+extern "C" long skw_layout_vtfrag_off(int slot, int H, int Tpad, int feat, int pos) { return skw_vtfrag_off(slot, H, Tpad, feat, pos); }
+extern "C" int skw_layout_kperm(int k) { return skw_kperm(k); }
 extern "C" void skw_debug_set_kv_frag(skw_ctx* c, int on) { c->kv_frag_on = on != 0; }                // tests: f16_mfma cross K / V^T as fragment-order images (one-pass cross attention) / as rows (two-phase kernel); takes effect at the next encoder pass
 extern "C" void skw_debug_set_prompt_pass(skw_ctx* c, int on) { c->prompt_pass_on = on != 0; }     // tests: the prompt as one pass / one token per step
 extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)
