@@ -125,7 +125,7 @@ __device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, in
     return (long)y * a.ldc + px;
 }
 
-template <int EPI, int BM, int BN, int NWM, int NWN>
+template <int EPI, int BM, int BN, int NWM, int NWN, bool PROBE = false>      // PROBE: the measurement hooks of tools/gemm16_probe.py (a.probe) compiled in; the product kernel has none
 __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwGemmArgs a) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_PIECES = BM / 8 / NW, B_PIECES = BN / 8 / NW;      // 1-KiB pieces per wave per K step
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
-            int gm = m0 + c; if (a.probe & 256) gm = c;      // (measurement only: every tile reads the first A panel — what the loop would take with the A operand always in L2)
+            int gm = m0 + c; if (PROBE && (a.probe & 256)) gm = c;      // (measurement only: every tile reads the first A panel — what the loop would take with the A operand always in L2)
             if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
             if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
             const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
     auto stage = [&](int buf, int kb) {
         char* base = lds + buf * (BM + BN) * 128;
         // (a.probe bits 5 / 6, measurement only: the non-temporal policy on the A / W stream)
-        if (a.probe & 32) {
+        if (PROBE && (a.probe & 32)) {
 #pragma unroll
             for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 2);
         } else {
 #pragma unroll
             for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 0);
         }
-        if (a.probe & 64) {
+        if (PROBE && (a.probe & 64)) {
 #pragma unroll
             for (int i = 0; i < B_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gB[i] + kb * 64), (lptr_t)(base + BM * 128 + (wave * B_PIECES + i) * 1024), 16, 0, 2);
         } else {
@@ -204,10 +204,15 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kb = 0; kb < nk; ++kb) {
             const char* base = lds + (kb & 1) * (BM + BN) * 128;
-            if (kb + 1 < nk && !(a.probe & 1)) stage((kb + 1) & 1, kb + 1);
+            // The next step is staged unconditionally — the last step re-stages itself into the idle buffer (1/nk more L2 -> LDS traffic) — so that the whole K step is ONE basic block:
+            // with the `kb + 1 < nk` branch (and the probe's) in front of the fragment reads, hipcc kept the step's address arithmetic and several accumulators' worth of state live
+            // across four code paths and spilled (72-116 B of scratch per lane in three of the eight epilogue variants, none now); same-box A/B per launch: Q/K 175-189 -> 167-177 us,
+            // cross K 175-180 -> 167, O-proj 286-290 -> 243-246, FC1 739-746 -> 722, FC2 686 -> 641-648; encode 40.4-41.0 -> 38.8 ms per batch (profiles/r03g/r03g_gemm16_probe_single_block_k_step.txt)
+            if (!PROBE) stage((kb + 1) & 1, min(kb + 1, nk - 1));
+            else if (kb + 1 < nk && !(a.probe & 1)) stage((kb + 1) & 1, kb + 1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {       // (SIMD partners taking the two halves in opposite order — a stagger — measured the same: 28.76 vs 28.63 ms per batch)
-                if (a.probe & 2) break;
+                if (PROBE && (a.probe & 2)) break;
                 const int fo = kk ? fo1 : fo0;
                 f16x8 fx[TX], fy[TY];
 #pragma unroll
@@ -221,13 +226,15 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             }
             if (kb + 1 < nk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
         }
-        // every wave must have read the last K step before the next tile's first step lands in buffer 0 (nk == 1: same buffer; nk odd: the last step's)
+        // every wave must have read the last K step before the next tile's first step lands in buffer 0 (nk == 1: same buffer; nk odd: the last step's);
+        // the last step's re-staging has landed before buffer 1 becomes the epilogue's staging area and buffer 0 the next tile's first step
+        if (!PROBE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int X0 = X_IS_M ? m0 : n0, Y0 = X_IS_M ? n0 : m0;                 // tile origin along memory (X) and across it (Y)
         tile += gridDim.x;
         const bool more = tile < nblk;
-        if (more) { tile_origin(tile, m0, n0); tile_sources(m0, n0); if (!(a.probe & 1)) stage(0, 0); }      // the next tile's first K step flies under this tile's epilogue (buffer 0)
-        if (!(a.probe & 4)) {
+        if (more) { tile_origin(tile, m0, n0); tile_sources(m0, n0); if (!(PROBE && (a.probe & 1))) stage(0, 0); }      // the next tile's first K step flies under this tile's epilogue (buffer 0)
+        if (!(PROBE && (a.probe & 4))) {
             constexpr bool F32OUT = Epi16Out<EPI>::F32OUT;
             constexpr int BX = X_IS_M ? BM : BN, BY = X_IS_M ? BN : BM, WTX = X_IS_M ? WTM : WTN, WTY = X_IS_M ? WTN : WTM;
             constexpr int ESZ = F32OUT ? 4 : 2, ROWB = BX * ESZ, CPR = ROWB / 16;           // bytes per staged row, 16-byte chunks per row
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                     }
                 }
                 };
-                if (a.probe & 16) phase_a(std::true_type{}); else phase_a(std::false_type{});
+                if (PROBE && (a.probe & 16)) phase_a(std::true_type{}); else phase_a(std::false_type{});
                 __syncthreads();
                 // phase B: whole rows out, 16 bytes per lane; the row-wise operands of a batch of chunks are requested together
                 constexpr int NCH = RP * CPR / (NW * 64), BATCH = !F32OUT ? 2 : (NCH < 4 ? NCH : 4);     // (f16 outputs have no row-wise operand to wait for)
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         const int cid = tid + (c0 + u) * NW * 64, ylp = cid / CPR, pc = cid % CPR, ck = pc ^ (ylp & (CPR - 1));
                         const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
                         lofs[u] = ylp * ROWB + (pc << 4);
-                        off[u] = (y >= y_lim || px >= x_lim || (a.probe & 8)) ? -1 : epi_chunk_offset<EPI>(a, y, px, pass * RP + ylp, ck * CE, qb, rb);
+                        off[u] = (y >= y_lim || px >= x_lim || (PROBE && (a.probe & 8))) ? -1 : epi_chunk_offset<EPI>(a, y, px, pass * RP + ylp, ck * CE, qb, rb);
                         if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? *(const f32x4*)(a.res + (long)y * a.ldres + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (EPI == EPI_CONV2) { int i = rb + pass * RP + ylp; if (i >= a.n_ctx) i -= a.n_ctx; opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
@@ -323,7 +330,9 @@ template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_
     const bool big = force ? force == 256 : (Mv >= 256 && a_in.N >= 256 && Mv % 256 == 0 && a_in.N % 256 == 0);
     const int cus = skw_cu_count() & ~7;
     const SkwGemmArgs& a = a_in;
-    if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
+    static const int oldloop = getenv("SKW_GEMM16_OLDLOOP") ? atoi(getenv("SKW_GEMM16_OLDLOOP")) : 0;      // (A/B: the K loop with the staging branch, as it was)
+    if (big && (a.probe || oldloop)) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4, true>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
+    else if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else { const int nblk = ((Mv + 127) / 128) * ((a.N + 127) / 128); hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(std::min(nblk, 2 * cus)), dim3(256), 0, s, a); }
 }
 // f16-MFMA form of skw_gemm.  Requirements (every Whisper geometry meets them): K % 64 == 0, N % 32 == 0, ldc / ldres % 4 == 0.
