@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 //            p = exp2((s - m) log2 e) rounded to f16 unnormalised (<= 1: no subnormal loss that 1 / sum would add), per-lane partial sums
 //   P.V      O^T[c][*] += V^T[c][keys] . p, four 16-channel tiles, one MFMA each
 // and the four partial (m, l, O) meet in LDS at the end (one barrier).  RD blocks (8 KB each) are in flight per wave, 12 waves per CU.
-template <int HPW, int RD, bool FRAG = false>
+template <int HPW, int RD, bool FRAG = false, int AUX = 0>      // AUX = 2: the K / V^T loads carry the non-temporal policy (experiment: keep the once-read stream out of the Infinity Cache so that the step's weights stay in it)
 __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cross_attn16(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk, const half_t* vtbase,
                                                                                          int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, const int* seq) {
     typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -1306,9 +1306,9 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
     auto issue = [&](u32x4 (&slot)[8], int kb) {
         if constexpr (FRAG) {      // fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB; pad keys of the last tile hold whatever memory held (masked below)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, 0);
+            for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, AUX);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)((kb * 4 + ct) * 1024 + lane * 16), 0, 0);
+            for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)((kb * 4 + ct) * 1024 + lane * 16), 0, AUX);
             __builtin_amdgcn_sched_barrier(0);
             return;
         }
@@ -1406,11 +1406,15 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         const int fo = (f32_out & 1) | (x16il ? 2 : 0);
         const dim3 grid((H + 2) / 3, B), blk(768);
         const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
+        static const int x16nt = getenv("SKW_XATTN16_NT") ? atoi(getenv("SKW_XATTN16_NT")) : 1;      // the once-read K / V^T stream with the non-temporal policy: 47.8 -> 46.0-46.3 us per launch in step (same-box A/B, profiles/r03h/r03h_xattn16_nt_ab.txt; on the two-phase kernel over the row layouts the same policy had cost 2 us)
         static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;      // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
         if (pv16 == 2 && x16hpw == 1) {
             const dim3 grid1(H, B), blk1(256);
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
             else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+        } else if (pv16 == 2 && x16nt) {
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
         } else if (pv16 == 2) {
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);

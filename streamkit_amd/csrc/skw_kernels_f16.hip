@@ -17,6 +17,9 @@
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef SKW_DEC_W_AUX
+#define SKW_DEC_W_AUX 0      // (experiment: 2 = the decode GEMMs' weight loads carry the non-temporal policy)
+#endif
 #define MFMA16X32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
         const bool in = j < nkw;
-        fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * 64 : oob, 0, 0);
+        fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * 64 : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
         for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) xa[t] = __builtin_bit_cast(f16x8, fa[j][t]);
             const int nb = kb0 + j + RD; const bool in = nb < nkw;       // refill the slot just read (zeros past the wave's K range: fma(0, 0, acc) == acc)
-            fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * 64 : oob, 0, 0);
+            fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * 64 : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
             for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
 #pragma unroll
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NKW; ++j)
 #pragma unroll
-        for (int q = 0; q < NT; ++q) fw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo[q] != oob) ? wo[q] + j * 64 : oob, 0, 0);
+        for (int q = 0; q < NT; ++q) fw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo[q] != oob) ? wo[q] + j * 64 : oob, 0, SKW_DEC_W_AUX);
     const int ft = w / NT, fq = w % NT;                                // the (row tile, strip) this wave finishes (waves >= MT * NT: none)
     const int em = my0 + ft * 16 + r16;
     f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
     const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
     u32x4 fw[RD];
 #pragma unroll
-    for (int j = 0; j < RD; ++j) fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo != oob) ? wo + j * 64 : oob, 0, 0);
+    for (int j = 0; j < RD; ++j) fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo != oob) ? wo + j * 64 : oob, 0, SKW_DEC_W_AUX);
     const int em = my0 + r16, ep0 = n0 + 4 * g;                 // wave 0 finishes the tile
     f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
     if (EPI == EPI_F32 && a.res && w == 0 && em < a.M && ep0 + 3 < a.N && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
     for (int h = 0; h < 2; ++h) {
         const unsigned o = w_off(0, h);
 #pragma unroll
-        for (int j = 0; j < RD; ++j) fw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, o != oob ? o + j * 64 : oob, 0, 0);
+        for (int j = 0; j < RD; ++j) fw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, o != oob ? o + j * 64 : oob, 0, SKW_DEC_W_AUX);
     }
     // A -> LDS (16-byte chunks, coalesced, eight in flight per thread; rows past M read as zeros)
     { const int cpr = a.K >> 3, total = 16 * MT * cpr;
@@ -994,8 +997,8 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const f16x8 xw0 = __builtin_bit_cast(f16x8, fw[0][j]), xw1 = __builtin_bit_cast(f16x8, fw[1][j]);
-            fw[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on0 != oob ? on0 + j * 64 : oob, 0, 0);
-            fw[1][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on1 != oob ? on1 + j * 64 : oob, 0, 0);
+            fw[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on0 != oob ? on0 + j * 64 : oob, 0, SKW_DEC_W_AUX);
+            fw[1][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on1 != oob ? on1 + j * 64 : oob, 0, SKW_DEC_W_AUX);
             const int kbn = (j + 1 < RD) ? kb0 + j + 1 : kb_next;
 #pragma unroll
             for (int t = 0; t < MT; ++t) xa[(j + 1) & 1][t] = __builtin_bit_cast(f16x8, *(const u32x4*)(la + t * 16 * rowb + kbn * 64));

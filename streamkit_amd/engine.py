@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskw_engine.so")
+LIB_PATH = os.environ.get("SKW_ENGINE_SO") or os.path.join(_HERE, "libskw_engine.so")      # (SKW_ENGINE_SO: A/B runs against another build of the same library, tools only)
 _LIB = None
 
 
