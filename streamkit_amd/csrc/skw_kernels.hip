@@ -1407,11 +1407,15 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         const dim3 grid((H + 2) / 3, B), blk(768);
         const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
         static const int x16nt = getenv("SKW_XATTN16_NT") ? atoi(getenv("SKW_XATTN16_NT")) : 1;      // the once-read K / V^T stream with the non-temporal policy: 47.8 -> 46.0-46.3 us per launch in step (same-box A/B, profiles/r03h/r03h_xattn16_nt_ab.txt; on the two-phase kernel over the row layouts the same policy had cost 2 us)
+        static const int x16rd = getenv("SKW_XATTN16_RD") ? atoi(getenv("SKW_XATTN16_RD")) : 3;
         static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;      // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
         if (pv16 == 2 && x16hpw == 1) {
             const dim3 grid1(H, B), blk1(256);
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
             else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+        } else if (pv16 == 2 && x16nt && x16rd != 3) {      // (blocks in flight per wave: 2 / 4, measurement)
+            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
         } else if (pv16 == 2 && x16nt) {
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
