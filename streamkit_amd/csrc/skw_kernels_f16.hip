@@ -17,6 +17,12 @@
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef SKW_VOCAB_W_AUX
+#define SKW_VOCAB_W_AUX 0    // (experiment: the vocabulary kernel's weight loads — 80 MB read once per step)
+#endif
+#ifndef SKW_EPI_RES_NT
+#define SKW_EPI_RES_NT 0     // (experiment: the big GEMM's residual rows, read once, with the non-temporal policy)
+#endif
 #ifndef SKW_DEC_W_AUX
 #define SKW_DEC_W_AUX 0      // (experiment: 2 = the decode GEMMs' weight loads carry the non-temporal policy)
 #endif
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
                         lofs[u] = ylp * ROWB + (pc << 4);
                         off[u] = (y >= y_lim || px >= x_lim || (PROBE && (a.probe & 8))) ? -1 : epi_chunk_offset<EPI>(a, y, px, pass * RP + ylp, ck * CE, qb, rb);
-                        if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? *(const f32x4*)(a.res + (long)y * a.ldres + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? (SKW_EPI_RES_NT ? __builtin_nontemporal_load((const f32x4*)(a.res + (long)y * a.ldres + px)) : *(const f32x4*)(a.res + (long)y * a.ldres + px)) : (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (EPI == EPI_CONV2) { int i = rb + pass * RP + ylp; if (i >= a.n_ctx) i -= a.n_ctx; opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
 #pragma unroll
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
     for (int h = 0; h < 2; ++h) {
         const unsigned o = w_off(0, h);
 #pragma unroll
-        for (int j = 0; j < RD; ++j) fw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, o != oob ? o + j * 64 : oob, 0, SKW_DEC_W_AUX);
+        for (int j = 0; j < RD; ++j) fw[h][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, o != oob ? o + j * 64 : oob, 0, SKW_VOCAB_W_AUX);
     }
     // A -> LDS (16-byte chunks, coalesced, eight in flight per thread; rows past M read as zeros)
     { const int cpr = a.K >> 3, total = 16 * MT * cpr;
@@ -997,8 +1003,8 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const f16x8 xw0 = __builtin_bit_cast(f16x8, fw[0][j]), xw1 = __builtin_bit_cast(f16x8, fw[1][j]);
-            fw[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on0 != oob ? on0 + j * 64 : oob, 0, SKW_DEC_W_AUX);
-            fw[1][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on1 != oob ? on1 + j * 64 : oob, 0, SKW_DEC_W_AUX);
+            fw[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on0 != oob ? on0 + j * 64 : oob, 0, SKW_VOCAB_W_AUX);
+            fw[1][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, on1 != oob ? on1 + j * 64 : oob, 0, SKW_VOCAB_W_AUX);
             const int kbn = (j + 1 < RD) ? kb0 + j + 1 : kb_next;
 #pragma unroll
             for (int t = 0; t < MT; ++t) xa[(j + 1) & 1][t] = __builtin_bit_cast(f16x8, *(const u32x4*)(la + t * 16 * rowb + kbn * 64));
