@@ -20,6 +20,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef SKW_VOCAB_W_AUX
 #define SKW_VOCAB_W_AUX 0    // (experiment: the vocabulary kernel's weight loads — 80 MB read once per step)
 #endif
+#ifndef SKW_EPI_ST_NT
+#define SKW_EPI_ST_NT 0      // (experiment: the big GEMM's output rows stored with the non-temporal policy, so that they do not push the re-read W / A lines out of L2)
+#endif
 #ifndef SKW_EPI_RES_NT
 #define SKW_EPI_RES_NT 0     // (experiment: the big GEMM's residual rows, read once, with the non-temporal policy)
 #endif
@@ -311,8 +314,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                             f32x4 v = *(const f32x4*)(stg + lofs[u]);
                             if (EPI == EPI_F32) { if (a.res) { v[0] = v[0] + opnd[u][0]; v[1] = v[1] + opnd[u][1]; v[2] = v[2] + opnd[u][2]; v[3] = v[3] + opnd[u][3]; } }
                             else { v[0] = opnd[u][0] + v[0]; v[1] = opnd[u][1] + v[1]; v[2] = opnd[u][2] + v[2]; v[3] = opnd[u][3] + v[3]; }
-                            *(f32x4*)((float*)a.C + off[u]) = v;
-                        } else *(u32x4*)((half_t*)a.C + off[u]) = *(const u32x4*)(stg + lofs[u]);
+                            if (SKW_EPI_ST_NT) __builtin_nontemporal_store(v, (f32x4*)((float*)a.C + off[u])); else *(f32x4*)((float*)a.C + off[u]) = v;
+                        } else { const u32x4 o16 = *(const u32x4*)(stg + lofs[u]); if (SKW_EPI_ST_NT) __builtin_nontemporal_store(o16, (u32x4*)((half_t*)a.C + off[u])); else *(u32x4*)((half_t*)a.C + off[u]) = o16; }
                     }
                 }
                 __syncthreads();
