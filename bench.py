@@ -284,6 +284,9 @@ def main():
         roof.update({"traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured by this run)",
                      "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern})
         if name == "k_dec_cross_attn":
+            # the profile class covers the step's cross attention in either precision; the symbol rocprofv3 shows for it:
+            roof["symbol"] = ("k_dec_cross_attn16<3,3,true,2> (one streaming pass over fragment-order K / V^T, non-temporal loads)" if fast and os.environ.get("SKW_XATTN_FRAG", "1") != "0"
+                              else "k_dec_cross_attn<24,4,3,...> (two-phase kernel over the row layouts)")
             # `achieved` books the bytes of LIVE rows only (a finished sequence's workgroups return at once): sum over launches of 4 x live rows x n_ctx x d,
             # over the summed launch time.  Beside it: one full launch (all rows live) in isolation, back to back over 12 different K / V^T images.
             import ctypes as C

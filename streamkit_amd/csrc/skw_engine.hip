@@ -433,7 +433,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
-    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, false); WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
+    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written) WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
       WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
