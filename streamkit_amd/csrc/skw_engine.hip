@@ -51,6 +51,7 @@ static void set_err(char* err, size_t n, const char* fmt, ...) {
 
 struct DevLin { half_t* w = nullptr; float* b = nullptr; int n_out = 0, n_in = 0, k_pad = 0;
                 half_t* w_nat = nullptr;   // the same weight with the contraction axis in natural order (decoder projections fed by a LayerNorm: skw_gemm16_small_lnA)
+                half_t* w_frag = nullptr; half_t* w_nat_frag = nullptr;   // fragment-order images of w / w_nat for the f16 decode kernels (SkwGemmArgs::Wf; decoder layers only)
                 // ggml's arithmetic for a block-quantised weight (skw_kernels_q8.hip): int8 [n_out][n_in], scales / offsets [n_in / 32][n_pad]; null for f16 weights
                 int8_t* qw = nullptr; float* dwT = nullptr; float* mwT = nullptr; int n_pad = 0, qform = 0; };
 struct HostQ { std::vector<int8_t> q; std::vector<float> d, m; int n_out = 0, K = 0; };      // a quantised weight in the common integer form, host side
@@ -266,6 +267,7 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     if (!(t = find_t(ts, "decoder.positional_embedding"))) { set_err(err, errlen, "missing decoder.positional_embedding"); return fail2(); }
     m->d_pe = dev_upload(m, as_f32(t, tmp), t->n);
     bool ok = true;
+    const bool wfrag_on = !(getenv("SKW_DEC_WFRAG") && atoi(getenv("SKW_DEC_WFRAG")) == 0);      // fragment-order images of the decoder projections (SkwGemmArgs::Wf); =0: the f16 decode kernels read weight rows
     ok = ok && up_lin(m, ts, "encoder.conv1.weight", "encoder.conv1.bias", &m->conv1, err, errlen);
     ok = ok && up_lin(m, ts, "encoder.conv2.weight", "encoder.conv2.bias", &m->conv2, err, errlen);
     ok = ok && up_ln(m, ts, "encoder.ln_post.weight", "encoder.ln_post.bias", &m->ln_post, err, errlen);
@@ -321,6 +323,18 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
                         L.qkv.w_nat = wn;
                     }
                 }
+            }
+            if (ok && wfrag_on) {   // fragment-order images for the f16 decode kernels (skw_make_wfrag): every decoder projection the small-M kernels multiply by; fc1's rows in its GELU epilogue's order
+                auto mk = [&](DevLin& X, int perm) {
+                    if ((X.n_out & 15) || (X.k_pad & 31)) return;
+                    for (int nat = 0; nat < 2; ++nat) {
+                        const half_t* src = nat ? X.w_nat : X.w; if (!src) continue;
+                        half_t* img = nullptr; if (hipMalloc((void**)&img, (size_t)X.n_out * X.k_pad * 2) != hipSuccess) continue;      // (no image: the kernels read the rows)
+                        m->allocs.push_back(img); skw_make_wfrag(src, X.k_pad, X.n_out, X.k_pad, perm, img, nullptr);
+                        (nat ? X.w_nat_frag : X.w_frag) = img;
+                    }
+                };
+                mk(L.qkv, 0); mk(L.o, 0); mk(L.cq, 0); mk(L.co, 0); mk(L.fc1, 1); mk(L.fc2, 0);
             }
             if (ok && m->quant) {   // the same concatenation in the integer form
                 HostQ hq, hk, hv, all; host_q(*find_t(ts, p + "attn.query.weight"), &hq); host_q(*find_t(ts, p + "attn.key.weight"), &hk); host_q(*find_t(ts, p + "attn.value.weight"), &hv);
@@ -433,7 +447,8 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
     WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
     WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
-    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written) WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
+    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written)
+    WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
       WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
@@ -594,7 +609,7 @@ static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0, bool dec
 static SkwGemmArgs q8_args(int M, void* C, long ldc, int epi) { SkwGemmArgs a{}; a.M = M; a.C = C; a.ldc = ldc; a.epi = epi; a.scale = 1.0f; return a; }
 
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
-    SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
+    SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.Wf = L.w_frag; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
 }
 
 // front end for `n` clips already described in c->pcm_off / n_samples / n_len (device): mel + normalisation
@@ -774,10 +789,10 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             GEMM(c, a, a.K); return;
         }
         if (lnA && site >= 0) {
-            a.W = Lw.w_nat; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b;
+            a.W = Lw.w_nat; a.Wf = Lw.w_nat_frag; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b;
             ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
             if (skw_gemm16_small_lnA(a, c->cur)) return;
-            a.W = Lw.w; a.ln_x = nullptr;
+            a.W = Lw.w; a.Wf = Lw.w_frag; a.ln_x = nullptr;
         }
         GEMM_LN(c, a, dx, ln, dy16, s, normalised);
     };
@@ -1306,14 +1321,16 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     const bool small = M <= 64;                                      // the decode-step form: a chain of dependent launches, so the figure includes the kernel boundary
     if (small && epi == EPI_DEC_QKV) { a.C2 = res; a.C3 = res; a.ldc2 = N; a.n_ctx = N / 3; a.ldc = N / 3; }
+    half_t* Wfrag = nullptr;      // probe bit 5 (decode shapes): the weights as fragment-order images (one per W copy of the cycle), what the step's launches read
+    if (small && (probe & 32) && !(N & 15)) { HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2 * wcycle)); for (int w = 0; w < wcycle; ++w) skw_make_wfrag(W + (size_t)w * N * K, K, N, K, epi == EPI_GELU_F16_KPERM, Wfrag + (size_t)w * N * K, c->stream); a.Wf = Wfrag; a.probe &= ~32; }
     for (int i = 0; i < 3; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e0, c->stream));
     // (a launch that also touched the NEXT launch's copy of W — LDS-DMA into a scratch slab, so the bytes sit in the Infinity Cache when wanted — measured no gain:
     //  7.63 vs 7.66 us for the QKV shape.  The cold-weight cost is the transfer into the consuming XCD's L2, ~1 us per 3.5 MB whether it starts in HBM or in the Infinity Cache.)
-    for (int i = 0; i < iters; ++i) { a.W = W + (size_t)(i % wcycle) * N * K; if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
+    for (int i = 0; i < iters; ++i) { a.W = W + (size_t)(i % wcycle) * N * K; if (Wfrag) a.Wf = Wfrag + (size_t)(i % wcycle) * N * K; if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_per_launch = ms / iters;
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(C); hipFree(bias); hipFree(res);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(Wfrag); hipFree(C); hipFree(bias); hipFree(res);
     return 0;
 }
 

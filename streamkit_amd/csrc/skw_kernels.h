@@ -48,6 +48,9 @@ struct SkwGemmArgs {
     const half_t* A; long lda;      // [M][K] f16, K axis kperm'ed, lda in elements (multiple of 8)
     int a_rows_per_batch; long a_batch_stride; // when a_rows_per_batch > 0: row m lives at A + (m / rpb) * a_batch_stride + (m % rpb) * lda
     const half_t* W; long ldw;      // [N][K] f16, K axis kperm'ed
+    const half_t* Wf;               // skw_gemm16_small / _lnA only, may be null: the same weight as a FRAGMENT-ORDER image (skw_make_wfrag) — per 16-row strip s and 32-k block kb one
+                                    // contiguous KiB [lane r16 + 16 g][8 halves] = W[row(16 s + r16)][32 kb + 8 g ..], so that a wave's weight stream is one contiguous run
+                                    // instead of 16 rows x 64 B per load instruction (decode: fc2 9.2 -> 7.3 us per launch with weights from HBM, the others -0.3 .. -0.5)
     int M, N, K;                    // K multiple of 32 (zero padded by the producer)
     void* C; long ldc;
     void* C2; void* C3; long ldc2;   // EPI_DEC_QKV
@@ -77,6 +80,8 @@ bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);   // the same wit
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // cross attention of the prompt pass (f16_mfma): the encoder attention kernel with a sequence's prompt tokens as the queries — one read of the sequence's cross K / V^T per 128 of them.
 // q: [rows][d] f16 plain (scaled); sequence i: rows row0[i] .. + nq[i], cross K / V^T of window slot slot[i]; out: [rows][kperm(d)] f16
+// fragment-order image of a [N][ldw] f16 weight (N % 16 == 0, K % 32 == 0; perm: rows taken in the kperm'ed output order of the GELU epilogues); out: N * K halves
+void skw_make_wfrag(const half_t* W, long ldw, int N, int K, int perm, half_t* out, hipStream_t s);
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
                          int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag = 0);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave

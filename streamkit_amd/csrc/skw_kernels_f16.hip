@@ -629,6 +629,19 @@ __device__ __forceinline__ void gemm16_small_ln_tail(const SkwGemmArgs& a, int m
     }
 }
 
+// fragment-order image of a decode weight (SkwGemmArgs::Wf): one 16-byte chunk per thread
+__global__ void k_make_wfrag(const half_t* W, long ldw, int N, int K, int perm, half_t* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // chunk id in the image: ((strip * nkb + kb) * 64 + lane)
+    const int nkb = K >> 5;
+    if (i >= (long)(N >> 4) * nkb * 64) return;
+    const int lane = (int)(i & 63), kb = (int)((i >> 6) % nkb), strip = (int)((i >> 6) / nkb), r16 = lane & 15, g = lane >> 4;
+    int n = strip * 16 + r16; if (perm) n = (n & ~31) | inv_kperm32(n & 31);
+    *(u32x4*)(out + i * 8) = *(const u32x4*)(W + (long)n * ldw + kb * 32 + g * 8);
+}
+void skw_make_wfrag(const half_t* W, long ldw, int N, int K, int perm, half_t* out, hipStream_t s) {
+    const long n = (long)(N >> 4) * (K >> 5) * 64;
+    hipLaunchKernelGGL(k_make_wfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, perm, out);
+}
 // ------------------------------------------------------------------ decode GEMM (M <= 64 rows per block row), f16 MFMA
 // Weight-streaming form for the batched single-token step (K8-K10).  One workgroup = one 16-column strip of W x 64 rows of A;
 // its four waves split the K axis (each chains its quarter on the matrix cores: K/128 MFMAs per row tile instead of the exact
@@ -645,12 +658,15 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;                  // k-blocks (of 32) per wave; host guarantees K % (32 NW) == 0
     int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = a.Wf ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     // a.probe (tools/dec_gemm_probe.py only): 1 = no weight loads, 2 = no activation loads (out-of-range offsets: zeros without memory traffic),
     // 4 = no partial-sum exchange and no epilogue, 8 = no stores
-    const unsigned wo = (wn < a.N && !(a.probe & 1)) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    // fragment-order weights (a.Wf): strip blockIdx.x's k-blocks are consecutive KiB, lane l's 16 bytes at l * 16 — the row permutation of the GELU epilogues is in the image
+    const bool wfrag = a.Wf != nullptr;
+    const unsigned wstep = wfrag ? 1024u : 64u;
+    const unsigned wo = (a.probe & 1) ? oob : wfrag ? (n0 + 15 < a.N ? (unsigned)(((long)blockIdx.x * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob) : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
     unsigned ao[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M && !(a.probe & 2)) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
         const bool in = j < nkw;
-        fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * 64 : oob, 0, SKW_DEC_W_AUX);
+        fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * wstep : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
         for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) xa[t] = __builtin_bit_cast(f16x8, fa[j][t]);
             const int nb = kb0 + j + RD; const bool in = nb < nkw;       // refill the slot just read (zeros past the wave's K range: fma(0, 0, acc) == acc)
-            fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * 64 : oob, 0, SKW_DEC_W_AUX);
+            fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * wstep : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
             for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
 #pragma unroll
@@ -726,14 +742,16 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
     const int n0 = blockIdx.x * (16 * NT), my0 = blockIdx.y * (16 * MT);
     const int r16 = lane & 15, g = lane >> 4;
     const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;               // host: nkw <= NKW
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    const bool wfrag = a.Wf != nullptr;      // fragment-order image of the natural-k weight (see k_gemm16_small)
+    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    const unsigned wstep = wfrag ? 1024u : 64u;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_x, 0, (unsigned)((long)a.M * a.K * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_w, 0, (unsigned)(a.K * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_b, 0, (unsigned)(a.K * 4), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     unsigned wo[NT];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) { int wn = n0 + 16 * q + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31); wo[q] = wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob; }
+    for (int q = 0; q < NT; ++q) { int wn = n0 + 16 * q + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31); wo[q] = wfrag ? (n0 + 16 * q + 15 < a.N ? (unsigned)(((long)(blockIdx.x * NT + q) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob) : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob; }
     const unsigned ko = (unsigned)((kb_lo * 32 + g * 8) * 4);          // byte offset of this lane's eight k inside an f32 row (x, gain, bias)
     unsigned xo[MT];
 #pragma unroll
@@ -750,7 +768,7 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NKW; ++j)
 #pragma unroll
-        for (int q = 0; q < NT; ++q) fw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo[q] != oob) ? wo[q] + j * 64 : oob, 0, SKW_DEC_W_AUX);
+        for (int q = 0; q < NT; ++q) fw[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo[q] != oob) ? wo[q] + j * wstep : oob, 0, SKW_DEC_W_AUX);
     const int ft = w / NT, fq = w % NT;                                // the (row tile, strip) this wave finishes (waves >= MT * NT: none)
     const int em = my0 + ft * 16 + r16;
     f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
