@@ -450,7 +450,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written)
     WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
-      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, R * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
+      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, (R + 16) * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     if (m->quant) {
@@ -781,6 +781,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     // the prompt pass of a long-form batch is thousands of rows: there the projections are the encoder's big-tile GEMM (f16_mfma; the small-M kernels stream the
     // weights once per 16 rows and reach ~50 TF/s at M = 4096, the big kernel 600).  The QKV product keeps the decode form: its epilogue appends to the K / V caches.
     const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !getenv("SKW_PROMPT_SMALL_GEMM");
+    static const bool afrag_on = !(getenv("SKW_DEC_AFRAG") && atoi(getenv("SKW_DEC_AFRAG")) == 0);
     auto gemm_s = [&](const SkwGemmArgs& a) { if (bigM) GEMM(c, a, a.K); else GEMM_S(c, a, a.K); };
     // a GEMM fed by LayerNorm(dx): the normalising form (site >= 0), else LayerNorm kernel + GEMM
     auto gemm_ln = [&](SkwGemmArgs a, const DevLin& Lw, const DevLN& ln, int site, bool normalised) {
@@ -822,8 +823,10 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b()); }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); gemm_s(a); }
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
-        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt;
+        // f16_mfma, small-M kernels on both sides: fc1 leaves its output as the fragment-order A image fc2 reads (fc2 7.4 -> 6.5 us per launch); the prompt pass's big-tile GEMMs keep rows
+        const bool h_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0;
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; a.c_frag = h_frag; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
+        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = h_frag;
           if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
           gemm_s(a); }
     }

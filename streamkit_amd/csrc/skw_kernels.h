@@ -25,6 +25,8 @@ __host__ __device__ __forceinline__ long skw_kfrag_off(int slot, int H, int Tpad
     const int h = feat >> 6, c = (feat >> 3) & 7, r = key & 15, i = 4 * (r & 3) + (r >> 2);
     return (((long)slot * H + h) * (Tpad >> 4) + (key >> 4)) * 1024 + (c >> 2) * 512 + (i + 16 * (c & 3)) * 8;
 }
+// fragment-order activation image (SkwGemmArgs::c_frag / a_frag): element offset of position p (multiple of 4) of row m, K halves per row
+__host__ __device__ __forceinline__ long skw_afrag_off(int m, int p, int K) { return ((long)(m >> 4) * (K >> 5) + (p >> 5)) * 512 + ((m & 15) + 16 * ((p >> 3) & 3)) * 8 + (p & 7); }
 __host__ __device__ __forceinline__ long skw_vtfrag_off(int slot, int H, int Tpad, int feat, int pos) {
     const int h = feat >> 6, ch = feat & 63;
     return (((long)slot * H + h) * (Tpad >> 5) + (pos >> 5)) * 2048 + (ch >> 4) * 512 + ((ch & 15) + 16 * ((pos >> 3) & 3)) * 8;
@@ -63,6 +65,8 @@ struct SkwGemmArgs {
     const float* pe; int n_ctx;     // EPI_CONV2: pe [n_ctx][N]; EPI_HEADS/VT: rows per batch item
     int H; int Tpad;                // EPI_HEADS / EPI_VT
     int epi;
+    int c_frag, a_frag;             // the f16 decode kernels (skw_gemm16_small / _lnA): c_frag — an EPI_GELU_F16_KPERM product writes C as the fragment-order A image of the product that follows
+                                    // (per 16-row tile and 32-k block one KiB [lane r16 + 16 g][8 halves], skw_afrag_off); a_frag — A is such an image.  The decode step's fc1 -> fc2 pair.
     int frag;                       // skw_gemm16, EPI_F16_PLAIN / EPI_VT_F16 with n_ctx, H, Tpad set: C is the fragment-order cross K / V^T image (skw_kfrag_off / skw_vtfrag_off) instead of rows
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)

@@ -92,6 +92,7 @@ __device__ __forceinline__ void epi_store4(const SkwGemmArgs& a, int y, int p0, 
         long row;
         if (EPI == EPI_GELU_F16_KPERM_ROWPAD) row = ((long)(y / a.n_ctx) * (a.n_ctx + 2) + (y % a.n_ctx) + 1) * a.ldc + p0;
         else if (EPI == EPI_HEADS_F16) { const int b = y / a.n_ctx, i = y % a.n_ctx; row = ((long)(b * a.H + (p0 >> 6)) * a.Tpad + i) * 64 + (p0 & 63); }
+        else if (EPI == EPI_GELU_F16_KPERM && a.c_frag) row = skw_afrag_off(y, p0, a.N);      // (decode step: fc1's output as fc2's fragment-order A image)
         else row = (long)y * a.ldc + p0;
         *(f16x4*)((half_t*)a.C + row) = o;
     } else if (EPI == EPI_VT_F16) {             // X = virtual token row b * Tpad + key (memory position p0 = b * Tpad + key position), y = feature
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;                  // k-blocks (of 32) per wave; host guarantees K % (32 NW) == 0
     int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
     __amdgpu_buffer_rsrc_t rw = a.Wf ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.a_frag ? (unsigned)((long)((a.M + 15) & ~15) * a.K * 2) : (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     // a.probe (tools/dec_gemm_probe.py only): 1 = no weight loads, 2 = no activation loads (out-of-range offsets: zeros without memory traffic),
     // 4 = no partial-sum exchange and no epilogue, 8 = no stores
@@ -668,15 +669,17 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     const unsigned wstep = wfrag ? 1024u : 64u;
     const unsigned wo = (a.probe & 1) ? oob : wfrag ? (n0 + 15 < a.N ? (unsigned)(((long)blockIdx.x * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob) : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
     unsigned ao[MT];
+    // a.a_frag: the activations are a fragment-order image (written that way by the product before, SkwGemmArgs::c_frag): a row tile's k-blocks are consecutive KiB
+    const bool afrag = a.a_frag != 0; const unsigned astep = afrag ? 1024u : 64u;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M && !(a.probe & 2)) ? (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2) : oob; }
+    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M && !(a.probe & 2)) ? (afrag ? (unsigned)(((long)(blockIdx.y * MT + t) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2)) : oob; }
     u32x4 fw[RD], fa[RD][MT];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
         const bool in = j < nkw;
         fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + j * wstep : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * 64 : oob, 0, 0);
+        for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + j * astep : oob, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // what the epilogue of THIS wave's row tile needs besides the sums is requested now: a short kernel cannot afford a dependent
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
             const int nb = kb0 + j + RD; const bool in = nb < nkw;       // refill the slot just read (zeros past the wave's K range: fma(0, 0, acc) == acc)
             fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && wo != oob) ? wo + nb * wstep : oob, 0, SKW_DEC_W_AUX);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * 64 : oob, 0, 0);
+            for (int t = 0; t < MT; ++t) fa[j][t] = __builtin_amdgcn_raw_buffer_load_b128(ra, (in && ao[t] != oob) ? ao[t] + nb * astep : oob, 0, 0);
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = MFMA16X32(xw, xa[t], acc[t]);          // D[n = 4g + r][m = 16 t + r16]
             __builtin_amdgcn_sched_barrier(0);

@@ -19,7 +19,7 @@ L.skw_debug_gemm16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C
 EPI = {"F32": 0, "GELU_KPERM": 2, "PLAIN": 6, "QKV": 8}
 shapes = [("out proj", 64, 768, 768, "F32"), ("q proj", 64, 768, 768, "PLAIN"), ("qkv", 64, 2304, 768, "QKV"), ("fc1", 64, 3072, 768, "GELU_KPERM"), ("fc2", 64, 768, 3072, "F32"), ("logits", 64, 51865, 768, "F32"),
           ("out proj 32", 32, 768, 768, "F32"), ("fc1 16", 16, 3072, 768, "GELU_KPERM")]
-probes = (0, 1, 2, 3, 4, 7, 8, 9, 11, 16, 32)
+probes = (0, 1, 2, 3, 4, 7, 8, 9, 11, 16, 32, 34, 96)
 print("%-12s %-22s" % ("", "M x N x K / epilogue") + "".join(" %8s" % ("p=%d" % p) for p in probes) + "   (us per dependent launch)")
 for name, M, N, K, epi in shapes:
     t = []
