@@ -805,7 +805,7 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA); }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); gemm_s(a); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;

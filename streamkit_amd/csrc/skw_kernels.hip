@@ -875,7 +875,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // One wave per (sequence, head), no block-level synchronisation: lane = key for the scores (64 independent d-chains per
 // pass over K), lane = channel for P.V (one key-ascending chain per output, p_j broadcast with v_readlane).
 // A block is 4 waves = 4 heads of one sequence.
-template <int MAXT>
+template <int MAXT, bool FASTV = false>      // FASTV (f16_mfma only): the V rows arrive as 16-byte pieces and each lane sums its own keys' share — see below
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
                                                   const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwQ8Out q8,
                                                   const int* seq) {
@@ -900,8 +900,18 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 #pragma unroll
       for (int c8 = 0; c8 < 8; ++c8) kk0[c8] = kr[c8]; }
     __builtin_amdgcn_sched_barrier(0);
-    half_t vpre[NPRE];
-    {
+    // FASTV.  The exact form below gives lane c the key-ascending fma chain of channel c: one 2-byte load per key and lane (128 load instructions for the prefetched keys, about a
+    // microsecond of issue in a 8.6 us kernel) and a readlane + convert + fma per key.  The tolerance precision owes no order: lane (kg = lane >> 3, piece = lane & 7) takes the
+    // 16-byte piece `piece` of the rows of keys kg, kg + 8, ... (one load instruction = eight whole 128-byte head rows), sums p_key * v over ITS keys for its eight channels, and the
+    // eight key groups meet in three shuffle steps.  16 load instructions instead of 128, 8 fmas per key and lane group instead of 64.
+    constexpr int NPV = FASTV ? NPRE / 8 : 1;
+    half_t vpre[FASTV ? 1 : NPRE];
+    uint4 vq[NPV];
+    const int kg = lane >> 3, piece = lane & 7;
+    if constexpr (FASTV) {
+#pragma unroll
+        for (int u = 0; u < NPV; ++u) vq[u] = *(const uint4*)(V + (long)min(u * 8 + kg, rows_cap - 1) * ldkv + piece * 8);
+    } else {
         const half_t* vp0 = V + lane;
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) vpre[u] = vp0[(long)min(u, rows_cap - 1) * ldkv];
@@ -946,6 +956,39 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
     const float inv = (float)(1.0 / lsum);
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) if (t * 64 < n_kv) sc[t] = h2f(f2h(sc[t] * inv));
+    if constexpr (FASTV) {
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[e] = 0.0f;
+        const int ngrp = (n_kv + 7) >> 3;                     // groups of eight keys (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < NPV; ++u) {
+            if (u < ngrp) {
+                const int key = u * 8 + kg;
+                const float pk = __shfl(sc[(u * 8) >> 6], key & 63);          // (the group's eight keys lie in one 64-key pass)
+                if (key < n_kv) { H8 v8; v8.u = vq[u];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a8[e] = __builtin_fmaf(pk, h2f(v8.h[e]), a8[e]); }
+            }
+        }
+        for (int u = NPV; u < ngrp; ++u) {                    // keys past the prefetched 128 (long prompts): one load per group
+            const int key = u * 8 + kg;
+            H8 v8; v8.u = *(const uint4*)(V + (long)min(key, n_kv - 1) * ldkv + piece * 8);
+            float pk = 0.0f;
+#pragma unroll
+            for (int t = NPRE / 64; t < MAXT; ++t) if ((u * 8) >> 6 == t) pk = __shfl(sc[t], key & 63);
+            if (key < n_kv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = __builtin_fmaf(pk, h2f(v8.h[e]), a8[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a8[e] += __shfl_xor(a8[e], 8); a8[e] += __shfl_xor(a8[e], 16); a8[e] += __shfl_xor(a8[e], 32); }
+        if (kg == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) att_store(out, (long)b * ldo, h * 64 + piece * 8 + e, a8[e], f32_out);
+        }
+        return;
+    }
     // P.V: lane = channel
     float acc = 0.0f;
     const half_t* vp = V + lane;
@@ -1477,7 +1520,10 @@ bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_
     return true;
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv) {
+    static const int fastv_env = getenv("SKW_DEC_ATTN_FASTV") ? atoi(getenv("SKW_DEC_ATTN_FASTV")) : 1;
+    if (fastv && fastv_env && !q8.q && !f32_out) { hipLaunchKernelGGL((k_dec_attn<7, true>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq); return; }
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
                        pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq);
 }
