@@ -208,16 +208,20 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_seg(SkwGemmArgs a) {
     const int r16 = lane & 15, kq = lane >> 4;
     const int gn = n0 + r16, gm = mt * 16 + r16;
     const unsigned wbytes = (unsigned)((long)a.N * a.ldw * 2), abytes = (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
+    // fragment-order weight image (SkwGemmArgs::Wf, built for the f16 decode kernels): the same sixteen bytes per lane from one contiguous KiB per (strip, k-block) instead of 16 rows x 64 B —
+    // the values, and so every chain, are unchanged.  (Not for the GELU product: its image holds the rows in the f16 kernels' output order.)
+    const bool wfrag = a.Wf != nullptr && EPI != EPI_GELU_F16_KPERM && !(a.N & 15);
+    const unsigned wstep = wfrag ? 1024u : 64u;
+    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, abytes, 0x00020000);
     const unsigned oob = 0x7fffff00u;
     const int nkq = (a.K >> 5) >> 2, kb_lo = wave * nkq;                 // host guarantees K % 128 == 0
-    const unsigned wo = (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kb_lo * 32 + kq * 8) * 2) : oob;
+    const unsigned wo = wfrag ? (unsigned)(((long)blockIdx.x * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kb_lo * 32 + kq * 8) * 2) : oob;
     const unsigned ao = (gm < a.M) ? (unsigned)(((long)gm * a.lda + kb_lo * 32 + kq * 8) * 2) : oob;
     H8v fw[SM_DEPTH], fa[SM_DEPTH];
 #pragma unroll
     for (int j = 0; j < SM_DEPTH; ++j) {
-        fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nkq) ? oob : wo + j * 64, 0, 0);
+        fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nkq) ? oob : wo + j * wstep, 0, 0);
         fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nkq) ? oob : ao + j * 64, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_seg(SkwGemmArgs a) {
             for (int e = 0; e < 8; ++e) { xa[e] = h2f(fa[j].h[e]); xw[e] = h2f(fw[j].h[e]); }
             __builtin_amdgcn_sched_barrier(0);
             const int nb = kb0 + j + SM_DEPTH;
-            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nkq) ? oob : wo + nb * 64, 0, 0);
+            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nkq) ? oob : wo + nb * wstep, 0, 0);
             fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nkq) ? oob : ao + nb * 64, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kb0 + j < nkq) {                                         // (uniform) blocks past the segment are skipped, not multiplied by zeros
