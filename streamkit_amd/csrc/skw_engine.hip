@@ -450,7 +450,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written)
     WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
     { const size_t R = (size_t)c->rows_cap;
-      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, R * dt, false); WS(dh16, half_t, (R + 16) * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
+      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, (R + 16) * dt, false); WS(dh16, half_t, (R + 16) * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
     WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     if (m->quant) {
@@ -782,6 +782,8 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     // weights once per 16 rows and reach ~50 TF/s at M = 4096, the big kernel 600).  The QKV product keeps the decode form: its epilogue appends to the K / V caches.
     const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !getenv("SKW_PROMPT_SMALL_GEMM");
     static const bool afrag_on = !(getenv("SKW_DEC_AFRAG") && atoi(getenv("SKW_DEC_AFRAG")) == 0);
+    // the attention kernels leave their rows as the fragment-order A image the out-projections read (f16_mfma, small-M kernels on both sides; the cross attention: the one-pass kernel / its multi-query prompt form)
+    const bool sa_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0, xa_frag = sa_frag && c->kv_frag();
     auto gemm_s = [&](const SkwGemmArgs& a) { if (bigM) GEMM(c, a, a.K); else GEMM_S(c, a, a.K); };
     // a GEMM fed by LayerNorm(dx): the normalising form (site >= 0), else LayerNorm kernel + GEMM
     auto gemm_ln = [&](SkwGemmArgs a, const DevLin& Lw, const DevLN& ln, int site, bool normalised) {
@@ -805,8 +807,8 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA); }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.cross_ln); gemm_s(a); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA, sa_frag); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = sa_frag; with_ln(a, L.cross_ln); gemm_s(a); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
         if (!tail && !lnA && !prefill && !c->kv_frag() && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
@@ -818,11 +820,11 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
                 // the prompt pass in the tolerance precision: one read of a sequence's cross K / V^T for up to 128 of its prompt tokens (the encoder attention kernel with the
                 // prompt tokens as queries) instead of one per token — 4.6 MB per row per layer otherwise.  The exact precision keeps the single-query kernel: bit-identical to stepping.
                 ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * 64.0 * H, 4.0 * c->pf_nseq * (double)nc * dt);
-                skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s, c->kv_frag());
+                skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s, c->kv_frag(), xa_frag);
             } else
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b()); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b(), xa_frag); }
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; with_ln(a, L.mlp_ln); gemm_s(a); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = xa_frag && !fused_q; with_ln(a, L.mlp_ln); gemm_s(a); }
         // f16_mfma, small-M kernels on both sides: fc1 leaves its output as the fragment-order A image fc2 reads (fc2 7.4 -> 6.5 us per launch); the prompt pass's big-tile GEMMs keep rows
         const bool h_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; a.c_frag = h_frag; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }

@@ -87,7 +87,7 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
 // fragment-order image of a [N][ldw] f16 weight (N % 16 == 0, K % 32 == 0; perm: rows taken in the kperm'ed output order of the GELU epilogues); out: N * K halves
 void skw_make_wfrag(const half_t* W, long ldw, int N, int K, int perm, half_t* out, hipStream_t s);
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
-                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag = 0);
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag = 0, int ofrag = 0);
 // small-M GEMM (M <= 64): fragments straight from global memory, one 16-column strip per wave
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s);
 
@@ -124,13 +124,13 @@ void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const i
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0},
-                       const int* seq = nullptr, int fastv = 0);      // fastv: the tolerance precision's P.V (16-byte V pieces, per-lane key shares)   // seq (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
+                       const int* seq = nullptr, int fastv = 0, int ofrag = 0);      // ofrag: output as a fragment-order A image (skw_afrag_off); fastv: the tolerance precision's P.V (16-byte V pieces, per-lane key shares)   // seq (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // events: stamped at the kernel's own begin / end (the engine's per-kernel profile)
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int ofrag = 0);   // ofrag (one-pass kernel only): the output rows as the fragment-order A image of the projection that follows; events: stamped at the kernel's own begin / end (the engine's per-kernel profile)
 // the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
 void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s);     // read and discard: warms the Infinity Cache
 bool skw_dec_cross_attn_vt_q_ok(int H, int d);

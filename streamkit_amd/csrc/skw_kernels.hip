@@ -336,6 +336,10 @@ void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
 __device__ __forceinline__ void att_store(half_t* out, long row_off, int col, float v, int f32_out) {
     if (f32_out) ((float*)out)[row_off + col] = v; else out[row_off + skw_kperm(col)] = f2h(v);
 }
+// the decode step's attention outputs when the projection that follows reads a fragment-order A image (SkwGemmArgs::a_frag, skw_afrag_off): fk = its K (0: rows)
+__device__ __forceinline__ void att_store_m(half_t* out, int m, long ldo, int col, float v, int f32_out, int fk) {
+    if (fk && !f32_out) out[skw_afrag_off(m, skw_kperm(col), fk)] = f2h(v); else att_store(out, (long)m * ldo, col, v, f32_out);
+}
 // ------------------------------------------------------------------ LayerNorm
 __device__ __forceinline__ double wave_sum_f64(double v) { return skw_wave_sum_f64(v); }   // DPP + readlane, no LDS crossbar (skw_dev_common.h)
 // one wave per row; d <= 64 NC (NC = 12 for every width up to Whisper-small's, 24 up to 1536); FULL: d == 64 NC (Whisper-small: straight-line code, no tail predicates)
@@ -882,7 +886,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 template <int MAXT, bool FASTV = false>      // FASTV (f16_mfma only): the V rows arrive as 16-byte pieces and each lane sums its own keys' share — see below
 __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, const half_t* kbase, const half_t* vbase, long batch_stride, long ldkv,
                                                   const int* n_kv_ptr, int n_kv_stride, int n_kv_fixed, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwQ8Out q8,
-                                                  const int* seq) {
+                                                  const int* seq, int ofrag_k) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (h >= H) return;
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
         for (int e = 0; e < 8; ++e) { a8[e] += __shfl_xor(a8[e], 8); a8[e] += __shfl_xor(a8[e], 16); a8[e] += __shfl_xor(a8[e], 32); }
         if (kg == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) att_store(out, (long)b * ldo, h * 64 + piece * 8 + e, a8[e], f32_out);
+            for (int e = 0; e < 8; ++e) att_store_m(out, b, ldo, h * 64 + piece * 8 + e, a8[e], f32_out, ofrag_k);
         }
         return;
     }
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
         if ((lane & 31) == 0) { q8.dT[(long)blk * q8.M + b] = dd; q8.sT[(long)blk * q8.M + b] = ss; }
         return;
     }
-    att_store(out, (long)b * ldo, h * 64 + lane, acc, f32_out);
+    att_store_m(out, b, ldo, h * 64 + lane, acc, f32_out, ofrag_k);
 }
 // ------------------------------------------------------------------ decoder cross-attention (K9), bandwidth form
 // Two waves per (sequence, head), three heads per workgroup (12 heads x 64 sequences = 256 workgroups of 6 waves: every CU, 1.5 waves/SIMD).
@@ -1324,7 +1328,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 // and the four partial (m, l, O) meet in LDS at the end (one barrier).  RD blocks (8 KB each) are in flight per wave, 12 waves per CU.
 template <int HPW, int RD, bool FRAG = false, int AUX = 0>      // AUX = 2: the K / V^T loads carry the non-temporal policy (experiment: keep the once-read stream out of the Infinity Cache so that the step's weights stay in it)
 __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cross_attn16(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk, const half_t* vtbase,
-                                                                                         int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, const int* seq) {
+                                                                                         int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, const int* seq, int ofrag_k) {
     typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
     const int b = blockIdx.y;
     if (active && !active[b * active_stride]) return;
@@ -1432,11 +1436,11 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
         float num = 0.0f, den = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float a = __builtin_amdgcn_exp2f((cmb[hs][i][0] - M) * LOG2E); num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }   // an empty quarter: m = -inf, a = 0
-        att_store(out, (long)b * ldo, h * 64 + lane, num / den, f32_out);
+        att_store_m(out, b, ldo, h * 64 + lane, num / den, f32_out, ofrag_k);
     }
 }
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16, const int* seq,
-                           hipEvent_t ev_start, hipEvent_t ev_stop) {
+                           hipEvent_t ev_start, hipEvent_t ev_stop, int ofrag) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     const SkwXQ none{};
@@ -1458,20 +1462,20 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;      // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
         if (pv16 == 2 && x16hpw == 1) {
             const dim3 grid1(H, B), blk1(256);
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2 && x16nt && x16rd != 3) {      // (blocks in flight per wave: 2 / 4, measurement)
-            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
-            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2 && x16nt) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         }
         return;
     }
@@ -1524,16 +1528,16 @@ bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_
     return true;
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv, int ofrag) {
     static const int fastv_env = getenv("SKW_DEC_ATTN_FASTV") ? atoi(getenv("SKW_DEC_ATTN_FASTV")) : 1;
     if (fastv && fastv_env && !q8.q && !f32_out) { hipLaunchKernelGGL((k_dec_attn<7, true>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq); return; }
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq, ofrag ? d : 0); return; }
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
-                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq);
+                       pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq, (ofrag && !q8.q && !f32_out) ? d : 0);
 }
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
     hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, (const int*)nullptr);
+                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, (const int*)nullptr, 0);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)

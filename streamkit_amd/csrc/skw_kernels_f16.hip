@@ -376,7 +376,7 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // XP — the prompt pass's cross attention (skw_engine.hip, prefill): the same kernel with the queries of a SEQUENCE'S prompt tokens (rows row0 .. row0 + nq of the pass, plain
 // [row][d] f16 in natural k order, as the cross-query GEMM leaves them) against that sequence's cross K (plain rows [key][d], natural order: both operands of the score MFMA
 // then agree on which k sits in which slot) and V^T (already this kernel's layout).  One read of a sequence's K / V^T serves up to 128 of its prompt tokens instead of one.
-struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; };   // frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
+struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };   // frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
 template <bool XP>
 __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
                                                            int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) op[skw_kperm(h * 64 + ct * 16 + 4 * g + r)] = (half_t)(oacc[qt][ct][r] * inv);
+                for (int r = 0; r < 4; ++r) { const int pk = skw_kperm(h * 64 + ct * 16 + 4 * g + r); if (XP && xp.ofrag_k) out[skw_afrag_off((int)(qrow0 + qi), pk, xp.ofrag_k)] = (half_t)(oacc[qt][ct][r] * inv); else op[pk] = (half_t)(oacc[qt][ct][r] * inv); }
         }
     }
 }
@@ -538,9 +538,9 @@ void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, ha
 }
 // the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
-                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag) {
+                         int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag, int ofrag) {
     const int qblocks = (nq_max + A16_QB - 1) / A16_QB;
-    const SkwXPrefill xp{row0, nq, slot, (long)d, (long)(frag ? Tpad : n_ctx) * d, (long)d, frag};
+    const SkwXPrefill xp{row0, nq, slot, (long)d, (long)(frag ? Tpad : n_ctx) * d, (long)d, frag, ofrag ? d : 0};
     hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp);
 }
 
