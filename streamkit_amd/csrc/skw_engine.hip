@@ -1326,6 +1326,7 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     const bool small = M <= 64;                                      // the decode-step form: a chain of dependent launches, so the figure includes the kernel boundary
     if (small && epi == EPI_DEC_QKV) { a.C2 = res; a.C3 = res; a.ldc2 = N; a.n_ctx = N / 3; a.ldc = N / 3; }
+    if (small && (probe & 64) && !(M & 15)) { a.a_frag = 1; a.probe &= ~64; }      // probe bit 6 (decode shapes, timing only): the activations addressed as a fragment-order image
     half_t* Wfrag = nullptr;      // probe bit 5 (decode shapes): the weights as fragment-order images (one per W copy of the cycle), what the step's launches read
     if (small && (probe & 32) && !(N & 15)) { HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2 * wcycle)); for (int w = 0; w < wcycle; ++w) skw_make_wfrag(W + (size_t)w * N * K, K, N, K, epi == EPI_GELU_F16_KPERM, Wfrag + (size_t)w * N * K, c->stream); a.Wf = Wfrag; a.probe &= ~32; }
     for (int i = 0; i < 3; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }

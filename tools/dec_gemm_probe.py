@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a decode-step GEMM launch (k_gemm16_small, 64 rows) spend its time?  Chains of dependent launches of the decoder's shapes
-with parts switched off (skw_debug_gemm16 with M <= 64: 1 = no weight loads, 2 = no activation loads, 4 = no exchange/epilogue, 8 = no stores; for the vocabulary kernel 1 / 2 / 8 likewise and 16 = the strip kernel instead).
+with parts switched off (skw_debug_gemm16 with M <= 64: 1 = no weight loads, 2 = no activation loads, 4 = no exchange/epilogue, 8 = no stores, 32 = weights as a fragment-order image, 64 = activations addressed as one; for the vocabulary kernel 1 / 2 / 8 likewise and 16 = the strip kernel instead).
 usage: python tools/dec_gemm_probe.py"""
 import ctypes as C
 import os
