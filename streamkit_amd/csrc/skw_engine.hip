@@ -492,6 +492,18 @@ static std::map<std::string, std::vector<float>> g_taps; static bool g_taps_on =
 extern "C" long skw_layout_kfrag_off(int slot, int H, int Tpad, int key, int feat) { return skw_kfrag_off(slot, H, Tpad, key, feat); }
 extern "C" long skw_layout_vtfrag_off(int slot, int H, int Tpad, int feat, int pos) { return skw_vtfrag_off(slot, H, Tpad, feat, pos); }
 extern "C" int skw_layout_kperm(int k) { return skw_kperm(k); }
+extern "C" long skw_layout_afrag_off(int m, int p, int K) { return skw_afrag_off(m, p, K); }
+// tests: the fragment-order image of a host weight [N][K] (f16 bits), as the decode kernels read it (skw_make_wfrag)
+extern "C" int skw_debug_make_wfrag(const uint16_t* w_host, int N, int K, int perm, uint16_t* img_host) {
+    if (N <= 0 || K <= 0 || (K & 31)) return -1;
+    const size_t n_in = (size_t)N * K, n_out = (size_t)((N + 15) & ~15) * K;
+    half_t *dw = nullptr, *di = nullptr;
+    if (hipMalloc((void**)&dw, n_in * 2) != hipSuccess || hipMalloc((void**)&di, n_out * 2) != hipSuccess) { hipFree(dw); hipFree(di); return -2; }
+    int rc = 0;
+    if (hipMemcpy(dw, w_host, n_in * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemset(di, 0xff, n_out * 2) != hipSuccess) rc = -3;
+    if (!rc) { skw_make_wfrag(dw, K, N & ~15, K, perm, di, nullptr); if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img_host, di, (size_t)(N & ~15) * K * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = -4; }
+    hipFree(dw); hipFree(di); return rc;
+}
 extern "C" void skw_debug_set_kv_frag(skw_ctx* c, int on) { c->kv_frag_on = on != 0; }                // tests: f16_mfma cross K / V^T as fragment-order images (one-pass cross attention) / as rows (two-phase kernel); takes effect at the next encoder pass
 extern "C" void skw_debug_set_prompt_pass(skw_ctx* c, int on) { c->prompt_pass_on = on != 0; }     // tests: the prompt as one pass / one token per step
 extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)

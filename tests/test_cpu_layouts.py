@@ -66,3 +66,22 @@ def test_score_accumulator_order_is_the_stored_key_order(L):
                 i = 4 * g + r
                 key_from_scores = 16 * j + 4 * (i & 3) + (i >> 2)
                 assert key_from_scores == inv[8 * g + 4 * j + r]
+
+
+def test_activation_image_offsets(L):
+    # skw_afrag_off: the fc1 -> fc2 hand-over and the attention outputs (SkwGemmArgs::c_frag / a_frag): a row tile's 32-k block is one KiB, lane r16 + 16 g holds row 16 t + r16, positions 8 g .. 8 g + 7
+    L.skw_layout_afrag_off.restype = C.c_long; L.skw_layout_afrag_off.argtypes = [C.c_int] * 3
+    K = 3072
+    seen = set()
+    for m in range(0, 48):
+        for p in range(0, K, 4):
+            o = L.skw_layout_afrag_off(m, p, K)
+            assert o % 4 == 0 and 0 <= o < 48 * K and o not in seen
+            seen.add(o)
+    for t in (0, 2):
+        for kb in (0, 5, 95):
+            base = (t * (K // 32) + kb) * 512
+            for lane in range(64):
+                r16, g = lane & 15, lane >> 4
+                assert L.skw_layout_afrag_off(16 * t + r16, 32 * kb + 8 * g, K) == base + lane * 8
+                assert L.skw_layout_afrag_off(16 * t + r16, 32 * kb + 8 * g + 4, K) == base + lane * 8 + 4

@@ -322,3 +322,25 @@ def test_cross_kv_layouts_agree(eng, tiny_model_path, small_model_path):
         print("cross K/V as fragment images vs rows, %s: max logit difference %.3g (range %.3g)" % (os.path.basename(path), err, rng))
         assert err < TOL_LOGIT_REL * rng and err < LOGIT_ERR_BOUND
         ctx.close(); m.close()
+
+
+@pytest.mark.parametrize("N,K,perm", [(768, 768, 0), (3072, 768, 1), (768, 3072, 0), (2304, 384, 0)])
+def test_weight_image_is_the_documented_permutation(eng, N, K, perm):
+    """skw_make_wfrag (the decode GEMMs' fragment-order weight images): per 16-row strip s and 32-k block kb one KiB, lane r16 + 16 g = eight halves W[row(16 s + r16)][32 kb + 8 g ..];
+    perm: the rows in the GELU epilogues' output order (skw_kperm's inverse inside each 32)."""
+    import ctypes as C
+    L = eng.lib()
+    L.skw_debug_make_wfrag.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.skw_layout_kperm.restype = C.c_int; L.skw_layout_kperm.argtypes = [C.c_int]
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 65536, size=(N, K), dtype=np.uint16)
+    img = np.empty(N * K, dtype=np.uint16)
+    assert L.skw_debug_make_wfrag(w.ctypes.data, N, K, perm, img.ctypes.data) == 0
+    inv = np.empty(32, dtype=np.int64)
+    for k in range(32):
+        inv[L.skw_layout_kperm(k)] = k
+    n = np.arange(N)
+    rows = ((n & ~31) | inv[n & 31]) if perm else n
+    # expected[s, kb, g, r16, e] = w[rows[16 s + r16], 32 kb + 8 g + e]  ->  image order [s][kb][lane = r16 + 16 g][e]
+    exp = w[rows].reshape(N // 16, 16, K // 32, 4, 8).transpose(0, 2, 3, 1, 4).reshape(-1)
+    assert np.array_equal(img, exp)
