@@ -715,6 +715,7 @@ static void compute_logprobs(const float* logits, int n, float* logprobs) {
     for (int i = 0; i < n; ++i) logprobs[i] = (logits[i] > -INFINITY) ? logits[i] - logsumexp : -INFINITY;
 }
 
+static int g_dbg_no_mass_rule = 0;   /* test hook only (skwo_debug_process_logits flag 1): leaves the timestamp-mass rule out so the index rules can be compared on their own */
 static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t* dc, const float* raw_logits, float* no_speech_prob, float temperature) {
     const int n_logits = m->hp.n_vocab; float* logits = dc->logits; float* logprobs = dc->logprobs; float* probs = dc->probs;
     const int is_initial = dc->n_tokens == 0;
@@ -759,7 +760,7 @@ static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t*
             if (acc > 0.0) timestamp_logprob = skw_logf((float)acc) + logprob_max;
         }
         float max_text = -INFINITY; for (int i = 0; i < m->tok_beg; ++i) if (logprobs[i] > max_text) max_text = logprobs[i];
-        if (timestamp_logprob > max_text) for (int i = 0; i < m->tok_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
+        if (timestamp_logprob > max_text && !g_dbg_no_mass_rule) for (int i = 0; i < m->tok_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
     }
     for (int i = 0; i < n_logits; ++i) probs[i] = (logits[i] == -INFINITY) ? 0.0f : skw_expf(logprobs[i]);
 }
@@ -822,6 +823,53 @@ static skwo_token sample_dist(const skwo_model* m, decoder_t* dc, mt19937_t* rng
     r.id = discrete_draw(probs, n, rng); r.p = probs[r.id]; r.plog = dc->logprobs[r.id];
     if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }
     return r;
+}
+
+/* test hook: ONE call of whisper_process_logits + whisper_sample_token(best = true) on caller-supplied logits, for a decoder whose tokens
+ * sampled so far in this window are hist[0 .. n_hist).  has_ts / seek_delta / result_len follow from the history by the update rule of
+ * whisper_full_with_state's token loop (above), so the history must be one that loop can produce (timestamps never decrease).
+ * flags bit 0: leave the timestamp-mass rule out.  out_logits: the filtered logits (-inf = suppressed).  Pinned against an independent
+ * implementation of the same rules (transformers' Whisper logits processors) by tests/test_cpu_logit_rules.py. */
+int skwo_debug_process_logits(const skwo_model* m, const skwo_params* p, const int32_t* hist, int n_hist, const float* raw_logits, float temperature, int flags,
+                              float* out_logits, float* out_logprobs, skwo_token* chosen, float* no_speech_prob) {
+    const int NV = m->hp.n_vocab;
+    decoder_t dc; memset(&dc, 0, sizeof dc);
+    dc.logits = xmalloc_f(NV); dc.logprobs = xmalloc_f(NV); dc.probs = xmalloc_f(NV); dc.cap = n_hist + 1; dc.tokens = (skwo_token*)calloc(dc.cap, sizeof(skwo_token)); dc.min_margin = INFINITY;
+    dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; dc.has_ts = 0;
+    for (int i = 0; i < n_hist; ++i) {
+        dc.tokens[i].id = hist[i]; dc.n_tokens = i + 1;
+        if (hist[i] > m->tok_beg) {
+            const int sd = 2 * (hist[i] - m->tok_beg);
+            if (dc.has_ts && dc.seek_delta > sd && dc.result_len < i) { free(dc.logits); free(dc.logprobs); free(dc.probs); free(dc.tokens); return -1; }   /* the loop would have failed here */
+            dc.seek_delta = sd; dc.result_len = i + 1; dc.has_ts = 1;
+        }
+    }
+    float nsp = 0.0f;
+    g_dbg_no_mass_rule = flags & 1;
+    process_logits(m, p, &dc, raw_logits, &nsp, temperature);
+    g_dbg_no_mass_rule = 0;
+    if (out_logits) memcpy(out_logits, dc.logits, sizeof(float) * NV);
+    if (out_logprobs) memcpy(out_logprobs, dc.logprobs, sizeof(float) * NV);
+    if (chosen) *chosen = sample_best(m, &dc);
+    if (no_speech_prob) *no_speech_prob = nsp;
+    free(dc.logits); free(dc.logprobs); free(dc.probs); free(dc.tokens);
+    return 0;
+}
+/* the ids the static suppression rules name, for the checker's side of the comparison: kind 0 = specials (not, sot, nosp, solm, translate, transcribe, prev, languages),
+ * 1 = the non-speech list (suppress_nst), 2 = the blank rule's pair (eot, " ").  Returns the count (ids may be NULL). */
+int skwo_debug_rule_ids(const skwo_model* m, int kind, int32_t* ids, int cap) {
+    int n = 0;
+#define PUSH(x) do { if ((x) >= 0) { if (ids && n < cap) ids[n] = (x); n++; } } while (0)
+    if (kind == 0) {
+        PUSH(m->tok_not); PUSH(m->tok_sot); PUSH(m->tok_nosp); PUSH(m->tok_solm); PUSH(m->tok_translate); PUSH(m->tok_transcribe); PUSH(m->tok_prev);
+        const int n_lang = N_LANG + (m->hp.n_vocab - 51865 > 0 ? m->hp.n_vocab - 51865 : 0); for (int i = 0; i < n_lang; ++i) PUSH(m->tok_sot + 1 + i);
+    } else if (kind == 1) {
+        for (int i = 0; i < m->n_nst; ++i) PUSH(m->nst_ids[i]);
+        PUSH(m->tok_sp_dash); PUSH(m->tok_sp_quote);
+    } else if (kind == 2) { PUSH(m->tok_eot); PUSH(m->tok_space); }
+    else if (kind == 3) { PUSH(m->tok_eot); PUSH(m->tok_not); PUSH(m->tok_beg); PUSH(m->tok_nosp); PUSH(m->tok_sot); }
+#undef PUSH
+    return n;
 }
 
 static void sequence_score(decoder_t* dc) {

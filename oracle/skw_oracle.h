@@ -112,6 +112,13 @@ int skwo_full(const skwo_model*, const skwo_params*, const float* pcm, int n_sam
 /* test hook: n_draws of std::discrete_distribution<>(probs, probs + n) from std::mt19937(seed), as restated in skw_oracle.c */
 int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, int32_t* out);
 void skwo_result_free(skwo_result*);
+/* test hooks for the K11 rules on their own (tests/test_cpu_logit_rules.py, tests/golden/make_logit_rule_goldens.py): one call of
+ * whisper_process_logits + whisper_sample_token(best) on caller-supplied logits for the decoder history hist[0..n_hist); flags bit 0
+ * leaves the timestamp-mass rule out; -1 if the token loop could not have produced the history */
+int skwo_debug_process_logits(const skwo_model*, const skwo_params*, const int32_t* hist, int n_hist, const float* raw_logits, float temperature, int flags,
+                              float* out_logits, float* out_logprobs, skwo_token* chosen, float* no_speech_prob);
+/* kind 0: always-suppressed specials; 1: the suppress_nst list; 2: the blank rule's pair; 3: {eot, notimestamps, timestamp_begin, nospeech, sot} */
+int skwo_debug_rule_ids(const skwo_model*, int kind, int32_t* ids, int cap);
 
 /* teacher-forced logits (for margin diagnostics): runs window at `seek` with given token prefix */
 

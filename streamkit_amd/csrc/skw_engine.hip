@@ -887,6 +887,21 @@ static void build_static_mask(skw_ctx* c, const skw_full_params* p) {
     c->static_mask_nst = p->suppress_nst ? 1 : 0;
 }
 
+// the sampler's view of the model's special tokens and of the whisper_full_params that shape whisper_process_logits
+static SkwLogitParams make_logit_params(const skw_model* m, const skw_full_params* p) {
+    const skw_hparams& hp = m->hp;
+    SkwLogitParams lp{};
+    lp.n_vocab = hp.n_vocab;
+    lp.tok_eot = m->tok_eot; lp.tok_sot = m->tok_sot; lp.tok_translate = m->tok_translate; lp.tok_transcribe = m->tok_transcribe; lp.tok_solm = m->tok_solm;
+    lp.tok_prev = m->tok_prev; lp.tok_nosp = m->tok_nosp; lp.tok_not = m->tok_not; lp.tok_beg = m->tok_beg;
+    lp.n_lang = m->n_lang; lp.tok_space = m->tok_space; lp.tok_sp_dash = m->tok_sp_dash; lp.tok_sp_quote = m->tok_sp_quote;
+    lp.suppress_blank = p->suppress_blank; lp.suppress_nst = p->suppress_nst; lp.no_timestamps = p->no_timestamps; lp.single_segment = p->single_segment; lp.max_tokens = p->max_tokens;
+    lp.tid0_initial = -1;
+    if (p->max_initial_ts > 0.0f) { const float precision = (float)WHISPER_CHUNK_SIZE / hp.n_audio_ctx; lp.tid0_initial = (int)roundf(p->max_initial_ts / precision); }
+    lp.n_max = hp.n_text_ctx / 2 - 4;
+    return lp;
+}
+
 struct SeqAcc { std::vector<skw_segment> seg; std::vector<skw_token> tok; std::string text; };
 
 // whisper_sequence_score: avg_logprobs + entropy of the last 32 tokens
@@ -1003,12 +1018,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
     prompt[n_prompt++] = m->tok_sot;
     if (NV >= 51865) { prompt[n_prompt++] = -1 /* per row: sot + 1 + lang[clip] */; prompt[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
     if (p->no_timestamps) prompt[n_prompt++] = m->tok_not;
-    SkwLogitParams lp{}; lp.n_vocab = NV; lp.tok_eot = m->tok_eot; lp.tok_sot = m->tok_sot; lp.tok_translate = m->tok_translate; lp.tok_transcribe = m->tok_transcribe; lp.tok_solm = m->tok_solm;
-    lp.tok_prev = m->tok_prev; lp.tok_nosp = m->tok_nosp; lp.tok_not = m->tok_not; lp.tok_beg = m->tok_beg; lp.n_lang = m->n_lang; lp.tok_space = m->tok_space; lp.tok_sp_dash = m->tok_sp_dash; lp.tok_sp_quote = m->tok_sp_quote;
-    lp.suppress_blank = p->suppress_blank; lp.suppress_nst = p->suppress_nst; lp.no_timestamps = p->no_timestamps; lp.single_segment = p->single_segment; lp.max_tokens = p->max_tokens;
-    lp.tid0_initial = -1;
-    if (p->max_initial_ts > 0.0f) { const float precision = (float)WHISPER_CHUNK_SIZE / hp.n_audio_ctx; lp.tid0_initial = (int)roundf(p->max_initial_ts / precision); }
-    lp.n_max = hp.n_text_ctx / 2 - 4;
+    SkwLogitParams lp = make_logit_params(m, p);
 
     while (true) {
         // clips that still have audio to decode ("if only 100ms left, then stop"; "input is too short": delta_min = 10 frames, whisper.cpp #2065)
@@ -1230,6 +1240,61 @@ extern "C" int skw_full_batch_traced(skw_ctx* c, const skw_full_params* p, const
         }
         return 0;
     } catch (const std::exception& e) { snprintf(c->errbuf, 512, "skw_full_batch_traced: %s", e.what()); return -5; }
+}
+// Test hook (tests/test_gpu_logit_rules.py): K11 on its own.  n_rows decoders whose tokens sampled so far in their window are hist[r][0 .. n_hist[r]) meet
+// caller-supplied logits; ONE launch of the sampler (form 0: the one the decode step uses; form 1: the streaming kernel, which leaves the filtered row in
+// memory) makes each row's next decision.  has_ts / seek_delta / result_len are replayed from the history by the token loop's update rule, as
+// oracle/skwo_debug_process_logits does.  Outputs per row: the decision (skw_token), its trace record, and (form 1, optional) the filtered logits.
+extern "C" int skw_debug_sample_rows(skw_ctx* c, const skw_full_params* p, int n_rows, const int32_t* hist, int hist_stride, const int32_t* n_hist, const float* logits_host, int form,
+                                     float* filtered_out, skw_token* tok_out, skw_trace_step* trace_out) {
+    char* errbuf = c->errbuf; errbuf[0] = 0;
+    if (n_rows < 1 || n_rows > c->max_batch) { snprintf(errbuf, 512, "n_rows %d outside [1, %d]", n_rows, c->max_batch); return -1; }
+    HIPCHK(hipSetDevice(c->m->device));
+    const skw_model* m = c->m; const int NV = m->hp.n_vocab, MT = c->max_tok;
+    for (int r = 0; r < n_rows; ++r) if (n_hist[r] < 0 || n_hist[r] >= MT || n_hist[r] > hist_stride) { snprintf(errbuf, 512, "row %d: history of %d tokens (at most %d)", r, n_hist[r], MT - 1); return -1; }
+    if (!c->trace_dev) {
+        int* f = nullptr; SkwTraceStep* t = nullptr;
+        if (hipMalloc((void**)&f, sizeof(int) * (size_t)c->max_batch * MT) != hipSuccess || hipMalloc((void**)&t, sizeof(SkwTraceStep) * (size_t)c->max_batch * MT) != hipSuccess) {
+            hipFree(f); snprintf(errbuf, 512, "trace buffers: device allocation failed"); return -1; }
+        c->forced_dev = f; c->trace_dev = t;
+    }
+    build_static_mask(c, p);
+    SkwLogitParams lp = make_logit_params(m, p); lp.any_sampled = 0;
+    std::vector<SkwTokenOut> toks((size_t)n_rows * MT); memset(toks.data(), 0, toks.size() * sizeof(SkwTokenOut));
+    std::vector<int> forced((size_t)n_rows * MT, -1), zero(n_rows, 0);
+    for (int r = 0; r < n_rows; ++r) {
+        SkwSeqState& s = c->h_st[r]; memset(&s, 0, sizeof s);
+        s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = 0; s.seek_end = 100 * WHISPER_CHUNK_SIZE; s.n_prompt = 1; s.min_margin = INFINITY; s.cur_pos = n_hist[r]; s.n_tokens = n_hist[r];
+        for (int i = 0; i < n_hist[r]; ++i) {
+            const int id = hist[(size_t)r * hist_stride + i]; toks[(size_t)r * MT + i].id = id;
+            if (id > m->tok_beg) {
+                const int sd = 2 * (id - m->tok_beg);
+                if (s.has_ts && s.seek_delta > sd && s.result_len < i) { snprintf(errbuf, 512, "row %d: the token loop cannot produce this history (timestamp goes backwards at %d)", r, i); return -1; }
+                s.seek_delta = sd; s.result_len = i + 1; s.has_ts = 1;
+            }
+        }
+        c->h_row_live[r] = 1;
+    }
+    HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->toks, toks.data(), sizeof(SkwTokenOut) * toks.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->forced_dev, forced.data(), sizeof(int) * forced.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->clip_idx, zero.data(), sizeof(int) * n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->logits, logits_host, sizeof(float) * (size_t)n_rows * NV, hipMemcpyHostToDevice, c->stream));
+    skw_debug_force_stream_sampler(form == 1);
+    skw_dec_sample(c->logits, c->static_mask, lp, c->st, c->toks, MT, n_rows, c->d_row_live, c->probs, c->rng, c->clip_idx, c->prompt_buf, c->stream, c->forced_dev, c->trace_dev);
+    skw_debug_force_stream_sampler(0);
+    HIPCHK(hipGetLastError());
+    std::vector<SkwTraceStep> tr((size_t)n_rows * MT);
+    HIPCHK(hipMemcpyAsync(toks.data(), c->toks, sizeof(SkwTokenOut) * toks.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(tr.data(), c->trace_dev, sizeof(SkwTraceStep) * tr.size(), hipMemcpyDeviceToHost, c->stream));
+    if (filtered_out) HIPCHK(hipMemcpyAsync(filtered_out, c->logits, sizeof(float) * (size_t)n_rows * NV, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < n_rows; ++r) {
+        const SkwTokenOut& t = toks[(size_t)r * MT + n_hist[r]];
+        if (tok_out) { skw_token o; o.id = t.id; o.tid = t.tid; o.p = t.p; o.plog = t.plog; o.pt = t.pt; o.ptsum = t.ptsum; o.margin = t.margin; tok_out[r] = o; }
+        if (trace_out) memcpy(&trace_out[r], &tr[(size_t)r * MT + n_hist[r]], sizeof(skw_trace_step));
+    }
+    return 0;
 }
 extern "C" void skw_trace_free(skw_trace* t) { if (!t) return; free(t->steps); t->steps = nullptr; t->n = 0; }
 extern "C" void skw_result_free(skw_result* r) { if (!r) return; free(r->segments); free(r->tokens); free(r->text); memset(r, 0, sizeof *r); }

@@ -183,6 +183,7 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s,
                     const int* forced = nullptr /* [B][max_tok]: token to feed after decision i instead of the chosen one (< 0: the chosen one) */, SkwTraceStep* trace = nullptr /* [B][max_tok] */);
+void skw_debug_force_stream_sampler(int on);   // tests: the streaming sampler (filters the logits row in place) even where the register-resident form applies
 void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   // std::mt19937(seed) for every clip
 
 // ---------------- resampler (R1) ----------------

@@ -2056,9 +2056,11 @@ void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out) {
     unsigned long long* kw = (unsigned long long*)(out + ((n_vocab + 15) & ~15));
     for (int i = 0; i < n_vocab && i < SMP_PT * SMP_NT; ++i) if (mask[i]) { const int t = i % SMP_NT, c = i / SMP_NT; kw[(c >> 6) * SMP_NT + t] |= 1ull << (c & 63); }
 }
+static int g_force_stream_sampler = 0;      // tests: run the streaming form where the register-resident one would (it leaves the filtered row in memory)
+void skw_debug_force_stream_sampler(int on) { g_force_stream_sampler = on; }
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s, const int* forced, SkwTraceStep* trace) {
-    if (p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) {
+    if (!g_force_stream_sampler && p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) {
         if (trace) hipLaunchKernelGGL((k_dec_sample<true, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
         else if (p.any_sampled) hipLaunchKernelGGL((k_dec_sample<false, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
         else hipLaunchKernelGGL((k_dec_sample<false, false>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);

@@ -111,6 +111,7 @@ def lib():
         L.skw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
         L.skw_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.skw_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        L.skw_debug_sample_rows.argtypes = [C.c_void_p, C.POINTER(FullParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.skw_debug_enable.argtypes = [C.c_int]
         L.skw_debug_get.restype = C.c_long
         L.skw_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
@@ -280,6 +281,25 @@ class Context:
         out = np.empty(self.model.hp.n_vocab, dtype=np.float32)
         self._check(lib().skw_decode_logits(self.h, t.ctypes.data, t.size, out.ctypes.data))
         return out
+
+    def sample_rows(self, hists, logits, params=None, form=0, want_filtered=False):
+        """K11 on its own (skw_debug_sample_rows): one sampler launch decides the next token of len(hists) decoders whose sampled tokens so far are
+        hists[r], on caller-supplied logits [rows][n_vocab].  form 0: the decode step's sampler; 1: the streaming kernel (leaves the filtered row
+        in memory: want_filtered).  -> (tokens structured array, trace records, filtered logits or None)"""
+        p = params or self.default_params()
+        R = len(hists)
+        stride = max(1, max(len(h) for h in hists))
+        hb = np.zeros((R, stride), dtype=np.int32)
+        for r, h in enumerate(hists):
+            hb[r, :len(h)] = h
+        nh = np.array([len(h) for h in hists], dtype=np.int32)
+        lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(R, self.model.hp.n_vocab)
+        filt = np.empty_like(lg) if want_filtered else None
+        toks = np.zeros(R, dtype=_TOKEN_DT)
+        tr = np.zeros(R, dtype=TRACE_DT)
+        self._check(lib().skw_debug_sample_rows(self.h, C.byref(p), R, hb.ctypes.data, stride, nh.ctypes.data, lg.ctypes.data, int(form),
+                                                filt.ctypes.data if want_filtered else None, toks.ctypes.data, tr.ctypes.data))
+        return toks, tr, filt
 
     def math(self, kind, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
