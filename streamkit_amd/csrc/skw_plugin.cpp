@@ -112,19 +112,28 @@ struct Job {
     std::vector<float> pcm; skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
 };
 struct SharedEngine {
-    skw_model* model = nullptr; skw_ctx* ctx = nullptr; int max_batch = 64; int window_ms = 2; int max_samples = 0; int precision = SKW_PRECISION_EXACT;
+    skw_model* model = nullptr;
+    skw_ctx* ctx = nullptr;
+    int max_batch = 0;          // rows the workspace was created for
+    int max_samples = 0;        // samples per row the workspace was created for
+    int batch_limit = 64;       // scheduler: largest batch formed (the max_batch param of the instance created most recently; under mu)
+    int window_ms = 2;          // scheduler: how long a batch waits for more jobs (batch_window_ms of the instance created most recently; under mu)
+    int precision = SKW_PRECISION_EXACT;
     static const int kMaxSamples = 16000 * 121;   // schema maximum of max_segment_duration_secs (120 s) + one VAD frame of slack: no segment is longer
     static int samples_for(float max_segment_secs) { const double s = std::min(120.0, std::max(1.0, (double)max_segment_secs)); return std::min(kMaxSamples, (int)std::ceil(s * 16000.0) + 1024); }
-    // The workspace is sized for the longest segment an instance of this engine can cut (its max_segment_duration_secs), not for the schema's
-    // maximum: 31 s by default instead of 121 (0.2 GB instead of 0.8 at 64 rows).  An instance that allows longer segments grows it, between batches.
-    bool ensure_samples(int need, std::string* err) {
-        if (need <= max_samples) return true;
+    // The workspace is sized for the longest segment an instance of this engine can cut (its max_segment_duration_secs) and the largest batch one asked
+    // for, not for the schema's maxima: 31 s by default instead of 121 (0.2 GB instead of 0.8 at 64 rows).  An instance that allows longer segments or
+    // larger batches grows it, between batches (the engine outlives its instances: lib.rs:170-180).
+    bool ensure_workspace(int need_samples, int need_batch, std::string* err) {
+        if (need_samples <= max_samples && need_batch <= max_batch) return true;
+        const int ns = std::max(need_samples, max_samples), nb = std::max(need_batch, max_batch);
         char ebuf[512] = {0};
-        skw_ctx* nc = skw_ctx_create(model, max_batch, need, ebuf, sizeof ebuf);
+        if (ctx) { skw_ctx_free(ctx); ctx = nullptr; max_samples = 0; max_batch = 0; }      // release first: two workspaces need not fit side by side
+        skw_ctx* nc = skw_ctx_create(model, nb, ns, ebuf, sizeof ebuf);
         if (!nc) { *err = std::string("Failed to create Whisper state: ") + ebuf; return false; }
         skw_ctx_set_precision(nc, precision);
-        if (ctx) skw_ctx_free(ctx);
-        ctx = nc; max_samples = need; return true;
+        ctx = nc; max_samples = ns; max_batch = nb;
+        return true;
     }
     std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<Job>> queue; bool stop = false; std::thread worker;
     ~SharedEngine() {
@@ -140,8 +149,8 @@ struct SharedEngine {
                 if (stop && queue.empty()) return;
                 // batch formation: give concurrent instances a short window to join
                 auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(window_ms);
-                while ((int)queue.size() < max_batch && !stop) { if (cv.wait_until(l, deadline) == std::cv_status::timeout) break; }
-                while (!queue.empty() && (int)batch.size() < max_batch) {
+                while ((int)queue.size() < batch_limit && !stop) { if (cv.wait_until(l, deadline) == std::cv_status::timeout) break; }
+                while (!queue.empty() && (int)batch.size() < batch_limit) {
                     // one skw_full_batch call shares its params: group by the params of the first job
                     if (!batch.empty() && memcmp(&batch[0]->params, &queue.front()->params, sizeof(skw_full_params)) != 0) break;
                     batch.push_back(queue.front()); queue.pop_front();
@@ -152,7 +161,7 @@ struct SharedEngine {
             try {
                 std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n); int need = 0;
                 for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->pcm.data(); ns[i] = (int32_t)batch[i]->pcm.size(); need = std::max(need, (int)ns[i]); }
-                if (ensure_samples(need, &why)) {
+                if (ensure_workspace(need, n, &why)) {
                     rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
                     if (rc == 0) for (int i = 0; i < n; ++i) batch[i]->result = res[i]; else why = skw_ctx_last_error(ctx);
                 }
@@ -161,27 +170,21 @@ struct SharedEngine {
         }
     }
 };
-std::mutex g_cache_mu;
-std::map<std::string, std::weak_ptr<SharedEngine>> g_cache;   // weak: the model is released when the last instance goes away
+// WHISPER_CONTEXT_CACHE (lib.rs:170-180): process-global, STRONG references — an entry lives until the library is unloaded or the process exits, so a
+// prewarmed model (apps/skit/src/plugins.rs:265-306: "Node is dropped immediately, but ... model loading via Arc persist") and every Oneshot request after
+// the first find it loaded.  What is cached here is the whole SharedEngine: the weights with their device images, the batch workspace (the reference's
+// per-instance WhisperState has no counterpart: instances share one batched context) and the scheduler thread.
+// The map is a function-local static constructed after the HIP runtime is up (skw_device_count makes the first HIP call), so that at process exit it is
+// destroyed — workers joined, device memory released — before the runtime's own teardown; a dlclose of the plugin runs the same destructor.
+struct EngineCache {
+    std::mutex mu;
+    std::map<std::string, std::shared_ptr<SharedEngine>> map;
+};
+EngineCache& engine_cache() { (void)skw_device_count(); static EngineCache c; return c; }
+std::atomic<int> g_model_loads{0}, g_cache_hits{0};
 
-std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, std::string* err) {
-    char keybuf[96]; snprintf(keybuf, sizeof keybuf, "|%d|%d|%s", cfg.use_gpu ? 1 : 0, cfg.gpu_device, cfg.precision.c_str());   // the reference's key (path, use_gpu, gpu_device) + the additive precision
-    const std::string key = cfg.model_path + keybuf;
-    std::lock_guard<std::mutex> l(g_cache_mu);
-    auto it = g_cache.find(key);
-    if (it != g_cache.end()) if (auto sp = it->second.lock()) return sp;
-    char ebuf[512] = {0};
-    auto eng = std::make_shared<SharedEngine>();
-    eng->model = skw_model_load(cfg.model_path.c_str(), cfg.gpu_device, ebuf, sizeof ebuf);
-    if (!eng->model) { *err = ebuf[0] ? ebuf : ("Failed to load Whisper model from '" + cfg.model_path + "'"); return nullptr; }
-    eng->max_batch = cfg.max_batch; eng->window_ms = cfg.batch_window_ms;
-    eng->precision = cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT;
-    if (!eng->ensure_samples(SharedEngine::samples_for(cfg.max_segment_duration_secs), err)) return nullptr;
-    eng->worker = std::thread([e = eng.get()] { e->run(); });
-    g_cache[key] = eng;
-    return eng;
-}
-
+struct WhisperPlugin;
+std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, WhisperPlugin* who, std::string* err);
 // gpu_device: "auto" (additive): instance k of the process runs on GPU k mod n_gpus — one SharedEngine (model copy + batch scheduler)
 // per device, which is how the reference's docs spread pipelines over GPUs by hand (docs/.../deployment/gpu.md:64-66)
 std::atomic<unsigned> g_auto_rr{0};
@@ -202,22 +205,58 @@ struct WhisperPlugin {
     }
 };
 
-// Silero gate behind the segmenter's Vad interface; the weights of one file are shared by every instance that names it
+std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, WhisperPlugin* who, std::string* err) {
+    char keybuf[96];
+    snprintf(keybuf, sizeof keybuf, "|%d|%d|%s", cfg.use_gpu ? 1 : 0, cfg.gpu_device, cfg.precision.c_str());   // the reference's key (path, use_gpu, gpu_device) + the additive precision
+    const std::string key = cfg.model_path + keybuf;
+    EngineCache& cache = engine_cache();
+    std::lock_guard<std::mutex> l(cache.mu);
+    auto it = cache.map.find(key);
+    if (it != cache.map.end()) {
+        g_cache_hits.fetch_add(1);
+        { std::lock_guard<std::mutex> le(it->second->mu); it->second->batch_limit = cfg.max_batch; it->second->window_ms = cfg.batch_window_ms; }      // additive scheduler params: the most recent instance's
+        if (who) who->log(SK_LOG_INFO, "CACHE HIT: Reusing cached Whisper context (model_path=%s, gpu_device=%d, precision=%s)", cfg.model_path.c_str(), cfg.gpu_device, cfg.precision.c_str());
+        return it->second;
+    }
+    if (who) who->log(SK_LOG_INFO, "CACHE MISS: Loading Whisper model (model_path=%s, gpu_device=%d, precision=%s)", cfg.model_path.c_str(), cfg.gpu_device, cfg.precision.c_str());
+    char ebuf[512] = {0};
+    auto eng = std::make_shared<SharedEngine>();
+    const auto t0 = std::chrono::steady_clock::now();
+    eng->model = skw_model_load(cfg.model_path.c_str(), cfg.gpu_device, ebuf, sizeof ebuf);
+    if (!eng->model) { *err = ebuf[0] ? ebuf : ("Failed to load Whisper model from '" + cfg.model_path + "'"); return nullptr; }
+    g_model_loads.fetch_add(1);
+    const auto t1 = std::chrono::steady_clock::now();
+    eng->batch_limit = cfg.max_batch;
+    eng->window_ms = cfg.batch_window_ms;
+    eng->precision = cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT;
+    if (!eng->ensure_workspace(SharedEngine::samples_for(cfg.max_segment_duration_secs), cfg.max_batch, err)) return nullptr;
+    const auto t2 = std::chrono::steady_clock::now();
+    eng->worker = std::thread([e = eng.get()] { e->run(); });
+    cache.map[key] = eng;
+    if (who) who->log(SK_LOG_INFO, "Whisper model loaded and cached (model_load_ms=%.1f, ctx_create_ms=%.1f, max_batch=%d)",
+                      std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), cfg.max_batch);
+    return eng;
+}
+
+// Silero gate behind the segmenter's Vad interface; the weights of one file are shared by every instance that names it and, like the Whisper
+// context, stay cached for the life of the process
 struct SileroGate : skw::Vad {
     skw::SileroVad v;
     explicit SileroGate(std::shared_ptr<const skw::SileroWeights> w) : v(std::move(w)) {}
     float process_chunk(const float* f) override { return v.process_chunk(f); }
     void reset() override { v.reset(); }
 };
-std::mutex g_vad_mu; std::map<std::string, std::weak_ptr<const skw::SileroWeights>> g_vad_cache;
+std::mutex g_vad_mu;
+std::map<std::string, std::shared_ptr<const skw::SileroWeights>> g_vad_cache;
 std::shared_ptr<const skw::SileroWeights> get_silero(const std::string& path, std::string* err) {
     std::lock_guard<std::mutex> l(g_vad_mu);
     auto it = g_vad_cache.find(path);
-    if (it != g_vad_cache.end()) if (auto sp = it->second.lock()) return sp;
+    if (it != g_vad_cache.end()) return it->second;
     auto w = std::make_shared<skw::SileroWeights>();
     try { if (!skw::SileroVad::load_weights(path, w.get(), err)) return nullptr; }
     catch (const std::exception& e) { *err = "Failed to load VAD model from '" + path + "': " + e.what(); return nullptr; }     // a malformed file must not unwind across the C ABI
-    g_vad_cache[path] = w; return w;
+    g_vad_cache[path] = w;
+    return w;
 }
 
 // SileroVAD::new at lib.rs:382-383 ("Failed to initialize VAD: {e}") / :557-560 ("Failed to reload VAD: {e}", added by the caller)
@@ -369,7 +408,7 @@ CPluginHandle create_instance_impl(const char* params, CLogCallback log_cb, void
     std::string err;
     if (!parse_config(params, &p->config, &err)) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     resolve_auto_device(&p->config);
-    p->engine = get_engine(p->config, &err);
+    p->engine = get_engine(p->config, p.get(), &err);
     if (!p->engine) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     p->vad = make_vad(p->config, p.get(), &err);
     if (!p->vad) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
@@ -436,7 +475,7 @@ CResult plugin_update_params(CPluginHandle handle, const char* params) {
         if (!parse_config(params, &nc, &err)) return err_result(err);
         if (nc.gpu_device_auto) nc.gpu_device = self->config.gpu_device;        // an "auto" instance stays on the device it was dealt
         if (nc.model_path != self->config.model_path || nc.precision != self->config.precision || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
-            auto eng = get_engine(nc, &err);
+            auto eng = get_engine(nc, self, &err);
             if (!eng) return err_result("Failed to reload Whisper model: " + err);
             self->engine = eng;
         }
@@ -474,3 +513,8 @@ const CNativePluginAPI kApi = {STREAMKIT_NATIVE_PLUGIN_API_VERSION, plugin_get_m
 }  // namespace
 
 extern "C" const CNativePluginAPI* streamkit_native_plugin_api(void) { return &kApi; }
+// additive, for tests and bench.py: how often this library loaded a model file / found one cached since it was loaded itself (W5)
+extern "C" void skw_whisper_plugin_cache_stats(int* model_loads, int* cache_hits) {
+    if (model_loads) *model_loads = g_model_loads.load();
+    if (cache_hits) *cache_hits = g_cache_hits.load();
+}

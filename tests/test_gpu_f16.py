@@ -18,7 +18,7 @@ import pytest
 
 from oracle_lib import OracleModel
 from streamkit_amd import synth
-from streamkit_amd.parity import LOGIT_ERR_BOUND, MARGIN_BOUND, teacher_forced_compare
+from streamkit_amd.parity import LOGIT_ERR_BOUND, MARGIN_BOUND, SMALL_MODEL_LOGIT_ERR_BOUND, teacher_forced_compare
 
 pytestmark = pytest.mark.gpu
 
@@ -129,6 +129,7 @@ def test_tokens_identical_to_oracle_ragged_batch(tiny16, suppress_nst):
             if ro["tokens"]:
                 lp = max(abs(a[3] - b[3]) for a, b in zip(rg["tokens"], ro["tokens"]))
                 assert lp < 5e-2, (c, n, lp)                                      # token log-probs
+    print("f16_mfma ragged batch (suppress_nst %d): %d of %d clips identical to the oracle" % (suppress_nst, n_same, len(CLIPS)))
     assert n_same >= len(CLIPS) - 2, n_same
 
 
@@ -174,7 +175,7 @@ def test_full_size_batch_tokens(eng, small_model_path):
     assert all(r["fallback_requested"] == 0 for r in fast)
     print("f16_mfma full size: %d of 64 clips identical to the exact mode; smallest margin among them %.4g; encode %.1f ms decode %.1f ms"
           % (sum(same), min(r["min_margin"] for r, s in zip(exact, same) if s), t_fast["encode_ms"], t_fast["decode_ms"]))
-    assert sum(same) >= 42                                                        # measured: 46 - 48 of 64 (each clip makes ~90 decisions; ~0.3 % are near-ties); what happens after a clip's first near-tie is what the teacher-forced test below checks
+    assert sum(same) >= 45                                                        # measured: 45 - 49 of 64 over round 3's builds (each clip makes ~90 decisions; ~0.3 % are near-ties); what happens after a clip's first near-tie is what the teacher-forced test below checks
     om = OracleModel(small_model_path)
     po = om.default_params(); po.suppress_nst = 1
     n_ok = 0
@@ -190,7 +191,7 @@ def _report(tag, r):
     print("%s: %d decisions checked under teacher forcing (%d inside temperature passes, %d of those draws came out differently), %d argmax disagreements (%d on the exact mode's "
           "runner-up), largest exact margin at one %s, largest logit error %.4g (bounds: logit %.3g, margin %.3g)"
           % (tag, r["steps_checked"], r["sampled_steps"], r["sampled_draws_that_differ"], r["argmax_disagreements"], r["disagreements_on_exact_runner_up"],
-             r["max_margin_at_disagreement"], r["max_logit_err"], LOGIT_ERR_BOUND, MARGIN_BOUND))
+             r["max_margin_at_disagreement"], r["max_logit_err"], r["logit_err_bound"], r["margin_bound"]))
 
 
 def test_teacher_forced_every_step_of_the_full_size_batch(eng, small_model_path):
@@ -227,7 +228,7 @@ def test_teacher_forced_ragged_multi_window_batch(eng, tiny_model_path):
     r = teacher_forced_compare(ctx, pcms, p)
     _report("tiny ragged multi-window", r)
     assert r["steps_checked"] > 300
-    assert r["max_logit_err"] <= LOGIT_ERR_BOUND
+    assert r["max_logit_err"] <= SMALL_MODEL_LOGIT_ERR_BOUND      # the tiny model's logits span 1.5 x the benchmark model's (parity.py)
     assert r["argmax_disagreements"] == 0 or r["max_margin_at_disagreement"] < MARGIN_BOUND
     for a, b in zip(r["results_exact"], r["results_forced"]):
         assert _ids(a) == _ids(b) and _segs(a) == _segs(b) and a["n_windows"] == b["n_windows"]

@@ -324,3 +324,43 @@ def test_engine_workspace_follows_max_segment_duration(plugin, tiny_model_path):
     outs = [json.loads(o[2].decode()) for o in node.outputs()]
     assert len(outs) == 1 and outs[0]["segments"][-1]["end_time_ms"] > 30000       # one 40 s segment, two Whisper windows
     node.destroy()
+
+
+def _cache_stats():
+    import ctypes as C
+    import os
+    L = C.CDLL(os.path.join(minihost.ROOT, "streamkit_amd", "libwhisper.so"))      # the handle the mini-host already holds
+    loads, hits = C.c_int(), C.c_int()
+    L.skw_whisper_plugin_cache_stats(C.byref(loads), C.byref(hits))
+    return loads.value, hits.value
+
+
+def test_model_cache_outlives_its_instances(plugin, micro_model_path):
+    """W5 (lib.rs:170-180, 330-374): the context cache holds strong references for the life of the process, which is what prewarm relies on
+    (apps/skit/src/plugins.rs:265-306: the prewarm node is dropped at once, the loaded model stays).  create -> destroy -> create: the second
+    create is a CACHE HIT with no second model load, and it transcribes like the first."""
+    params = {"model_path": micro_model_path, "vad_mode": "always", "flush_tail": True, "gpu_device": 0, "precision": "exact", "max_batch": 2}
+    pcm = synth.clip(4, 16000 * 6)
+    loads0, hits0 = _cache_stats()
+    first = plugin.create_node(params)                       # the prewarm shape: created ...
+    log1 = "\n".join(first.logs())
+    loads1, hits1 = _cache_stats()
+    first.destroy()                                          # ... and dropped immediately
+    if loads1 == loads0 + 1:
+        assert "CACHE MISS" in log1 and "Whisper model loaded and cached (model_load_ms=" in log1
+    else:                                                    # an earlier test of this process already cached this key: equally a hit
+        assert loads1 == loads0 and "CACHE HIT" in log1
+    second = plugin.create_node(params)
+    loads2, hits2 = _cache_stats()
+    assert loads2 == loads1, "the model was loaded again after its only instance went away"
+    assert hits2 == hits1 + 1 and any("CACHE HIT" in l for l in second.logs())
+    _feed(second, pcm)
+    assert second.flush() == 0
+    out2 = second.outputs()
+    second.destroy()
+    third = plugin.create_node(dict(params, max_batch=5, batch_window_ms=0))      # scheduler params follow the latest instance; the cached model serves it
+    assert _cache_stats()[0] == loads1
+    _feed(third, pcm)
+    assert third.flush() == 0
+    assert [o[2] for o in third.outputs()] == [o[2] for o in out2] and len(out2) == 1
+    third.destroy()
