@@ -142,7 +142,9 @@ void skw_trace_free(skw_trace*);
 
 /* timing of the last skw_full_batch (milliseconds, GPU events on the engine's stream) */
 typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t n_windows, n_decode_steps, n_tokens;
-                 int32_t n_row_steps;   /* sum over rows of the decode steps the row was live in (a finished row's attention kernels return at once: the HBM bytes of a step scale with its live rows) */
+                 /* n_row_steps: sum over rows of the decode steps the row was live in (a finished row's attention kernels return at once:
+                    the HBM bytes of a step scale with its live rows) */
+                 int32_t n_row_steps;
 } skw_timing;
 void skw_ctx_last_timing(const skw_ctx*, skw_timing* out);
 /* per-kernel-class event timing (adds an event pair around every launch; use for roofline accounting, not for the timed run).

@@ -26,7 +26,8 @@ int skwo_segment_sim(const float* prob, int n_frames, float threshold, uint64_t 
             const uint64_t segment_duration_ms = absolute_time_ms - segment_start_time_ms;
             const uint64_t max_duration_ms = (uint64_t)(max_secs * 1000.0f);                                 /* lib.rs:460-461 */
             if (segment_duration_ms >= max_duration_ms) {
-                if (n_cuts < max_cuts) { int64_t* c = cuts + 6 * n_cuts; c[0] = (int64_t)segment_start_time_ms; c[1] = (int64_t)(absolute_time_ms + 32); c[2] = (int64_t)speech_samples; c[3] = 0; c[4] = -1; c[5] = f; }
+                if (n_cuts < max_cuts) { int64_t* c = cuts + 6 * n_cuts; c[0] = (int64_t)segment_start_time_ms;
+                c[1] = (int64_t)(absolute_time_ms + 32); c[2] = (int64_t)speech_samples; c[3] = 0; c[4] = -1; c[5] = f; }
                 n_cuts++; speech_samples = 0; silence_frame_count = 0;                                       /* lib.rs:463-464, 612, 699 */
             }
         } else {
@@ -35,7 +36,8 @@ int skwo_segment_sim(const float* prob, int n_frames, float threshold, uint64_t 
                 const uint64_t silence_frames = silence_frame_count > 0 ? silence_frame_count - 1 : 0;
                 const uint64_t back = silence_frames * 32;
                 const uint64_t end_time_ms = absolute_time_ms >= back ? absolute_time_ms - back : 0;         /* lib.rs:474-476 */
-                if (n_cuts < max_cuts) { int64_t* c = cuts + 6 * n_cuts; c[0] = (int64_t)segment_start_time_ms; c[1] = (int64_t)end_time_ms; c[2] = (int64_t)speech_samples; c[3] = 1; c[4] = (int64_t)(silence_frame_count * 32); c[5] = f; }
+                if (n_cuts < max_cuts) { int64_t* c = cuts + 6 * n_cuts; c[0] = (int64_t)segment_start_time_ms;
+                c[1] = (int64_t)end_time_ms; c[2] = (int64_t)speech_samples; c[3] = 1; c[4] = (int64_t)(silence_frame_count * 32); c[5] = f; }
                 n_cuts++; speech_samples = 0; silence_frame_count = 0;
             }
         }

@@ -60,7 +60,8 @@ static void adain(const float* z, long F, int C, const float* ada, const float* 
         double s = 0.0; for (long f = 0; f < F; ++f) s += (double)z[f * C + c]; const double mean = s / F;
         double q = 0.0; for (long f = 0; f < F; ++f) { const double u = (double)z[f * C + c] - mean; q += u * u; }
         const float mu = (float)mean, rstd = (float)(1.0 / sqrt(q / F + 1e-5));
-        for (long f = 0; f < F; ++f) { float v = ((z[f * C + c] - mu) * rstd) * (1.0f + ada[c]) + ada[C + c]; v = leaky(v, 0.2f); out[f * C + c] = res ? (res[f * C + c] + v) * 0.70710678118654752f : v; }
+        for (long f = 0; f < F; ++f) { float v = ((z[f * C + c] - mu) * rstd) * (1.0f + ada[c]) + ada[C + c];
+        v = leaky(v, 0.2f); out[f * C + c] = res ? (res[f * C + c] + v) * 0.70710678118654752f : v; }
     }
 }
 
@@ -75,11 +76,13 @@ long skwo_tts_synth(const skwo_tts_dims* D, const int* ids, const float* style25
     for (int i = 0; i < D->n_te; ++i) {
         const float* cw = w[wi++]; const float* cb = w[wi++]; const float* ga = w[wi++]; const float* be = w[wi++];
         conv1d(x, T, d, cw, cb, 5, d, yb, 0, 0.0f);
-        for (int t = 0; t < T; ++t) { float mu, rstd; ln_row(yb + (long)t * d, d, &mu, &rstd); for (int c = 0; c < d; ++c) x[(long)t * d + c] = leaky(((yb[(long)t * d + c] - mu) * rstd) * ga[c] + be[c], 0.2f); }
+        for (int t = 0; t < T; ++t) { float mu, rstd; ln_row(yb + (long)t * d, d, &mu, &rstd);
+        for (int c = 0; c < d; ++c) x[(long)t * d + c] = leaky(((yb[(long)t * d + c] - mu) * rstd) * ga[c] + be[c], 0.2f); }
     }
     float* ada = (float*)malloc(sizeof(float) * 2 * (size_t)(d > C ? d : C));
     { const float* fw = w[wi++]; const float* fb = w[wi++]; style_fc(fw, fb, s_pr, 2 * d, ada); }
-    for (int t = 0; t < T; ++t) { float mu, rstd; ln_row(x + (long)t * d, d, &mu, &rstd); for (int c = 0; c < d; ++c) h[(long)t * d + c] = ((x[(long)t * d + c] - mu) * rstd) * (1.0f + ada[c]) + ada[d + c]; }
+    for (int t = 0; t < T; ++t) { float mu, rstd; ln_row(x + (long)t * d, d, &mu, &rstd);
+    for (int c = 0; c < d; ++c) h[(long)t * d + c] = ((x[(long)t * d + c] - mu) * rstd) * (1.0f + ada[c]) + ada[d + c]; }
     const float* dw = w[wi++]; const float* db = w[wi++];
     int* dur = (int*)malloc(sizeof(int) * T); long F = 0;
     for (int t = 0; t < T; ++t) {
@@ -95,7 +98,8 @@ long skwo_tts_synth(const skwo_tts_dims* D, const int* ids, const float* style25
     const float* f0w = w[wi++]; const float* f0s = w[wi++]; const float* f0b = w[wi++]; const float* nw = w[wi++]; const float* nb = w[wi++];
     float* f0 = (float*)malloc(sizeof(float) * F); float* en = (float*)malloc(sizeof(float) * F);
     { double sv = 0.0; for (int j = 0; j < STYLE_; ++j) sv += (double)f0s[j] * (double)s_pr[j];
-      for (long f = 0; f < F; ++f) { const float* hr = h + (long)tok[f] * d; double a = 0.0, e = 0.0; for (int c = 0; c < d; ++c) { a += (double)f0w[c] * (double)hr[c]; e += (double)nw[c] * (double)hr[c]; }
+      for (long f = 0; f < F; ++f) { const float* hr = h + (long)tok[f] * d;
+      double a = 0.0, e = 0.0; for (int c = 0; c < d; ++c) { a += (double)f0w[c] * (double)hr[c]; e += (double)nw[c] * (double)hr[c]; }
           f0[f] = 60.0f + 340.0f * sigm((float)(a + sv + (double)f0b[0])); en[f] = (float)(e + (double)nb[0]); } }
     if (f0_out) memcpy(f0_out, f0, sizeof(float) * F);
     if (en_out) memcpy(en_out, en, sizeof(float) * F);
@@ -110,7 +114,8 @@ long skwo_tts_synth(const skwo_tts_dims* D, const int* ids, const float* style25
         float* tmp = z; z = z2; z2 = tmp;
     }
     if (z_out) memcpy(z_out, z, sizeof(float) * (size_t)F * C);
-    const float* upw = w[wi++]; const float* upb = w[wi++]; const float* srcw = w[wi++]; const float* alpha = w[wi++]; const float* rbw = w[wi++]; const float* rbb = w[wi++]; const float* pw = w[wi++]; const float* pb = w[wi++];
+    const float* upw = w[wi++]; const float* upb = w[wi++]; const float* srcw = w[wi++];
+    const float* alpha = w[wi++]; const float* rbw = w[wi++]; const float* rbb = w[wi++]; const float* pw = w[wi++]; const float* pb = w[wi++];
     double* phi = (double*)malloc(sizeof(double) * F); { double a = 0.0; for (long f = 0; f < F; ++f) { phi[f] = a; a += (double)U_ * (double)f0[f] / SUBRATE_; a -= floor(a); } }
     float* g = (float*)malloc(sizeof(float) * (size_t)P * G); float* g1 = (float*)malloc(sizeof(float) * (size_t)P * G); float* g2 = (float*)malloc(sizeof(float) * (size_t)P * G);
 #pragma omp parallel for

@@ -60,7 +60,8 @@ static float* xmalloc_f(size_t n) { float* p = (float*)aligned_alloc(64, ((n * 4
 
 static const char* NST_LIST[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
     "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))",
-    "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
+    "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac",
+        "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
 #define N_NST_LIST ((int)(sizeof(NST_LIST) / sizeof(NST_LIST[0])))
 
 /* 1 (default): a uniformly quantised file runs ggml's q8 arithmetic; 0: its dequantised f16 twin (what the f16_mfma precision of the engine runs) */
@@ -172,7 +173,9 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
         if (fread(t->name, 1, len, f) != (size_t)len) { snprintf(err, errlen, "short tensor name"); return NULL; }
         t->name[len] = 0; t->data = xmalloc_f(t->n);
         if (tt == 0) { if (fread(t->data, 4, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } }
-        else if (tt == 1) { uint16_t* h = (uint16_t*)malloc(t->n * 2); if (fread(h, 2, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; } for (size_t i = 0; i < t->n; ++i) t->data[i] = skw_f16_to_f32(h[i]); free(h); }
+        else if (tt == 1) { uint16_t* h = (uint16_t*)malloc(t->n * 2);
+        if (fread(h, 2, t->n, f) != t->n) { snprintf(err, errlen, "short tensor data %s", t->name);
+        return NULL; } for (size_t i = 0; i < t->n; ++i) t->data[i] = skw_f16_to_f32(h[i]); free(h); }
         else if (skw_ggml_block_bytes(tt) && t->ne[0] % 32 == 0) {   /* block-quantised: blocks kept, decoded once the whole file has been seen */
             const size_t bb = skw_ggml_block_bytes(tt), nb = t->n / 32; t->qblk = (uint8_t*)malloc(nb * bb); t->qtype = tt;
             if (fread(t->qblk, bb, nb, f) != nb) { snprintf(err, errlen, "short tensor data %s", t->name); return NULL; }
@@ -187,7 +190,8 @@ skwo_model* skwo_load(const char* path, char* err, int errlen) {
       m->quant = (uniform && qt) ? qt : 0;
       for (int i = 0; i < nt; ++i) if (ts[i].qblk) {
           raw_t* t = &ts[i]; const size_t bb = skw_ggml_block_bytes(t->qtype), nb = t->n / 32;
-          for (size_t b = 0; b < nb; ++b) { skw_ggml_dequant_block(t->qtype, t->qblk + b * bb, t->data + b * 32); if (!m->quant) for (int j = 0; j < 32; ++j) t->data[b * 32 + j] = skw_round_f16(t->data[b * 32 + j]); }
+          for (size_t b = 0; b < nb; ++b) { skw_ggml_dequant_block(t->qtype, t->qblk + b * bb, t->data + b * 32);
+          if (!m->quant) for (int j = 0; j < 32; ++j) t->data[b * 32 + j] = skw_round_f16(t->data[b * 32 + j]); }
           t->type = 1; if (!m->quant || !is_matmul_weight(t)) { free(t->qblk); t->qblk = NULL; t->qtype = 0; }
       } }
     int rc = 0; char nmw[128], nmb[128];
@@ -260,8 +264,11 @@ void skwo_free(skwo_model* m) {
     for (int i = 0; i < m->hp.n_vocab; ++i) free(m->tok_str[i]);
     free(m->tok_str); free(m->tok_len); free(m->nst_ids); free(m->filters); free(m->e_pe); free(m->d_pe); free(m->d_te); free(m->gelu_tab);
     free_lin(&m->conv1); free_lin(&m->conv2); free_ln(&m->ln_post); free_lin(&m->d_te_lin); free_ln(&m->d_ln);
-    for (int l = 0; l < m->hp.n_audio_layer; ++l) { enc_layer_t* L = &m->enc[l]; free_ln(&L->attn_ln); free_ln(&L->mlp_ln); free_lin(&L->q); free_lin(&L->k); free_lin(&L->v); free_lin(&L->o); free_lin(&L->fc1); free_lin(&L->fc2); }
-    for (int l = 0; l < m->hp.n_text_layer; ++l) { dec_layer_t* L = &m->dec[l]; free_ln(&L->attn_ln); free_ln(&L->cross_ln); free_ln(&L->mlp_ln); free_lin(&L->q); free_lin(&L->k); free_lin(&L->v); free_lin(&L->o); free_lin(&L->cq); free_lin(&L->ck); free_lin(&L->cv); free_lin(&L->co); free_lin(&L->fc1); free_lin(&L->fc2); }
+    for (int l = 0; l < m->hp.n_audio_layer; ++l) { enc_layer_t* L = &m->enc[l]; free_ln(&L->attn_ln); free_ln(&L->mlp_ln); free_lin(&L->q); free_lin(&L->k);
+    free_lin(&L->v); free_lin(&L->o); free_lin(&L->fc1); free_lin(&L->fc2); }
+    for (int l = 0; l < m->hp.n_text_layer; ++l) { dec_layer_t* L = &m->dec[l]; free_ln(&L->attn_ln); free_ln(&L->cross_ln); free_ln(&L->mlp_ln);
+    free_lin(&L->q); free_lin(&L->k); free_lin(&L->v); free_lin(&L->o); free_lin(&L->cq); free_lin(&L->ck); free_lin(&L->cv); free_lin(&L->co);
+    free_lin(&L->fc1); free_lin(&L->fc2); }
     free(m->enc); free(m->dec); free(m);
 }
 void skwo_get_hparams(const skwo_model* m, skwo_hparams* out) { *out = m->hp; }
@@ -464,7 +471,8 @@ static void linear_q8_seg(const float* A, long lda, int rows, const lin_t* L, fl
     const int K = L->n_in, nb = K / 32, N = L->n_out, form = skw_ggml_dot_form(L->qtype); const int bps = nb / nseg;   /* blocks per segment */
     int8_t* qa = (int8_t*)malloc((size_t)rows * K); float* da = xmalloc_f((size_t)rows * nb); float* sa = xmalloc_f((size_t)rows * nb);
 #pragma omp parallel for schedule(static)
-    for (int r = 0; r < rows; ++r) for (int b = 0; b < nb; ++b) skw_ggml_quantize_q8_block(A + (long)r * lda + b * 32, qa + ((size_t)r * nb + b) * 32, &da[(size_t)r * nb + b], &sa[(size_t)r * nb + b]);
+    for (int r = 0; r < rows; ++r) for (int b = 0; b < nb; ++b) skw_ggml_quantize_q8_block(A + (long)r * lda + b * 32, qa + ((size_t)r * nb + b) * 32,
+        &da[(size_t)r * nb + b], &sa[(size_t)r * nb + b]);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int r = 0; r < rows; ++r) for (int n = 0; n < N; ++n) {
         const int8_t* x = qa + (size_t)r * K; const int8_t* w = L->qw + (size_t)n * K;
@@ -582,12 +590,19 @@ int skwo_encode(const skwo_model* m, const float* mel, int n_len, int seek, int 
             for (int j = 0; j < n_ctx; ++j) for (int c = 0; c < dh; ++c) { kt[(size_t)c * n_ctx + j] = kk[(size_t)j * d + h * dh + c]; vh[(size_t)j * dh + c] = v[(size_t)j * d + h * dh + c]; }
             gemm_chain(q + h * dh, d, n_ctx, kt, n_ctx, n_ctx, dh, S, n_ctx);
             float* spd = NULL;
-            if (l == 0 && h == 0 && g_taps_on) { int Tp = (n_ctx + 31) & ~31; spd = (float*)calloc((size_t)64 * Tp, 4); for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)i * Tp + j] = S[(size_t)i * n_ctx + j] * KQscale; for (int i = 0; i < 32; ++i) for (int j = n_ctx; j < Tp; ++j) spd[(size_t)i * Tp + j] = -INFINITY; }
+            if (l == 0 && h == 0 && g_taps_on) { int Tp = (n_ctx + 31) & ~31;
+            spd = (float*)calloc((size_t)64 * Tp, 4); for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)i * Tp + j] = S[(size_t)i * n_ctx + j] * KQscale;
+            for (int i = 0; i < 32; ++i) for (int j = n_ctx; j < Tp; ++j) spd[(size_t)i * Tp + j] = -INFINITY; }
 #pragma omp parallel for schedule(static)
-            for (int i = 0; i < n_ctx; ++i) { float* s = S + (size_t)i * n_ctx; float mx, iv; softmax_row2(s, n_ctx, KQscale, &mx, &iv); if (g_dbg_max) { g_dbg_max[(size_t)h * n_ctx + i] = mx; g_dbg_inv[(size_t)h * n_ctx + i] = iv; } for (int j = 0; j < n_ctx; ++j) s[j] = skw_round_f16(s[j]); }
-            if (spd) { int Tp = (n_ctx + 31) & ~31; for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)(32 + i) * Tp + j] = S[(size_t)i * n_ctx + j]; tap("l0.SP", spd, (size_t)64 * Tp); free(spd); }
+            for (int i = 0; i < n_ctx; ++i) { float* s = S + (size_t)i * n_ctx;
+            float mx, iv; softmax_row2(s, n_ctx, KQscale, &mx, &iv); if (g_dbg_max) { g_dbg_max[(size_t)h * n_ctx + i] = mx;
+            g_dbg_inv[(size_t)h * n_ctx + i] = iv; } for (int j = 0; j < n_ctx; ++j) s[j] = skw_round_f16(s[j]); }
+            if (spd) { int Tp = (n_ctx + 31) & ~31; for (int i = 0; i < 32; ++i) for (int j = 0; j < n_ctx; ++j) spd[(size_t)(32 + i) * Tp + j] = S[(size_t)i * n_ctx + j];
+            tap("l0.SP", spd, (size_t)64 * Tp); free(spd); }
             gemm_chain(S, n_ctx, n_ctx, vh, dh, dh, n_ctx, oh, dh);
-            if (l == 0 && g_taps_on) { static float* a32 = NULL; if (h == 0) a32 = (float*)calloc((size_t)n_ctx * d, 4); for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) a32[(size_t)i * d + h * dh + c] = oh[(size_t)i * dh + c]; if (h == nh - 1) { tap("l0.att32", a32, (size_t)n_ctx * d); free(a32); } }
+            if (l == 0 && g_taps_on) { static float* a32 = NULL; if (h == 0) a32 = (float*)calloc((size_t)n_ctx * d, 4);
+            for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) a32[(size_t)i * d + h * dh + c] = oh[(size_t)i * dh + c];
+            if (h == nh - 1) { tap("l0.att32", a32, (size_t)n_ctx * d); free(a32); } }
 #pragma omp parallel for schedule(static)
             for (int i = 0; i < n_ctx; ++i) for (int c = 0; c < dh; ++c) att[(size_t)i * d + h * dh + c] = m->quant ? oh[(size_t)i * dh + c] : skw_round_f16(oh[(size_t)i * dh + c]);
         }
@@ -768,7 +783,8 @@ static void process_logits(const skwo_model* m, const skwo_params* p, decoder_t*
 /* whisper_sample_token(best = true) */
 static skwo_token sample_best(const skwo_model* m, decoder_t* dc) {
     skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, INFINITY}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
-    { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i]; if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
+    { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i];
+    if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
     for (int i = 0; i < n; ++i) if (r.p < probs[i]) { r.id = i; r.p = probs[i]; r.plog = dc->logprobs[i]; }
     if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }
     { /* diagnostics: margin between the two largest admissible logits */
@@ -819,7 +835,8 @@ int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, in
 /* whisper_sample_token(best = false) */
 static skwo_token sample_dist(const skwo_model* m, decoder_t* dc, mt19937_t* rng) {
     skwo_token r = {0, 0, 0.0f, 0.0f, 0.0f, 0.0f, INFINITY}; const int n = m->hp.n_vocab; const float* probs = dc->probs;
-    { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i]; if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
+    { double sum_ts = 0.0, max_ts = 0.0; for (int i = m->tok_beg; i < n; ++i) { sum_ts += probs[i];
+    if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; } } r.pt = (float)(max_ts / (sum_ts + 1e-10)); r.ptsum = (float)sum_ts; }
     r.id = discrete_draw(probs, n, rng); r.p = probs[r.id]; r.plog = dc->logprobs[r.id];
     if (r.id >= m->tok_beg) { r.tid = r.id; r.pt = r.p; }
     return r;
@@ -877,7 +894,12 @@ static void sequence_score(decoder_t* dc) {
     double result = 0.0; for (int i = 0; i < dc->result_len; ++i) result += dc->tokens[i].plog;
     dc->sum_logprobs = result; dc->avg_logprobs = result / dc->result_len; dc->score = result / (double)dc->result_len; /* length_penalty <= 0 */
     const int n = 32; int cnt = 0; int ids[32], c[32], nu = 0;
-    for (int i = dc->result_len - n > 0 ? dc->result_len - n : 0; i < dc->result_len; ++i) { int id = dc->tokens[i].id, f = -1; for (int u = 0; u < nu; ++u) if (ids[u] == id) f = u; if (f < 0) { ids[nu] = id; c[nu] = 1; nu++; } else c[f]++; cnt++; }
+    for (int i = dc->result_len - n > 0 ? dc->result_len - n : 0; i < dc->result_len; ++i) {
+        int id = dc->tokens[i].id, f = -1;
+        for (int u = 0; u < nu; ++u) if (ids[u] == id) f = u;
+        if (f < 0) { ids[nu] = id; c[nu] = 1; nu++; } else c[f]++;
+        cnt++;
+    }
     /* std::map iterates in key order: sort for identical summation order */
     for (int a = 0; a < nu; ++a) for (int b = a + 1; b < nu; ++b) if (ids[b] < ids[a]) { int t = ids[a]; ids[a] = ids[b]; ids[b] = t; t = c[a]; c[a] = c[b]; c[b] = t; }
     double entropy = 0.0; for (int u = 0; u < nu; ++u) { double pp = c[u] / (double)cnt; entropy -= pp * log(pp); }
@@ -929,7 +951,8 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     float* enc_out = xmalloc_f((size_t)nc * m->hp.n_audio_state);
     float* ck = xmalloc_f((size_t)m->hp.n_text_layer * nc * d); float* cv = xmalloc_f((size_t)m->hp.n_text_layer * nc * d);
     float* raw = xmalloc_f(NV);
-    decoder_t dc; memset(&dc, 0, sizeof dc); dc.logits = xmalloc_f(NV); dc.logprobs = xmalloc_f(NV); dc.probs = xmalloc_f(NV); dc.cap = 512; dc.tokens = (skwo_token*)malloc(dc.cap * sizeof(skwo_token)); dc.min_margin = INFINITY;
+    decoder_t dc; memset(&dc, 0, sizeof dc); dc.logits = xmalloc_f(NV); dc.logprobs = xmalloc_f(NV); dc.probs = xmalloc_f(NV); dc.cap = 512;
+    dc.tokens = (skwo_token*)malloc(dc.cap * sizeof(skwo_token)); dc.min_margin = INFINITY;
     int32_t prompt_init[8]; int n_prompt = 0;
     prompt_init[n_prompt++] = m->tok_sot;
     if (NV >= 51865) { prompt_init[n_prompt++] = m->tok_sot + 1 + lang_id; prompt_init[n_prompt++] = p->translate ? m->tok_translate : m->tok_transcribe; }
@@ -955,7 +978,8 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
             int n_prompt_cur = 0, n_take = 0;
             if (n_past_tok > 0 && t_cur < 0.5f) {
                 n_take = m->hp.n_text_ctx / 2 < n_past_tok ? m->hp.n_text_ctx / 2 : n_past_tok;
-                { const int room = m->hp.n_text_ctx - (m->hp.n_text_ctx / 2 - 4) - n_prompt - 1; if (n_take > room) n_take = room; }   /* only binds with no_timestamps (4-token init): keeps every position inside n_text_ctx */
+                { const int room = m->hp.n_text_ctx - (m->hp.n_text_ctx / 2 - 4) - n_prompt - 1;
+                if (n_take > room) n_take = room; }   /* only binds with no_timestamps (4-token init): keeps every position inside n_text_ctx */
                 prompt[n_prompt_cur++] = m->tok_prev;
                 for (int i = 0; i < n_take; ++i) prompt[n_prompt_cur++] = prompt_past[n_past_tok - n_take + i];
             }

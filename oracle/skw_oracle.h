@@ -81,7 +81,8 @@ typedef struct {
 void skwo_set_quant_mode(int mode);
 skwo_model* skwo_load(const char* path, char* err, int errlen);
 int skwo_model_quant(const skwo_model* m);
-int skwo_debug_linear_q8(int type, const uint8_t* blocks, int n_out, int n_in, const float* A, int rows, float* out);   /* test hook: one quantised mul_mat */   /* ggml type running in q8 arithmetic, 0 if none */
+int skwo_debug_linear_q8(int type, const uint8_t* blocks, int n_out, int n_in, const float* A, int rows, float* out);
+/* test hook: one quantised mul_mat */   /* ggml type running in q8 arithmetic, 0 if none */
 void skwo_free(skwo_model*);
 void skwo_get_hparams(const skwo_model*, skwo_hparams* out);
 const char* skwo_token_str(const skwo_model*, int id, int* len);

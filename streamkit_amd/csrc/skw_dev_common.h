@@ -76,8 +76,10 @@ __device__ __forceinline__ float skw_wave_max_f32(float v) {
                 r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
-template <int R, int NC = 24, bool FULL = false>     // NC slots of 64 elements per row: 12 covers d <= 768 with half the instructions (same operations on the live elements); FULL: d == 64 NC, no tail predicates
-__device__ __forceinline__ void skw_ln_rows(float (&v)[R][NC], const float (&wv)[NC], const float (&bv)[NC], int d, int lane, const bool (&live)[R], half_t* const (&out16)[R], float* const (&out32)[R]) {
+// NC slots of 64 elements per row: 12 covers d <= 768 with half the instructions (same operations on the live elements); FULL: d == 64 NC, no tail predicates
+template <int R, int NC = 24, bool FULL = false>
+__device__ __forceinline__ void skw_ln_rows(float (&v)[R][NC], const float (&wv)[NC], const float (&bv)[NC], int d, int lane, const bool (&live)[R],
+    half_t* const (&out16)[R], float* const (&out32)[R]) {
     double sum[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -40,7 +40,8 @@ static_assert(sizeof(g_lang_name) / sizeof(g_lang_name[0]) == sizeof(g_lang) / s
 
 static const char* const NST_LIST[] = {"\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
     "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f", "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))",
-    "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
+    "[[", "]]", "{{", "}}", "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac",
+        "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};
 static const int N_NST_LIST = (int)(sizeof(NST_LIST) / sizeof(NST_LIST[0]));
 
 static void set_err(char* err, size_t n, const char* fmt, ...) {
@@ -59,7 +60,8 @@ struct DevLN { float* w = nullptr; float* b = nullptr; };
 struct EncLayer { DevLN attn_ln, mlp_ln; DevLin q, k, v, o, fc1, fc2; };
 struct DecLayer { DevLN attn_ln, cross_ln, mlp_ln; DevLin q, k, v, o, cq, ck, cv, co, fc1, fc2; DevLin qkv; /* q|k|v rows concatenated for the fused decode projection */ };
 
-struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; std::vector<uint8_t> qblk; int qtype = 0; };   // qblk: the file's blocks of a quantised tensor (data: its f16 twin)
+// qblk: the file's blocks of a quantised tensor (data: its f16 twin)
+struct RawT { std::string name; int n_dims = 0; int ne[4] = {1, 1, 1, 1}; int type = 0; std::vector<uint8_t> data; size_t n = 0; std::vector<uint8_t> qblk; int qtype = 0; };
 
 struct skw_model {
     skw_hparams hp{};
@@ -125,7 +127,8 @@ static bool up_lin(skw_model* m, std::vector<RawT>& ts, const std::string& wname
     L->n_in = n_in; L->n_out = n_out; L->k_pad = k_pad;
     L->w = (half_t*)dev_upload(m, h.data(), h.size());
     if (!L->w) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; }
-    if (want_nat && w->n_dims == 2 && k_pad == n_in) { L->w_nat = (half_t*)dev_upload(m, src, (size_t)n_out * n_in); if (!L->w_nat) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
+    if (want_nat && w->n_dims == 2 && k_pad == n_in) { L->w_nat = (half_t*)dev_upload(m, src, (size_t)n_out * n_in);
+    if (!L->w_nat) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
     if (m->quant && !w->qblk.empty()) { HostQ h; host_q(*w, &h); if (!up_q(m, h, w->qtype, L)) { set_err(err, errlen, "device allocation failed for %s", wname.c_str()); return false; } }
     L->b = nullptr;
     if (bname) {
@@ -225,13 +228,15 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
         if (fread(&len, 4, 1, f) != 1 || fread(&tt, 4, 1, f) != 1) return fail("short tensor header");
         RawT t; t.n_dims = nd; t.type = tt; t.n = 1;
         if (nd < 1 || nd > 4 || len < 0 || len > 255) return fail("corrupt tensor header");
-        for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header"); if (e < 1 || e > (1 << 24)) return fail("corrupt tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
+        for (int i = 0; i < nd; ++i) { int32_t e; if (fread(&e, 4, 1, f) != 1) return fail("short tensor header");
+        if (e < 1 || e > (1 << 24)) return fail("corrupt tensor header"); t.ne[i] = e; t.n *= (size_t)e; }
         if (t.n > ((size_t)1 << 31)) return fail("corrupt tensor header");
         t.name.resize(len); if (len && fread(&t.name[0], 1, len, f) != (size_t)len) return fail("short tensor name");
         size_t esz = tt == 0 ? 4 : tt == 1 ? 2 : 0;
         if (!esz) {   // block-quantised 2-D weights: decoded to f16 here (include/skw_ggml_quant.h, DEVIATION D4)
             const size_t bb = skw_ggml_block_bytes(tt);
-            if (!bb || t.ne[0] % 32) { std::string msg = "tensor " + t.name + ": unsupported ggml type " + std::to_string(tt) + " (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)"; return fail(msg.c_str()); }
+            if (!bb || t.ne[0] % 32) { std::string msg = "tensor " + t.name + ": unsupported ggml type " + std::to_string(tt) + " (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0 are read)";
+            return fail(msg.c_str()); }
             std::vector<uint8_t> blocks(t.n / 32 * bb); if (fread(blocks.data(), 1, blocks.size(), f) != blocks.size()) return fail("short tensor data");
             t.data.resize(t.n * 2); skw_ggml_dequant_to_f16(tt, blocks.data(), t.n, (uint16_t*)t.data.data()); t.type = 1; t.qtype = tt; t.qblk = std::move(blocks);
             ts.push_back(std::move(t)); continue;
@@ -250,12 +255,14 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     m->filters = dev_upload(m, filt.data(), filt.size());
     {   // per mel filter: the range of 4-bin groups with a non-zero tap (the filterbank comes from the model file; Slaney filters are narrow)
         std::vector<int> lo(nm, 0), hi(nm, 0);
-        for (int j = 0; j < nm; ++j) { int a = nf, b = -1; for (int k = 0; k < nf; ++k) if (filt[(size_t)j * nf + k] != 0.0f) { a = std::min(a, k); b = std::max(b, k); } if (b >= 0) { lo[j] = a / 4; hi[j] = b / 4 + 1; } }
+        for (int j = 0; j < nm; ++j) { int a = nf, b = -1; for (int k = 0; k < nf; ++k) if (filt[(size_t)j * nf + k] != 0.0f) { a = std::min(a, k);
+        b = std::max(b, k); } if (b >= 0) { lo[j] = a / 4; hi[j] = b / 4 + 1; } }
         m->mel_grp_lo = dev_upload(m, lo.data(), lo.size()); m->mel_grp_hi = dev_upload(m, hi.data(), hi.size());
     }
     {
         std::vector<float> sn(WHISPER_N_FFT), cs(WHISPER_N_FFT), hn(WHISPER_N_FFT);
-        for (int i = 0; i < WHISPER_N_FFT; ++i) { double theta = (2 * M_PI * i) / WHISPER_N_FFT; sn[i] = sinf(theta); cs[i] = cosf(theta); hn[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / (WHISPER_N_FFT))); }
+        for (int i = 0; i < WHISPER_N_FFT; ++i) { double theta = (2 * M_PI * i) / WHISPER_N_FFT;
+        sn[i] = sinf(theta); cs[i] = cosf(theta); hn[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / (WHISPER_N_FFT))); }
         m->sin_t = dev_upload(m, sn.data(), sn.size()); m->cos_t = dev_upload(m, cs.data(), cs.size()); m->hann = dev_upload(m, hn.data(), hn.size());
         std::vector<uint16_t> gt(65536); for (int i = 0; i < 65536; ++i) gt[i] = skw_gelu_table_entry((uint16_t)i);
         m->gelu_tab = dev_upload(m, gt.data(), gt.size());
@@ -267,7 +274,8 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     if (!(t = find_t(ts, "decoder.positional_embedding"))) { set_err(err, errlen, "missing decoder.positional_embedding"); return fail2(); }
     m->d_pe = dev_upload(m, as_f32(t, tmp), t->n);
     bool ok = true;
-    const bool wfrag_on = !(getenv("SKW_DEC_WFRAG") && atoi(getenv("SKW_DEC_WFRAG")) == 0);      // fragment-order images of the decoder projections (SkwGemmArgs::Wf); =0: the f16 decode kernels read weight rows
+    // fragment-order images of the decoder projections (SkwGemmArgs::Wf); =0: the f16 decode kernels read weight rows
+    const bool wfrag_on = !(getenv("SKW_DEC_WFRAG") && atoi(getenv("SKW_DEC_WFRAG")) == 0);
     ok = ok && up_lin(m, ts, "encoder.conv1.weight", "encoder.conv1.bias", &m->conv1, err, errlen);
     ok = ok && up_lin(m, ts, "encoder.conv2.weight", "encoder.conv2.bias", &m->conv2, err, errlen);
     ok = ok && up_ln(m, ts, "encoder.ln_post.weight", "encoder.ln_post.bias", &m->ln_post, err, errlen);
@@ -312,19 +320,24 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
             if (hipMalloc((void**)&w, (size_t)3 * d * kp * 2) != hipSuccess || hipMalloc((void**)&b, (size_t)3 * d * 4) != hipSuccess) { set_err(err, errlen, "device allocation failed"); ok = false; }
             else {
                 m->allocs.push_back(w); m->allocs.push_back(b);
-                hipMemcpy(w, L.q.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)d * kp, L.k.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(w + (size_t)2 * d * kp, L.v.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                hipMemcpy(w, L.q.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                hipMemcpy(w + (size_t)d * kp, L.k.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                hipMemcpy(w + (size_t)2 * d * kp, L.v.w, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
                 hipMemset(b, 0, (size_t)3 * d * 4); hipMemcpy(b, L.q.b, (size_t)d * 4, hipMemcpyDeviceToDevice); hipMemcpy(b + 2 * d, L.v.b, (size_t)d * 4, hipMemcpyDeviceToDevice);
                 L.qkv.w = w; L.qkv.b = b;
                 if (L.q.w_nat && L.k.w_nat && L.v.w_nat) {      // the concatenation again in natural k order
                     half_t* wn = nullptr;
                     if (hipMalloc((void**)&wn, (size_t)3 * d * kp * 2) == hipSuccess) {
                         m->allocs.push_back(wn);
-                        hipMemcpy(wn, L.q.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(wn + (size_t)d * kp, L.k.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice); hipMemcpy(wn + (size_t)2 * d * kp, L.v.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                        hipMemcpy(wn, L.q.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                        hipMemcpy(wn + (size_t)d * kp, L.k.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
+                        hipMemcpy(wn + (size_t)2 * d * kp, L.v.w_nat, (size_t)d * kp * 2, hipMemcpyDeviceToDevice);
                         L.qkv.w_nat = wn;
                     }
                 }
             }
-            if (ok && wfrag_on) {   // fragment-order images for the f16 decode kernels (skw_make_wfrag): every decoder projection the small-M kernels multiply by; fc1's rows in its GELU epilogue's order
+            // fragment-order images for the f16 decode kernels (skw_make_wfrag): every decoder projection the small-M kernels multiply by; fc1's rows in its GELU epilogue's order
+            if (ok && wfrag_on) {
                 auto mk = [&](DevLin& X, int perm) {
                     if ((X.n_out & 15) || (X.k_pad & 31)) return;
                     for (int nat = 0; nat < 2; ++nat) {
@@ -339,7 +352,8 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
             if (ok && m->quant) {   // the same concatenation in the integer form
                 HostQ hq, hk, hv, all; host_q(*find_t(ts, p + "attn.query.weight"), &hq); host_q(*find_t(ts, p + "attn.key.weight"), &hk); host_q(*find_t(ts, p + "attn.value.weight"), &hv);
                 all.n_out = 3 * d; all.K = hq.K;
-                for (const HostQ* h : {&hq, &hk, &hv}) { all.q.insert(all.q.end(), h->q.begin(), h->q.end()); all.d.insert(all.d.end(), h->d.begin(), h->d.end()); all.m.insert(all.m.end(), h->m.begin(), h->m.end()); }
+                for (const HostQ* h : {&hq, &hk, &hv}) { all.q.insert(all.q.end(), h->q.begin(), h->q.end());
+                all.d.insert(all.d.end(), h->d.begin(), h->d.end()); all.m.insert(all.m.end(), h->m.begin(), h->m.end()); }
                 ok = up_q(m, all, m->quant, &L.qkv);
             }
         }
@@ -385,9 +399,14 @@ struct skw_ctx {
     float* x = nullptr; half_t* y16 = nullptr; half_t *Qh = nullptr, *Kh = nullptr, *Vt = nullptr; half_t* hbuf = nullptr; float* enc_out32 = nullptr;
     half_t *crossK = nullptr, *crossV = nullptr;
     // decoder
-    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr; half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr; float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr; int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;   // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
+    // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
+    float* dx = nullptr; half_t *dy16 = nullptr, *dq16 = nullptr, *datt16 = nullptr, *dh16 = nullptr;
+    half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
+    float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr;
+    int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;
     unsigned* ln_cnt = nullptr;
-    half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;   // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
+    // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
+    half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
     float* probs = nullptr; uint32_t* rng = nullptr;   // sampled (t > 0) passes: probability workspace, std::mt19937 state per clip
@@ -396,18 +415,27 @@ struct skw_ctx {
     int* h_row_live = nullptr; int* d_row_live = nullptr;      // per-row live flags in pinned host memory and their device-side address: k_dec_sample clears a row's flag itself,
                                                                // so a step ends with no 4-byte copy kernel (4.2 us in the chain of every step) — the host reads the flags after the stream drains
     int max_tok = 0;
-    int prompt_pass_on = 1;                          // the prompt ([prev] + past text + sot / language / task) in one multi-row pass instead of one token per step; SKW_PROMPT_PASS=0 or skw_debug_set_prompt_pass(ctx, 0)
+    // the prompt ([prev] + past text + sot / language / task) in one multi-row pass instead of one token per step; SKW_PROMPT_PASS=0 or skw_debug_set_prompt_pass(ctx, 0)
+    int prompt_pass_on = 1;
     int* pf_meta = nullptr; int pf_nseq = 0, pf_nq_max = 0;      // the pass's sequences on the device: [row0 | nq | slot] x max_batch (the multi-query cross attention of the f16_mfma prompt pass)
     int rows_cap = 0; SkwSeqState* pf_st = nullptr;  // decode-step scratch rows (>= max_batch: the prompt pass runs one row per prompt token) and the prompt pass's per-token pseudo-states
     int ln_stats_on = 1;                             // LayerNorm folded into the decode GEMMs (f16_mfma); SKW_DEC_LN_STATS=0 or skw_debug_set_ln_stats(ctx, 0): LayerNorm kernels
-    int live_rows_hint = -1;                         // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
+    // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
+    int live_rows_hint = -1;
     int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
     skw_timing timing{};
     int last_enc_B = 0;
+    struct WsEntry { const char* name; void** slot; size_t bytes; bool zero; };      // one workspace buffer: the field it fills and its size (skw_ctx_create)
+    std::vector<WsEntry> ws_table;
 };
-template <typename T> static T* ws_alloc(skw_ctx* c, size_t n, bool zero = false) {
-    T* d = nullptr; if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr; if (zero) (void)hipMemset(d, 0, n * sizeof(T)); c->allocs.push_back(d); return d;
+// name of the first workspace buffer whose pointer is null, or nullptr when every entry of the table is allocated
+static const char* ws_first_null(const skw_ctx* c) {
+    if (c->ws_table.empty()) return "(empty workspace table)";
+    for (const skw_ctx::WsEntry& e : c->ws_table) if (!*e.slot) return e.name;
+    return nullptr;
 }
+// every entry point that launches kernels starts here: a context whose table holds a null buffer never reaches a launch
+#define WS_READY(c) do { if (const char* nb_ = ws_first_null(c)) { snprintf((c)->errbuf, 512, "workspace buffer '%s' is not allocated", nb_); return -1; } } while (0)
 extern "C" const char* skw_ctx_last_error(const skw_ctx* c) { return c->errbuf; }
 extern "C" int skw_ctx_set_precision(skw_ctx* c, int precision) {
     if (precision != SKW_PRECISION_EXACT && precision != SKW_PRECISION_F16_MFMA) { snprintf(c->errbuf, 512, "unknown precision %d", precision); return -1; }
@@ -438,34 +466,93 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     { const char* e = getenv("SKW_PROMPT_PASS"); c->prompt_pass_on = e ? (atoi(e) != 0) : 1; }
     c->rows_cap = std::max(max_batch, std::min(max_batch * (SKW_PROMPT_CAP - 1), 4096));
     { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
-    for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess; ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
+    for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-#define WS(field, type, count, zero) ok = ok && ((c->field = ws_alloc<type>(c, (size_t)(count), zero)) != nullptr)
-    WS(pcm, float, (size_t)B * max_samples, false); WS(pcm_off, long, B, false); WS(n_samples, int, B, false); WS(n_len, int, B, false);
-    WS(mel, float, (size_t)B * c->n_len_max * hp.n_mels, false); WS(clip_max, float, B, false); WS(clip_idx, int, B, false); WS(seek, int, B, false); WS(row_tok, int, B, true); WS(prompt_buf, int, (size_t)B * SKW_PROMPT_CAP, true);
-    WS(im2col, half_t, (size_t)B * T * 256, false); WS(h1, half_t, (size_t)B * (T + 2) * d, true);
-    WS(x, float, (size_t)B * nc * d, false); WS(y16, half_t, (size_t)B * nc * d, false);
-    WS(Qh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Kh, half_t, (size_t)B * hp.n_audio_head * c->Tpad * 64, true); WS(Vt, half_t, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
-    WS(hbuf, half_t, (size_t)B * nc * 4 * d, false); WS(enc_out32, float, (size_t)nc * d, false);
-    WS(crossK, half_t, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);      // (zeroed: the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written)
-    WS(crossV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);   // V^T per head, keys kperm'ed, pad keys stay zero
-    { const size_t R = (size_t)c->rows_cap;
-      WS(dx, float, R * dt, false); WS(dy16, half_t, R * dt, false); WS(dq16, half_t, R * dt, false); WS(datt16, half_t, (R + 16) * dt, false); WS(dh16, half_t, (R + 16) * 4 * dt, false); WS(pf_st, SkwSeqState, R, true); WS(pf_meta, int, (size_t)3 * B, true); }
-    WS(selfK, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true); WS(selfV, half_t, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
-    WS(logits, float, (size_t)B * hp.n_vocab, false); WS(ln_cnt, unsigned, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
-    if (m->quant) {
-        const int kmax = 4 * std::max(d, dt); const size_t rows = (size_t)B * nc; c->q8_kmax = kmax;
-        WS(y32, float, rows * d, false); WS(h32, float, rows * 4 * d, false); WS(encq32, float, rows * d, false);
-        WS(dy32, float, (size_t)c->rows_cap * dt, false); WS(datt32, float, (size_t)c->rows_cap * dt, false); WS(dh32, float, (size_t)c->rows_cap * 4 * dt, false);
-        WS(q8_a, int8_t, rows * kmax, false); WS(q8_d, float, rows * (kmax / 32), false); WS(q8_s, float, rows * (kmax / 32), false);
-    }
+    // The workspace, as a table: one buffer per line — name, the context field it fills, element count, zero-filled or not.  Every entry is
+    // allocated by the loop below and verified non-null BY NAME (skw_ctx_create fails with the buffer's name; full_batch_impl re-checks the table
+    // before its first launch), so a buffer that is declared but never allocated cannot reach a kernel as a null pointer.
+    const size_t R = (size_t)c->rows_cap;
+    const size_t enc_rows = (size_t)B * nc;
+    const int kmax = 4 * std::max(d, dt);
     c->max_tok = hp.n_text_ctx / 2;
-    WS(st, SkwSeqState, B, true); WS(toks, SkwTokenOut, (size_t)B * c->max_tok, true); WS(probs, float, (size_t)B * skw_probs_row_floats(hp.n_vocab), false); WS(rng, uint32_t, (size_t)B * SKW_RNG_WORDS, true); WS(static_mask, uint8_t, skw_static_mask_bytes(hp.n_vocab), true);
-#undef WS
+    if (m->quant) c->q8_kmax = kmax;
+    auto want = [&](const char* name, auto*& field, size_t count, bool zero) {
+        c->ws_table.push_back(skw_ctx::WsEntry{name, (void**)&field, count * sizeof(*field), zero});
+    };
+    // front end
+    want("pcm", c->pcm, (size_t)B * max_samples, false);
+    want("pcm_off", c->pcm_off, B, false);
+    want("n_samples", c->n_samples, B, false);
+    want("n_len", c->n_len, B, false);
+    want("mel", c->mel, (size_t)B * c->n_len_max * hp.n_mels, false);
+    want("clip_max", c->clip_max, B, false);
+    want("clip_idx", c->clip_idx, B, false);
+    want("seek", c->seek, B, false);
+    want("row_tok", c->row_tok, B, true);
+    want("prompt_buf", c->prompt_buf, (size_t)B * SKW_PROMPT_CAP, true);
+    want("im2col", c->im2col, (size_t)B * T * 256, false);
+    want("h1", c->h1, (size_t)B * (T + 2) * d, true);
+    // encoder
+    want("x", c->x, enc_rows * d, false);
+    want("y16", c->y16, enc_rows * d, false);
+    want("Qh", c->Qh, (size_t)B * hp.n_audio_head * c->Tpad * 64, true);
+    want("Kh", c->Kh, (size_t)B * hp.n_audio_head * c->Tpad * 64, true);
+    want("Vt", c->Vt, (size_t)B * hp.n_audio_head * 64 * c->Tpad, true);
+    want("hbuf", c->hbuf, enc_rows * 4 * d, false);
+    want("enc_out32", c->enc_out32, (size_t)nc * d, false);
+    // cross K: zeroed — the fragment-order image's pad keys, rows n_audio_ctx .. Tpad of a slot, are never written
+    want("crossK", c->crossK, (size_t)hp.n_text_layer * B * c->Tpad * dt, true);
+    // cross V^T per head, keys kperm'ed, pad keys stay zero
+    want("crossV", c->crossV, (size_t)hp.n_text_layer * B * hp.n_text_head * 64 * c->Tpad, true);
+    // decoder: step scratch rows (sized for the prompt pass), caches, logits, sampler state
+    want("dx", c->dx, R * dt, false);
+    want("dy16", c->dy16, R * dt, false);
+    want("dq16", c->dq16, R * dt, false);
+    want("datt16", c->datt16, (R + 16) * dt, false);
+    want("dh16", c->dh16, (R + 16) * 4 * dt, false);
+    want("pf_st", c->pf_st, R, true);
+    want("pf_meta", c->pf_meta, (size_t)3 * B, true);
+    want("selfK", c->selfK, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
+    want("selfV", c->selfV, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
+    want("logits", c->logits, (size_t)B * hp.n_vocab, false);
+    want("ln_cnt", c->ln_cnt, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
+    want("st", c->st, B, true);
+    want("toks", c->toks, (size_t)B * c->max_tok, true);
+    want("probs", c->probs, (size_t)B * skw_probs_row_floats(hp.n_vocab), false);
+    want("rng", c->rng, (size_t)B * SKW_RNG_WORDS, true);
+    want("static_mask", c->static_mask, skw_static_mask_bytes(hp.n_vocab), true);
+    if (m->quant) {      // ggml q8 arithmetic (quantised files, exact precision): unrounded f32 activations and their q8 blocks
+        want("y32", c->y32, enc_rows * d, false);
+        want("h32", c->h32, enc_rows * 4 * d, false);
+        want("encq32", c->encq32, enc_rows * d, false);
+        want("dy32", c->dy32, R * dt, false);
+        want("datt32", c->datt32, R * dt, false);
+        want("dh32", c->dh32, R * 4 * dt, false);
+        want("q8_a", c->q8_a, enc_rows * kmax, false);
+        want("q8_d", c->q8_d, enc_rows * (kmax / 32), false);
+        want("q8_s", c->q8_s, enc_rows * (kmax / 32), false);
+    }
+    const char* ws_failed = nullptr;
+    size_t ws_failed_bytes = 0;
+    for (const skw_ctx::WsEntry& e : c->ws_table) {
+        if (!ok) break;
+        void* p = nullptr;
+        if (hipMalloc(&p, e.bytes) != hipSuccess || !p) { ok = false; ws_failed = e.name; ws_failed_bytes = e.bytes; break; }
+        c->allocs.push_back(p);
+        if (e.zero) (void)hipMemset(p, 0, e.bytes);
+        *e.slot = p;
+    }
+    if (ok) ws_failed = ws_first_null(c);
+    if (ws_failed) {
+        set_err(err, errlen, "workspace buffer '%s' could not be allocated (%zu bytes, max_batch %d)", ws_failed, ws_failed_bytes, max_batch);
+        skw_ctx_free(c);
+        return nullptr;
+    }
     ok = ok && hipHostMalloc((void**)&c->h_st, sizeof(SkwSeqState) * B) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_toks, sizeof(SkwTokenOut) * B * c->max_tok) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&c->h_row_live, sizeof(int) * B, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_row_live, c->h_row_live, 0) == hipSuccess;
-    if (!ok) { set_err(err, errlen, "workspace allocation failed (max_batch %d)", max_batch); skw_ctx_free(c); return nullptr; }
+    if (!ok) { set_err(err, errlen, "stream, event or pinned host allocation failed (max_batch %d)", max_batch); skw_ctx_free(c); return nullptr; }
     hipDeviceSynchronize();
     return c;
 }
@@ -501,10 +588,12 @@ extern "C" int skw_debug_make_wfrag(const uint16_t* w_host, int N, int K, int pe
     if (hipMalloc((void**)&dw, n_in * 2) != hipSuccess || hipMalloc((void**)&di, n_out * 2) != hipSuccess) { hipFree(dw); hipFree(di); return -2; }
     int rc = 0;
     if (hipMemcpy(dw, w_host, n_in * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemset(di, 0xff, n_out * 2) != hipSuccess) rc = -3;
-    if (!rc) { skw_make_wfrag(dw, K, N & ~15, K, perm, di, nullptr); if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img_host, di, (size_t)(N & ~15) * K * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = -4; }
+    if (!rc) { skw_make_wfrag(dw, K, N & ~15, K, perm, di, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(img_host, di, (size_t)(N & ~15) * K * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = -4; }
     hipFree(dw); hipFree(di); return rc;
 }
-extern "C" void skw_debug_set_kv_frag(skw_ctx* c, int on) { c->kv_frag_on = on != 0; }                // tests: f16_mfma cross K / V^T as fragment-order images (one-pass cross attention) / as rows (two-phase kernel); takes effect at the next encoder pass
+// tests: f16_mfma cross K / V^T as fragment-order images (one-pass cross attention) / as rows (two-phase kernel); takes effect at the next encoder pass
+extern "C" void skw_debug_set_kv_frag(skw_ctx* c, int on) { c->kv_frag_on = on != 0; }
 extern "C" void skw_debug_set_prompt_pass(skw_ctx* c, int on) { c->prompt_pass_on = on != 0; }     // tests: the prompt as one pass / one token per step
 extern "C" void skw_debug_set_ln_stats(skw_ctx* c, int on) { c->ln_stats_on = on != 0; }      // tests: the decode step with / without the LayerNorm launches (f16_mfma)
 extern "C" void skw_debug_enable(int on) { g_taps_on = on != 0; g_taps.clear(); }
@@ -534,7 +623,8 @@ static void tap(skw_ctx* c, const char* name, const void* dev, int rows, int col
 enum ProfClass { PC_GEMM = 0, PC_GEMM_SMALL, PC_ATTN_ENC, PC_LAYERNORM, PC_MEL, PC_DEC_ATTN, PC_DEC_SAMPLE, PC_OTHER, PC_DEC_XATTN, PC_COUNT };
 static const char* const g_prof_names[PC_COUNT] = {"k_gemm", "k_gemm_smallm", "k_attn_encoder", "k_layernorm", "k_mel", "k_dec_self_attn", "k_dec_sample", "other", "k_dec_cross_attn"};
 struct ProfRec { int cls; double flops, bytes; hipEvent_t a, b; };
-struct ProfState { bool on = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t next = 0; double ms[PC_COUNT] = {}, flops[PC_COUNT] = {}, bytes[PC_COUNT] = {}; long count[PC_COUNT] = {}; };
+struct ProfState { bool on = false; std::vector<ProfRec> recs;
+std::vector<hipEvent_t> pool; size_t next = 0; double ms[PC_COUNT] = {}, flops[PC_COUNT] = {}, bytes[PC_COUNT] = {}; long count[PC_COUNT] = {}; };
 static void prof_free(skw_ctx* c) { if (!c->prof) return; for (hipEvent_t e : c->prof->pool) hipEventDestroy(e); delete c->prof; c->prof = nullptr; }
 struct ProfScope {
     ProfState* ps; skw_ctx* c; size_t idx; bool ext;      // ext: the launch stamps the two events itself (hipExtLaunchKernelGGL: kernel begin / end, what rocprofv3 calls the duration)
@@ -557,16 +647,20 @@ hipEvent_t ProfScope::ev_b() const { return (ps && ext) ? ps->recs[idx].b : null
 static void prof_collect(skw_ctx* c) {
     if (!c->prof || !c->prof->on) return; ProfState& ps = *c->prof;
     hipStreamSynchronize(c->stream);
-    for (auto& r : ps.recs) { float ms = 0; if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue; ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
+    for (auto& r : ps.recs) { float ms = 0; if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    ps.ms[r.cls] += ms; ps.flops[r.cls] += r.flops; ps.bytes[r.cls] += r.bytes; ps.count[r.cls]++; }
     ps.recs.clear(); ps.next = 0;
 }
-extern "C" void skw_ctx_profile(skw_ctx* c, int on) { if (!c->prof) c->prof = new ProfState(); ProfState& ps = *c->prof; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0; ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
+extern "C" void skw_ctx_profile(skw_ctx* c, int on) { if (!c->prof) c->prof = new ProfState();
+ProfState& ps = *c->prof; ps.on = on != 0; for (int i = 0; i < PC_COUNT; ++i) { ps.ms[i] = ps.flops[i] = ps.bytes[i] = 0;
+ps.count[i] = 0; } ps.recs.clear(); ps.next = 0; }
 extern "C" int skw_ctx_profile_get(skw_ctx* c, int cls, char* name, size_t name_len, long* count, double* ms, double* flops, double* bytes) {
     if (cls < 0 || cls >= PC_COUNT || !c->prof) return -1; ProfState& ps = *c->prof;
     if (name) snprintf(name, name_len, "%s", g_prof_names[cls]); *count = ps.count[cls]; *ms = ps.ms[cls]; *flops = ps.flops[cls]; *bytes = ps.bytes[cls]; return 0;
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops; bytes = operands read once + result written once
-static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical; *by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
+static void gemm_work(const SkwGemmArgs& a, int k_logical, double* fl, double* by) { *fl = 2.0 * a.M * a.N * k_logical;
+*by = 2.0 * ((double)a.M * k_logical + (double)a.N * k_logical) + 2.0 * a.M * a.N; }
 static void GEMM(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     double fl, by; gemm_work(a, k_logical, &fl, &by); ProfScope p(c, PC_GEMM, fl, by);
     if (c->precision == SKW_PRECISION_F16_MFMA && (a.K & 63) == 0) skw_gemm16(a, c->cur);   // K step of the f16 kernel is 64; every Whisper geometry satisfies it
@@ -621,7 +715,8 @@ static void Q8_GEMM(skw_ctx* c, SkwGemmArgs a, const DevLin& L, int r0, bool dec
 static SkwGemmArgs q8_args(int M, void* C, long ldc, int epi) { SkwGemmArgs a{}; a.M = M; a.C = C; a.ldc = ldc; a.epi = epi; a.scale = 1.0f; return a; }
 
 static SkwGemmArgs gemm_args(const half_t* A, long lda, const DevLin& L, int M, void* C, long ldc, int epi) {
-    SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.Wf = L.w_frag; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C; a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
+    SkwGemmArgs a{}; a.A = A; a.lda = lda; a.W = L.w; a.Wf = L.w_frag; a.ldw = L.k_pad; a.M = M; a.N = L.n_out; a.K = L.k_pad; a.C = C;
+    a.ldc = ldc; a.bias = L.b; a.epi = epi; a.scale = 1.0f; return a;
 }
 
 // front end for `n` clips already described in c->pcm_off / n_samples / n_len (device): mel + normalisation
@@ -639,7 +734,8 @@ static void run_conv(skw_ctx* c, int Bw_all, int row0 = 0) {
     skw_mel_im2col(c->mel, c->clip_idx + row0, c->seek + row0, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
     SkwGemmArgs a = gemm_args(c->im2col, 256, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
     GEMM(c, a, m->conv1.n_in);
-    SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d; b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;
+    SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d;
+    b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;
     GEMM(c, b, m->conv2.n_in);
 }
 // encoder blocks + ln_post (+ cross K/V) over Bw windows; input c->x
@@ -687,8 +783,10 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
         { SkwGemmArgs a = gemm_args(c->y16, d, L.q, M, c->Qh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; GEMM(c, a, d); }
         { SkwGemmArgs a = gemm_args(c->y16, d, L.k, M, c->Kh, 0, EPI_HEADS_F16); a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; GEMM(c, a, d); }
         { // V^T via the swapped product: rows = features (weights as the A operand), columns = tokens
-            SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt; a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
-            if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.v.w; a.ldw = L.v.k_pad; a.M = M; a.N = L.v.n_out; }   // the f16 kernel takes V^T in the natural orientation (tokens x features)
+            SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt;
+            a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
+            // the f16 kernel takes V^T in the natural orientation (tokens x features)
+            if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.v.w; a.ldw = L.v.k_pad; a.M = M; a.N = L.v.n_out; }
             GEMM(c, a, d);
         }
         if (l == 0) { tap(c, "l0.q", c->Qh, nc, d, TAP_HEADS); tap(c, "l0.k", c->Kh, nc, d, TAP_HEADS); tap(c, "l0.v", c->Vt, nc, d, TAP_VT); }
@@ -700,7 +798,8 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
           if (c->precision == SKW_PRECISION_F16_MFMA && !dbg) skw_attn_encoder16(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream);
           else skw_attn_encoder(c->Qh, c->Kh, c->Vt, c->y16, d, Bw, H, nc, c->Tpad, c->stream, dbg, dbg2); }
         if (dbg2) { tap(c, "l0.SP", dbg2, 64, c->Tpad, TAP_F32); hipFree(dbg2); }
-        if (dbg) { tap(c, "l0.att32", dbg, nc, d, TAP_F32); tap(c, "l0.rmax", dbg + (size_t)nc * d, H, nc, TAP_F32); tap(c, "l0.rinv", dbg + (size_t)nc * d + (size_t)H * nc, H, nc, TAP_F32); hipFree(dbg); }
+        if (dbg) { tap(c, "l0.att32", dbg, nc, d, TAP_F32); tap(c, "l0.rmax", dbg + (size_t)nc * d, H, nc, TAP_F32);
+        tap(c, "l0.rinv", dbg + (size_t)nc * d + (size_t)H * nc, H, nc, TAP_F32); hipFree(dbg); }
         if (l == 0) tap(c, "l0.att", c->y16, nc, d, TAP_F16_KPERM);
         { SkwGemmArgs a = gemm_args(c->y16, d, L.o, M, c->x, d, EPI_F32); a.res = c->x; a.ldres = d; GEMM(c, a, d); }
         if (l == 0) tap(c, "l0.x1", c->x, nc, d, TAP_F32);
@@ -717,9 +816,11 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
         for (int l = 0; l < hp.n_text_layer; ++l) {
             const DecLayer& L = m->dec[l];
             half_t* ck = c->crossK + (size_t)l * c->max_batch * c->kclip() + xk0; half_t* cv = c->crossV + (size_t)l * c->max_batch * hp.n_text_head * 64 * c->Tpad + xv0;
-            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; if (c->kv_frag()) { a.frag = 1; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; } GEMM(c, a, d); }
+            { SkwGemmArgs a = gemm_args(c->y16, d, L.ck, M, ck, dt, EPI_F16_PLAIN); a.scale = Kscale; a.has_scale = 1; if (c->kv_frag()) { a.frag = 1;
+            a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; } GEMM(c, a, d); }
             { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
-                SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv; a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
+                SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv;
+                a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
                 if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; a.frag = c->kv_frag(); }
                 GEMM(c, a, d);
             }
@@ -747,7 +848,8 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     float* dx = c->dx + (size_t)r0 * dt; half_t* dy16 = c->dy16 + (size_t)r0 * dt; half_t* dq16 = c->dq16 + (size_t)r0 * dt; half_t* datt16 = c->datt16 + (size_t)r0 * dt;
     half_t* dh16 = c->dh16 + (size_t)r0 * 4 * dt; SkwSeqState* st = prefill ? c->pf_st : c->st + r0;
     const int* seqp = prefill ? &st[0].pad : nullptr;                                  // row -> sequence for the attention kernels
-    const int* kvpos = prefill ? &st[0].seek : &st[0].cur_pos;                          // where the QKV epilogue appends a row's K / V: absolute cache row (prefill) or position inside the row's own cache
+    // where the QKV epilogue appends a row's K / V: absolute cache row (prefill) or position inside the row's own cache
+    const int* kvpos = prefill ? &st[0].seek : &st[0].cur_pos;
     const long kv_ld = prefill ? 0 : (long)ntc * dt;
     if (use_q8(c)) {   // quantised file, exact precision: ggml's arithmetic (see run_encoder); the row group's q8 scratch starts at its first row
         float* dy32 = c->dy32 + (size_t)r0 * dt; float* datt32 = c->datt32 + (size_t)r0 * dt; float* dh32 = c->dh32 + (size_t)r0 * 4 * dt;
@@ -757,14 +859,16 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
             half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
             half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
             Q8_LN(c, dx, Bw, dt, L.attn_ln, r0, dy32);
-            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
+            { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt; a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld;
+            a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); Q8_GEMM(c, a, L.qkv, r0, true); }
             { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
               SkwQ8Out qo{c->q8_a + (size_t)r0 * c->q8_kmax, c->q8_d + (size_t)r0 * (c->q8_kmax / 32), c->q8_s + (size_t)r0 * (c->q8_kmax / 32), Bw};
               skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, nullptr, &st[0].active, s, 0, qo, seqp); }
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.o, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.cross_ln, r0, dy32);
             { SkwGemmArgs a = q8_args(Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; Q8_GEMM(c, a, L.cq, r0, true); }
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1, 0, seqp); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt);
+            skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, (half_t*)datt32, &st[0].active, s, 1, 0, seqp); }
             Q8_ROWS(c, datt32, dt, Bw, dt, r0);
             { SkwGemmArgs a = q8_args(Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; Q8_GEMM(c, a, L.co, r0, true); }
             Q8_LN(c, dx, Bw, dt, L.mlp_ln, r0, dy32);
@@ -788,13 +892,15 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
     const bool embed_ln = dt <= 1536;
     // LayerNorm without a launch (f16_mfma): the GEMM that consumes LayerNorm(x) loads the f32 rows, takes their statistics from its own
     // registers and normalises on the way into the MFMA.  35 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
-    const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
+    const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat
+        && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
     auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
     // the prompt pass of a long-form batch is thousands of rows: there the projections are the encoder's big-tile GEMM (f16_mfma; the small-M kernels stream the
     // weights once per 16 rows and reach ~50 TF/s at M = 4096, the big kernel 600).  The QKV product keeps the decode form: its epilogue appends to the K / V caches.
     const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !getenv("SKW_PROMPT_SMALL_GEMM");
     static const bool afrag_on = !(getenv("SKW_DEC_AFRAG") && atoi(getenv("SKW_DEC_AFRAG")) == 0);
-    // the attention kernels leave their rows as the fragment-order A image the out-projections read (f16_mfma, small-M kernels on both sides; the cross attention: the one-pass kernel / its multi-query prompt form)
+    // the attention kernels leave their rows as the fragment-order A image the out-projections read (f16_mfma, small-M kernels on both sides; the cross attention: the one-pass
+    //  kernel / its multi-query prompt form)
     const bool sa_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0, xa_frag = sa_frag && c->kv_frag();
     auto gemm_s = [&](const SkwGemmArgs& a) { if (bigM) GEMM(c, a, a.K); else GEMM_S(c, a, a.K); };
     // a GEMM fed by LayerNorm(dx): the normalising form (site >= 0), else LayerNorm kernel + GEMM
@@ -818,12 +924,16 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* sk = c->selfK + ((size_t)l * c->max_batch + r0) * ntc * dt; half_t* sv = c->selfV + ((size_t)l * c->max_batch + r0) * ntc * dt;
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
-          a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int)); gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
-        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt); skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA, sa_frag); }
+          a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int));
+          gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
+        { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
+        skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA, sa_frag);
+        }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = sa_frag; with_ln(a, L.cross_ln); gemm_s(a); }
         // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
         bool fused_q = false;
-        if (!tail && !lnA && !prefill && !c->kv_frag() && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
+        if (!tail && !lnA && !prefill && !c->kv_frag() && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN,
+            4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
             fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
         if (!fused_q) {
             { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
@@ -834,7 +944,9 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
                 ProfScope p_(c, PC_DEC_XATTN, 4.0 * Bw * (double)nc * 64.0 * H, 4.0 * c->pf_nseq * (double)nc * dt);
                 skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s, c->kv_frag(), xa_frag);
             } else
-            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true); skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b(), xa_frag); }
+            { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true);
+            skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b(), xa_frag);
+            }
         }
         { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = xa_frag && !fused_q; with_ln(a, L.mlp_ln); gemm_s(a); }
         // f16_mfma, small-M kernels on both sides: fc1 leaves its output as the fragment-order A image fc2 reads (fc2 7.4 -> 6.5 us per launch); the prompt pass's big-tile GEMMs keep rows
@@ -845,7 +957,8 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
           gemm_s(a); }
     }
     if (want_logits) {
-        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }      // (the vocabulary kernel's 256 workgroups would each normalise all 64 rows: measured +6.4 us against this 5.0 us launch)
+        // (the vocabulary kernel's 256 workgroups would each normalise all 64 rows: measured +6.4 us against this 5.0 us launch)
+        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
         SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
     c->cur = c->stream;
@@ -864,7 +977,8 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     run_decoder_step(c, r0, n, 0, true, s);
-    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->d_row_live + r0, c->probs + (size_t)r0 * skw_probs_row_floats(NV), c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
+    skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->d_row_live + r0,
+        c->probs + (size_t)r0 * skw_probs_row_floats(NV), c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
     hipGraphDestroy(graph);
@@ -947,7 +1061,8 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
     const long ke = (long)c->kclip(), ka = (long)c->Tpad * hp.n_text_state, ve = (long)hp.n_text_head * 64 * c->Tpad;      // ka: the staging buffer is sized like crossK (Tpad rows per slot)
     if (!c->stageK || !c->stageV || !c->slot_map) {      // all three or none: a partial failure must not leave a later retry launching k_slot_copy on a null buffer
         half_t *sk = nullptr, *sv = nullptr; int* sm = nullptr;
-        if (hipMalloc((void**)&sk, (size_t)L * c->max_batch * ka * 2) != hipSuccess || hipMalloc((void**)&sv, (size_t)L * c->max_batch * ve * 2) != hipSuccess || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
+        if (hipMalloc((void**)&sk, (size_t)L * c->max_batch * ka * 2) != hipSuccess || hipMalloc((void**)&sv, (size_t)L * c->max_batch * ve * 2) != hipSuccess
+            || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
             hipFree(sk); hipFree(sv); hipFree(sm); snprintf(errbuf, 512, "temperature retry: staging buffers for the cross K/V move could not be allocated"); return -1;
         }
         hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); c->stageK = sk; c->stageV = sv; c->slot_map = sm;
@@ -968,6 +1083,7 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
 static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results,
                            const int32_t* const* forced_ids, const int32_t* n_forced, std::vector<std::vector<SkwTraceStep>>* traces) {
     char* errbuf = c->errbuf; errbuf[0] = 0;
+    WS_READY(c);
     if (n_clips < 1 || n_clips > c->max_batch) { snprintf(errbuf, 512, "n_clips %d outside [1, %d]", n_clips, c->max_batch); return -1; }
     HIPCHK(hipSetDevice(c->m->device));
     const bool tracing = traces != nullptr;
@@ -1040,7 +1156,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; int* pr = pbuf.data() + (size_t)j * SKW_PROMPT_CAP; int n = 0, take = 0;
             if (!prompt_past[ci].empty() && temps[tidx[ci]] < 0.5f) {
-                take = std::min(std::min(hp.n_text_ctx / 2, (int)prompt_past[ci].size()), hp.n_text_ctx - lp.n_max - n_prompt - 1);   // the last bound only binds with no_timestamps: every position stays inside n_text_ctx
+                // the last bound only binds with no_timestamps: every position stays inside n_text_ctx
+                take = std::min(std::min(hp.n_text_ctx / 2, (int)prompt_past[ci].size()), hp.n_text_ctx - lp.n_max - n_prompt - 1);
                 pr[n++] = m->tok_prev; for (int i = 0; i < take; ++i) pr[n++] = prompt_past[ci][prompt_past[ci].size() - take + i];
             }
             last_take[ci] = take;
@@ -1062,7 +1179,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         // decoder state
         for (int j = 0; j < Bw; ++j) {
             SkwSeqState& s = c->h_st[j]; memset(&s, 0, sizeof s);
-            s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j]; s.seek_end = n_len_org[act[j]]; s.n_prompt = np_row[j]; s.min_margin = INFINITY; s.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP]; s.cur_pos = 0;
+            s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = sk[j];
+            s.seek_end = n_len_org[act[j]]; s.n_prompt = np_row[j]; s.min_margin = INFINITY; s.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP]; s.cur_pos = 0;
             s.temperature = temps[tidx[act[j]]];
         }
         // The prompt in one pass (whisper.cpp evaluates it in one whisper_decode call): every prompt token but a row's last becomes a row of ONE decoder pass —
@@ -1075,7 +1193,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
             const int ntc = hp.n_text_ctx;
             std::vector<SkwSeqState> pf; std::vector<int> row_end;      // row_end: cumulative rows after each sequence (chunks are whole sequences)
             for (int j = 0; j < Bw; ++j) {
-                for (int k = 0; k + 1 < np_row[j]; ++k) { SkwSeqState t; memset(&t, 0, sizeof t); t.active = 1; t.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP + k]; t.cur_pos = k; t.pad = j; t.seek = j * ntc + k; pf.push_back(t); }
+                for (int k = 0; k + 1 < np_row[j]; ++k) { SkwSeqState t; memset(&t, 0, sizeof t);
+                t.active = 1; t.cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP + k]; t.cur_pos = k; t.pad = j; t.seek = j * ntc + k; pf.push_back(t); }
                 row_end.push_back((int)pf.size());
                 c->h_st[j].cur_token = pbuf[(size_t)j * SKW_PROMPT_CAP + np_row[j] - 1]; c->h_st[j].cur_pos = np_row[j] - 1;
             }
@@ -1102,7 +1221,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
         const int n_groups = c->n_groups > 0 ? c->n_groups : 1;   // one row group in both precisions (exact: 194 ms against 213 with two, since the segmented decode GEMMs; f16_mfma: 178 against 204)
-        const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;   // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
+        // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
+        const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;
         const int G = std::max(1, std::min(n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
         for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; }
@@ -1115,8 +1235,11 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         if (use_graphs && !profiling && !tracing) for (int g = 0; g < G; ++g) gexec[g] = step_graph(c, g, g_r0[g], g_n[g], lp);   // nullptr -> eager launches
         auto sample = [&](int g) {
             c->cur = c->gstream[g];
-            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g], c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->d_row_live + g_r0[g], c->probs + (size_t)g_r0[g] * skw_probs_row_floats(NV), c->rng, c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g],
-                                                                                     tracing ? c->forced_dev + (size_t)g_r0[g] * c->max_tok : nullptr, tracing ? c->trace_dev + (size_t)g_r0[g] * c->max_tok : nullptr); }
+            { ProfScope p_(c, PC_DEC_SAMPLE, 0, 4.0 * g_n[g] * NV); skw_dec_sample(c->logits + (size_t)g_r0[g] * NV, c->static_mask, lp, c->st + g_r0[g],
+                c->toks + (size_t)g_r0[g] * c->max_tok, c->max_tok, g_n[g], c->d_row_live + g_r0[g], c->probs + (size_t)g_r0[g] * skw_probs_row_floats(NV), c->rng,
+                c->clip_idx + g_r0[g], c->prompt_buf + (size_t)g_r0[g] * SKW_PROMPT_CAP, c->gstream[g],
+                                                                                     tracing ? c->forced_dev + (size_t)g_r0[g] * c->max_tok : nullptr,
+                                                                                         tracing ? c->trace_dev + (size_t)g_r0[g] * c->max_tok : nullptr); }
             c->cur = c->stream;
             return hipSuccess;
         };
@@ -1133,12 +1256,14 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
                 for (int g = 0; g < G; ++g) if (g_live[g]) {
                     if (gexec[g]) HIPCHK(hipGraphLaunch(gexec[g], c->gstream[g]));
                     else {
-                        if (profiling) { int lv = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) lv += ((volatile int*)c->h_row_live)[j] != 0; c->live_rows_hint = lv; }   // (ahead == 1: the previous step has drained)
+                        // (ahead == 1: the previous step has drained)
+                        if (profiling) { int lv = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) lv += ((volatile int*)c->h_row_live)[j] != 0; c->live_rows_hint = lv; }
                         run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); c->live_rows_hint = -1; HIPCHK(sample(g));
                     }
                 }
             bool any = false;
-            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g])); int live = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) live += ((volatile int*)c->h_row_live)[j] != 0;
+            for (int g = 0; g < G; ++g) if (g_live[g]) { HIPCHK(hipStreamSynchronize(c->gstream[g]));
+            int live = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) live += ((volatile int*)c->h_row_live)[j] != 0;
                                                         if (live <= 0) g_live[g] = false; else any = true; }
             if (!any) break;
         }
@@ -1152,14 +1277,18 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
             HIPCHK(hipMemcpy(tb.data(), c->trace_dev, sizeof(SkwTraceStep) * tb.size(), hipMemcpyDeviceToHost));
             for (int j = 0; j < Bw; ++j) {
                 const int ci = act[j], n = std::min(c->h_st[j].n_tokens, c->max_tok);
-                if (forced_ids && forced_ids[ci] && f_cursor[ci] + n > n_forced[ci]) { snprintf(errbuf, 512, "clip %d: forced token sequence exhausted (%d given, decision %d reached): the runs' control flow diverged", ci, n_forced[ci], f_cursor[ci] + n); return -4; }
+                if (forced_ids && forced_ids[ci] && f_cursor[ci] + n > n_forced[ci]) { snprintf(errbuf, 512,
+                    "clip %d: forced token sequence exhausted (%d given, decision %d reached): the runs' control flow diverged", ci, n_forced[ci], f_cursor[ci] + n);
+                return -4; }
                 (*traces)[ci].insert((*traces)[ci].end(), tb.begin() + (size_t)j * c->max_tok, tb.begin() + (size_t)j * c->max_tok + n);
                 f_cursor[ci] += n;
             }
         }
         { float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[2], c->ev[3]); hipEventElapsedTime(&b, c->ev[3], c->ev[4]); enc_ms += a; dec_ms += b; }
         tot_windows += Bw;
-        { int mx = 0; for (int j = 0; j < Bw; ++j) { const int rs = c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens; mx = std::max(mx, c->prompt_pass_on ? c->h_st[j].n_tokens : rs); tot_row_steps += rs; } tot_steps += mx + prefill_passes; }   // decoder passes until the last row finished (the prompt pass counts as one); row-steps: (row, token) pairs that streamed cross K / V, prompt tokens included
+        // decoder passes until the last row finished (the prompt pass counts as one); row-steps: (row, token) pairs that streamed cross K / V, prompt tokens included
+        { int mx = 0; for (int j = 0; j < Bw; ++j) { const int rs = c->h_st[j].n_prompt - 1 + c->h_st[j].n_tokens;
+        mx = std::max(mx, c->prompt_pass_on ? c->h_st[j].n_tokens : rs); tot_row_steps += rs; } tot_steps += mx + prefill_passes; }
         // per-clip: ranking, segment assembly, seek update (whisper_full_with_state tail)
         for (int j = 0; j < Bw; ++j) {
             const int ci = act[j]; const SkwSeqState& s = c->h_st[j]; const SkwTokenOut* tk = c->h_toks + (size_t)j * c->max_tok; skw_result& R = results[ci]; SeqAcc& A = acc[ci];
@@ -1218,7 +1347,9 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
     }
     prof_collect(c);
     { float a = 0, t = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&t, c->ev[0], c->ev[5]);
-      c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms; c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps; c->timing.n_tokens = tot_tokens; c->timing.n_row_steps = (int32_t)tot_row_steps; }
+      c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms;
+      c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps;
+      c->timing.n_tokens = tot_tokens; c->timing.n_row_steps = (int32_t)tot_row_steps; }
     return 0;
 }
 extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
@@ -1248,10 +1379,12 @@ extern "C" int skw_full_batch_traced(skw_ctx* c, const skw_full_params* p, const
 extern "C" int skw_debug_sample_rows(skw_ctx* c, const skw_full_params* p, int n_rows, const int32_t* hist, int hist_stride, const int32_t* n_hist, const float* logits_host, int form,
                                      float* filtered_out, skw_token* tok_out, skw_trace_step* trace_out) {
     char* errbuf = c->errbuf; errbuf[0] = 0;
+    WS_READY(c);
     if (n_rows < 1 || n_rows > c->max_batch) { snprintf(errbuf, 512, "n_rows %d outside [1, %d]", n_rows, c->max_batch); return -1; }
     HIPCHK(hipSetDevice(c->m->device));
     const skw_model* m = c->m; const int NV = m->hp.n_vocab, MT = c->max_tok;
-    for (int r = 0; r < n_rows; ++r) if (n_hist[r] < 0 || n_hist[r] >= MT || n_hist[r] > hist_stride) { snprintf(errbuf, 512, "row %d: history of %d tokens (at most %d)", r, n_hist[r], MT - 1); return -1; }
+    for (int r = 0; r < n_rows; ++r) if (n_hist[r] < 0 || n_hist[r] >= MT || n_hist[r] > hist_stride) { snprintf(errbuf, 512, "row %d: history of %d tokens (at most %d)", r, n_hist[r], MT - 1);
+    return -1; }
     if (!c->trace_dev) {
         int* f = nullptr; SkwTraceStep* t = nullptr;
         if (hipMalloc((void**)&f, sizeof(int) * (size_t)c->max_batch * MT) != hipSuccess || hipMalloc((void**)&t, sizeof(SkwTraceStep) * (size_t)c->max_batch * MT) != hipSuccess) {
@@ -1264,12 +1397,14 @@ extern "C" int skw_debug_sample_rows(skw_ctx* c, const skw_full_params* p, int n
     std::vector<int> forced((size_t)n_rows * MT, -1), zero(n_rows, 0);
     for (int r = 0; r < n_rows; ++r) {
         SkwSeqState& s = c->h_st[r]; memset(&s, 0, sizeof s);
-        s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = 0; s.seek_end = 100 * WHISPER_CHUNK_SIZE; s.n_prompt = 1; s.min_margin = INFINITY; s.cur_pos = n_hist[r]; s.n_tokens = n_hist[r];
+        s.active = 1; s.seek_delta = 100 * WHISPER_CHUNK_SIZE; s.seek = 0; s.seek_end = 100 * WHISPER_CHUNK_SIZE; s.n_prompt = 1; s.min_margin = INFINITY;
+        s.cur_pos = n_hist[r]; s.n_tokens = n_hist[r];
         for (int i = 0; i < n_hist[r]; ++i) {
             const int id = hist[(size_t)r * hist_stride + i]; toks[(size_t)r * MT + i].id = id;
             if (id > m->tok_beg) {
                 const int sd = 2 * (id - m->tok_beg);
-                if (s.has_ts && s.seek_delta > sd && s.result_len < i) { snprintf(errbuf, 512, "row %d: the token loop cannot produce this history (timestamp goes backwards at %d)", r, i); return -1; }
+                if (s.has_ts && s.seek_delta > sd && s.result_len < i) { snprintf(errbuf, 512, "row %d: the token loop cannot produce this history (timestamp goes backwards at %d)", r, i);
+                return -1; }
                 s.seek_delta = sd; s.result_len = i + 1; s.has_ts = 1;
             }
         }
@@ -1304,7 +1439,9 @@ __global__ void k_transpose_mel(const float* mel, int n_len, int n_mel, float* o
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)n_len * n_mel) return; int fr = (int)(i / n_mel), j = (int)(i % n_mel); out[(long)j * n_len + fr] = mel[i];
 }
 extern "C" int skw_log_mel(skw_ctx* c, const float* pcm_host, int n_samples, float* mel_out, size_t cap, int* n_len_o, int* n_len_org_o) {
-    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    char* errbuf = c->errbuf;
+    WS_READY(c);
+    HIPCHK(hipSetDevice(c->m->device));
     std::vector<int> n_len, n_len_org; const float* pp[1] = {pcm_host}; int32_t ns[1] = {n_samples};
     if (load_clips(c, pp, ns, 1, 0, n_len, n_len_org)) return -1;
     run_mel(c, 1);
@@ -1316,7 +1453,9 @@ extern "C" int skw_log_mel(skw_ctx* c, const float* pcm_host, int n_samples, flo
     *n_len_o = n_len[0]; *n_len_org_o = n_len_org[0]; return 0;
 }
 static int tap_prepare(skw_ctx* c, const float* pcm_host, int n_samples, int seek) {
-    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    char* errbuf = c->errbuf;
+    WS_READY(c);
+    HIPCHK(hipSetDevice(c->m->device));
     std::vector<int> n_len, n_len_org; const float* pp[1] = {pcm_host}; int32_t ns[1] = {n_samples};
     if (load_clips(c, pp, ns, 1, 0, n_len, n_len_org)) return -1;
     run_mel(c, 1);
@@ -1329,10 +1468,14 @@ extern "C" int skw_conv_stem(skw_ctx* c, const float* pcm_host, int n_samples, i
     HIPCHK(hipMemcpyAsync(x0, c->x, sizeof(float) * c->m->hp.n_audio_ctx * c->m->hp.n_audio_state, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0;
 }
 // cross V^T [(h*64 + c)][Tpad kperm] of batch slot 0 -> natural [key][d] f32
-__global__ void k_vt2f_copy(const half_t* src, float* dst, int nc, int dt, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[(long)n * Tpad + skw_kperm(key)]; }
+__global__ void k_vt2f_copy(const half_t* src, float* dst, int nc, int dt, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[(long)n * Tpad + skw_kperm(key)]; }
 // the same exports from the fragment-order images
-__global__ void k_kfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[skw_kfrag_off(0, H, Tpad, key, n & ~7) + (n & 7)]; }
-__global__ void k_vtfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); const int p = skw_kperm(key); dst[i] = (float)src[skw_vtfrag_off(0, H, Tpad, n, p & ~7) + (p & 7)]; }
+__global__ void k_kfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt); dst[i] = (float)src[skw_kfrag_off(0, H, Tpad, key, n & ~7) + (n & 7)]; }
+__global__ void k_vtfrag2f_copy(const half_t* src, float* dst, int nc, int dt, int H, int Tpad) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+if (i >= (long)nc * dt) return; int key = (int)(i / dt), n = (int)(i % dt);
+const int p = skw_kperm(key); dst[i] = (float)src[skw_vtfrag_off(0, H, Tpad, n, p & ~7) + (p & 7)]; }
 __global__ void k_h2f_copy(const half_t* src, float* dst, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = (float)src[i]; }
 extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int seek, float* enc_out, float* cross_k, float* cross_v) {
     char* errbuf = c->errbuf; if (tap_prepare(c, pcm_host, n_samples, seek)) return -1;
@@ -1354,7 +1497,9 @@ extern "C" int skw_encode(skw_ctx* c, const float* pcm_host, int n_samples, int 
     HIPCHK(hipStreamSynchronize(c->stream)); return 0;
 }
 extern "C" int skw_decode_logits(skw_ctx* c, const int32_t* tokens, int n_tokens, float* logits) {
-    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    char* errbuf = c->errbuf;
+    WS_READY(c);
+    HIPCHK(hipSetDevice(c->m->device));
     if (n_tokens < 1 || n_tokens > c->m->hp.n_text_ctx) { snprintf(errbuf, 512, "bad n_tokens"); return -1; }
     for (int t = 0; t < n_tokens; ++t) {
         hipLaunchKernelGGL(k_set_tokens, dim3(1), dim3(1), 0, c->stream, c->st, tokens[t], t);
@@ -1371,7 +1516,8 @@ __global__ void k_math_probe(int kind, const float* in, float* out, long n, cons
     else if (kind == 1) y = skw_logf(x);
     else if (kind == 2) y = (float)((half_t)x);
     else if (kind == 3) y = skw_round_f16(x);
-    else if (kind == 4) { if (x <= -10.0f) y = 0.0f; else if (x >= 10.0f) y = x; else { half_t h = (half_t)x; uint16_t b = __builtin_bit_cast(uint16_t, h); uint16_t o = gelu_tab[b]; y = (float)__builtin_bit_cast(half_t, o); } }
+    else if (kind == 4) { if (x <= -10.0f) y = 0.0f; else if (x >= 10.0f) y = x; else { half_t h = (half_t)x; uint16_t b = __builtin_bit_cast(uint16_t, h);
+    uint16_t o = gelu_tab[b]; y = (float)__builtin_bit_cast(half_t, o); } }
     else if (kind == 5) y = 1.0f / sqrtf(x + 1e-5f);
     else if (kind == 6) y = (float)(1.0 / (double)x);
     else y = (float)log10((double)x);
@@ -1393,9 +1539,11 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     const size_t cbytes = (size_t)M * N * 4 + (size_t)64 * c->Tpad * N;
     // SKW_PROBE_WCYCLE=n: the launches walk n copies of W (n x N x K x 2 bytes > the 256 MB Infinity Cache: every launch finds its weights in HBM, as a decode step does)
     const int wcycle = (M <= 64 && getenv("SKW_PROBE_WCYCLE")) ? std::max(1, atoi(getenv("SKW_PROBE_WCYCLE"))) : 1;
-    HIPCHK(hipMalloc((void**)&A, (size_t)M * K * 2)); HIPCHK(hipMalloc((void**)&W, (size_t)N * K * 2 * wcycle)); HIPCHK(hipMalloc(&C, cbytes)); HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)); HIPCHK(hipMalloc((void**)&res, (size_t)M * N * 4));
+    HIPCHK(hipMalloc((void**)&A, (size_t)M * K * 2)); HIPCHK(hipMalloc((void**)&W, (size_t)N * K * 2 * wcycle));
+    HIPCHK(hipMalloc(&C, cbytes)); HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)); HIPCHK(hipMalloc((void**)&res, (size_t)M * N * 4));
     { std::vector<uint16_t> h((size_t)std::max(M, N) * K); uint32_t x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16(((x >> 8) & 0xffff) / 65536.0f - 0.5f); }
-      HIPCHK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice)); for (int w = 0; w < wcycle; ++w) HIPCHK(hipMemcpy(W + (size_t)w * N * K, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice)); }
+      HIPCHK(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice));
+      for (int w = 0; w < wcycle; ++w) HIPCHK(hipMemcpy(W + (size_t)w * N * K, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice)); }
     HIPCHK(hipMemset(bias, 0, (size_t)std::max(M, N) * 4)); HIPCHK(hipMemset(res, 0, (size_t)M * N * 4));
     SkwGemmArgs a{}; a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = N; a.bias = bias; a.epi = epi; a.scale = 1.0f; a.probe = probe;
     a.gelu_tab = c->m->gelu_tab; a.pe = res; a.n_ctx = c->m->hp.n_audio_ctx; a.H = N / 64; a.Tpad = c->Tpad; if (epi == EPI_F32 && N < 8192) { a.res = res; a.ldres = N; }
@@ -1405,12 +1553,15 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     if (small && epi == EPI_DEC_QKV) { a.C2 = res; a.C3 = res; a.ldc2 = N; a.n_ctx = N / 3; a.ldc = N / 3; }
     if (small && (probe & 64) && !(M & 15)) { a.a_frag = 1; a.probe &= ~64; }      // probe bit 6 (decode shapes, timing only): the activations addressed as a fragment-order image
     half_t* Wfrag = nullptr;      // probe bit 5 (decode shapes): the weights as fragment-order images (one per W copy of the cycle), what the step's launches read
-    if (small && (probe & 32) && !(N & 15)) { HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2 * wcycle)); for (int w = 0; w < wcycle; ++w) skw_make_wfrag(W + (size_t)w * N * K, K, N, K, epi == EPI_GELU_F16_KPERM, Wfrag + (size_t)w * N * K, c->stream); a.Wf = Wfrag; a.probe &= ~32; }
+    if (small && (probe & 32) && !(N & 15)) { HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2 * wcycle));
+    for (int w = 0; w < wcycle; ++w) skw_make_wfrag(W + (size_t)w * N * K, K, N, K, epi == EPI_GELU_F16_KPERM, Wfrag + (size_t)w * N * K, c->stream);
+    a.Wf = Wfrag; a.probe &= ~32; }
     for (int i = 0; i < 3; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e0, c->stream));
     // (a launch that also touched the NEXT launch's copy of W — LDS-DMA into a scratch slab, so the bytes sit in the Infinity Cache when wanted — measured no gain:
     //  7.63 vs 7.66 us for the QKV shape.  The cold-weight cost is the transfer into the consuming XCD's L2, ~1 us per 3.5 MB whether it starts in HBM or in the Infinity Cache.)
-    for (int i = 0; i < iters; ++i) { a.W = W + (size_t)(i % wcycle) * N * K; if (Wfrag) a.Wf = Wfrag + (size_t)(i % wcycle) * N * K; if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
+    for (int i = 0; i < iters; ++i) { a.W = W + (size_t)(i % wcycle) * N * K;
+    if (Wfrag) a.Wf = Wfrag + (size_t)(i % wcycle) * N * K; if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_per_launch = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(A); hipFree(W); hipFree(Wfrag); hipFree(C); hipFree(bias); hipFree(res);
@@ -1424,7 +1575,8 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
     const skw_hparams& hp = c->m->hp; const int d = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, Tpad = c->Tpad;
     const size_t kn = (size_t)B * Tpad * d, vn = (size_t)B * H * 64 * Tpad;
     half_t *K = nullptr, *V = nullptr, *q = nullptr, *out = nullptr;
-    HIPCHK(hipMalloc((void**)&K, kn * 2 * layers)); HIPCHK(hipMalloc((void**)&V, vn * 2 * layers)); HIPCHK(hipMalloc((void**)&q, (size_t)B * d * 2)); HIPCHK(hipMalloc((void**)&out, (size_t)B * d * 4));
+    HIPCHK(hipMalloc((void**)&K, kn * 2 * layers)); HIPCHK(hipMalloc((void**)&V, vn * 2 * layers));
+    HIPCHK(hipMalloc((void**)&q, (size_t)B * d * 2)); HIPCHK(hipMalloc((void**)&out, (size_t)B * d * 4));
     { std::vector<uint16_t> h(std::max(kn, vn)); uint32_t x = 777; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16((((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.25f); }
       for (int l = 0; l < layers; ++l) { HIPCHK(hipMemcpy(K + kn * l, h.data(), kn * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(V + vn * l, h.data(), vn * 2, hipMemcpyHostToDevice)); }
       HIPCHK(hipMemcpy(q, h.data(), (size_t)B * d * 2, hipMemcpyHostToDevice)); }
@@ -1442,8 +1594,10 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
     } else {
         std::vector<hipEvent_t> ev(2 * (size_t)iters);
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-        // SKW_XATTN_PROBE_TOUCH_K / _V = megabytes of the launch's K / V^T image read (and discarded) by k_touch in front of it, untimed: what the launch gains from bytes waiting in the Infinity Cache
-        const size_t tk = getenv("SKW_XATTN_PROBE_TOUCH_K") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_K")) * 1000000 : 0, tv = getenv("SKW_XATTN_PROBE_TOUCH_V") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_V")) * 1000000 : 0;
+        // SKW_XATTN_PROBE_TOUCH_K / _V = megabytes of the launch's K / V^T image read (and discarded) by k_touch in front of it, untimed: what the launch gains from bytes waiting
+        //  in the Infinity Cache
+        const size_t tk = getenv("SKW_XATTN_PROBE_TOUCH_K") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_K")) * 1000000 : 0,
+            tv = getenv("SKW_XATTN_PROBE_TOUCH_V") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_V")) * 1000000 : 0;
         for (int i = 0; i < iters; ++i) {
             if (tk) skw_touch(K + kn * (i % layers), std::min(tk, kn * 2) & ~(size_t)15, 256, nullptr, c->stream);
             if (tv) skw_touch(V + vn * (i % layers), std::min(tv, vn * 2) & ~(size_t)15, 256, nullptr, c->stream);
@@ -1459,7 +1613,9 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
 }
 
 // ------------------------------------------------------------------ resampler front end (R1-R3), model-free device context
-struct skw_dsp { int device = 0; hipStream_t stream = nullptr; char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr; int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
+struct skw_dsp { int device = 0; hipStream_t stream = nullptr;
+char errbuf[512] = {0}; float *d_in = nullptr, *d_out = nullptr, *d_frac = nullptr, *d_coef = nullptr;
+int* d_pos = nullptr; int* d_n = nullptr; double* d_li = nullptr;
                  size_t cap_in = 0, cap_out = 0; int coef_L = 0, coef_M = 0;
                  double* d_start = nullptr; int *d_count = nullptr, *d_offset = nullptr, *d_flag = nullptr; size_t cap_chunks = 0; int last_flags[2] = {0, 0}; bool host_walk_last = false; };
 extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
@@ -1467,15 +1623,21 @@ extern "C" skw_dsp* skw_dsp_create(int device, char* err, size_t errlen) {
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: the resampler kernels require an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
     if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", device, ndev); return nullptr; }
     skw_dsp* d = new skw_dsp(); d->device = device;
-    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&d->d_n, sizeof(int)) != hipSuccess || hipMalloc((void**)&d->d_li, sizeof(double)) != hipSuccess) { set_err(err, errlen, "device allocation failed"); delete d; return nullptr; }
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&d->d_n, sizeof(int)) != hipSuccess || hipMalloc((void**)&d->d_li,
+        sizeof(double)) != hipSuccess) { set_err(err, errlen, "device allocation failed");
+    delete d; return nullptr; }
     return d;
 }
-extern "C" void skw_dsp_free(skw_dsp* d) { if (!d) return; hipSetDevice(d->device); hipStreamSynchronize(d->stream); hipFree(d->d_in); hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); hipFree(d->d_coef); hipFree(d->d_n); hipFree(d->d_li); hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset); hipFree(d->d_flag); hipStreamDestroy(d->stream); delete d; }
+extern "C" void skw_dsp_free(skw_dsp* d) { if (!d) return; hipSetDevice(d->device); hipStreamSynchronize(d->stream); hipFree(d->d_in); hipFree(d->d_out);
+hipFree(d->d_frac); hipFree(d->d_pos); hipFree(d->d_coef); hipFree(d->d_n); hipFree(d->d_li); hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset);
+hipFree(d->d_flag); hipStreamDestroy(d->stream); delete d; }
 extern "C" const char* skw_dsp_last_error(const skw_dsp* d) { return d->errbuf; }
 static int dsp_reserve(skw_dsp* d, size_t n_in, size_t n_out) {
     char* errbuf = d->errbuf;
     if (n_in > d->cap_in) { hipFree(d->d_in); d->cap_in = n_in * 2; HIPCHK(hipMalloc((void**)&d->d_in, d->cap_in * sizeof(float))); }
-    if (n_out > d->cap_out) { hipFree(d->d_out); hipFree(d->d_frac); hipFree(d->d_pos); d->cap_out = n_out * 2; HIPCHK(hipMalloc((void**)&d->d_out, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_frac, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_pos, d->cap_out * sizeof(int))); }
+    if (n_out > d->cap_out) { hipFree(d->d_out); hipFree(d->d_frac);
+    hipFree(d->d_pos); d->cap_out = n_out * 2; HIPCHK(hipMalloc((void**)&d->d_out, d->cap_out * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d->d_frac, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_pos, d->cap_out * sizeof(int))); }
     return 0;
 }
 extern "C" void skw_resampler_init(skw_resampler_state* st, double ratio, int chunk_frames, int channels) {
@@ -1485,14 +1647,16 @@ extern "C" void skw_resampler_init(skw_resampler_state* st, double ratio, int ch
 extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const float* in, int n_chunks, float* out, int out_cap_frames, int* out_frames) {
     char* errbuf = d->errbuf; HIPCHK(hipSetDevice(d->device));
     const int ch = st->channels, chunk = st->chunk_frames; *out_frames = 0;
-    if (ch < 1 || ch > 2 || chunk < 1 || n_chunks < 1 || (chunk < 16 && n_chunks != 1)) { snprintf(errbuf, 512, "resampler: unsupported geometry (channels %d, chunk_frames %d)", ch, chunk); return -1; }
+    if (ch < 1 || ch > 2 || chunk < 1 || n_chunks < 1 || (chunk < 16 && n_chunks != 1)) { snprintf(errbuf, 512, "resampler: unsupported geometry (channels %d, chunk_frames %d)", ch, chunk);
+    return -1; }
     const size_t n_in = (size_t)(16 + (size_t)n_chunks * chunk) * ch;
     if (dsp_reserve(d, n_in, (size_t)out_cap_frames * ch)) return -1;
     HIPCHK(hipMemcpyAsync(d->d_in, st->hist, sizeof(float) * 16 * ch, hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipMemcpyAsync(d->d_in + 16 * ch, in, sizeof(float) * (size_t)n_chunks * chunk * ch, hipMemcpyHostToDevice, d->stream));
     if ((size_t)n_chunks + 1 > d->cap_chunks) {
         hipFree(d->d_start); hipFree(d->d_count); hipFree(d->d_offset); d->cap_chunks = ((size_t)n_chunks + 1) * 2;
-        HIPCHK(hipMalloc((void**)&d->d_start, d->cap_chunks * sizeof(double))); HIPCHK(hipMalloc((void**)&d->d_count, d->cap_chunks * sizeof(int))); HIPCHK(hipMalloc((void**)&d->d_offset, d->cap_chunks * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&d->d_start, d->cap_chunks * sizeof(double))); HIPCHK(hipMalloc((void**)&d->d_count, d->cap_chunks * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&d->d_offset, d->cap_chunks * sizeof(int)));
         if (!d->d_flag) HIPCHK(hipMalloc((void**)&d->d_flag, 2 * sizeof(int)));
     }
     // The chunk starts are one sequential f64 recurrence over the whole call (rubato's idx += t_ratio).  When every addition of it is exact (48 / 32 / 96 / 8 kHz
@@ -1508,7 +1672,8 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
         const double end_idx = (double)(chunk - 9) - ceil(t_ratio); double s = st->last_index; int off = 0;
         for (int cix = 0; cix < n_chunks; ++cix) { double x = s; int n = 0; while (x < end_idx) { x += t_ratio; n++; } hs[cix] = s; hc[cix] = n; ho[cix] = off; off += n; s = x - (double)chunk; }
         hs[n_chunks] = s; ho[n_chunks] = off;
-        HIPCHK(hipMemcpyAsync(d->d_start, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipMemcpyAsync(d->d_count, hc.data(), sizeof(int) * hc.size(), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->d_start, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(d->d_count, hc.data(), sizeof(int) * hc.size(), hipMemcpyHostToDevice, d->stream));
         HIPCHK(hipMemcpyAsync(d->d_offset, ho.data(), sizeof(int) * ho.size(), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));      // (the vectors are locals)
     }
     d->host_walk_last = host_walk;

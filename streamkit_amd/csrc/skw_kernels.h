@@ -79,8 +79,10 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
 // f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
 bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);
-bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);  // A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b), statistics and normalisation inside the kernel from the rows it holds in registers; W in NATURAL k order
-bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);   // the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
+// A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b), statistics and normalisation inside the kernel from the rows it holds in registers; W in NATURAL k order
+bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);
+// the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
+bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // cross attention of the prompt pass (f16_mfma): the encoder attention kernel with a sequence's prompt tokens as the queries — one read of the sequence's cross K / V^T per 128 of them.
 // q: [rows][d] f16 plain (scaled); sequence i: rows row0[i] .. + nq[i], cross K / V^T of window slot slot[i]; out: [rows][kperm(d)] f16
@@ -96,7 +98,9 @@ void skw_layernorm(const float* x, int rows, int d, const float* w, const float*
 
 // Encoder self-attention, exact three-pass softmax. Qh/Kh: [(b*H+h)*Tpad + i][64 kperm], Vt: [(b*H+h)*64 + c][Tpad kperm],
 // out: f16 [b*n_ctx + i][kperm(h*64 + c)] with row stride ld_out
-void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg = nullptr, float* dbg2 = nullptr, int f32_out = 0);   // f32_out: `out` is a float [B*n_ctx][ld_out] buffer, natural order, unrounded
+// f32_out: `out` is a float [B*n_ctx][ld_out] buffer, natural order, unrounded
+void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s,
+    float* dbg = nullptr, float* dbg2 = nullptr, int f32_out = 0);
 
 // log-mel front end
 struct SkwMelTables { const float* hann; const float* sin_t; const float* cos_t; const float* filters; int n_mel; int n_fft_bins;
@@ -115,7 +119,9 @@ void skw_dec_embed(const half_t* te, const float* pe, const int* tok, const int*
 struct SkwQ8Out { int8_t* q; float* dT; float* sT; int M; };   // where a producer leaves its rows as q8 blocks (q == nullptr: it does not)
 struct SkwQ8Args { const int8_t* qa; const float* dyT; const float* syT;        // activations: int8 [M][K], scales [K/32][M]
                    const int8_t* qw; const float* dwT; const float* mwT; int n_pad; int form;
-                   int segmented; };   // segmented: the decoder's form — four contiguous runs of blocks, partial sums added in ascending order (D3'); needs K % 128 == 0   // weights: int8 [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
+                   // segmented: the decoder's form — four contiguous runs of blocks, partial sums added in ascending order (D3'); needs K % 128 == 0   // weights: int8
+                   //  [N][K], scales [K/32][n_pad]; form: skw_ggml_dot_form
+                   int segmented; };
 void skw_q8_quantize(const float* x, long ldx, int M, int K, int8_t* q, float* dT, float* sT, hipStream_t s);
 bool skw_gemm_q8(const SkwGemmArgs& a, const SkwQ8Args& qa, hipStream_t s);
 void skw_dec_embed_f32(const float* te32, const float* pe, const int* tok, const int* pos, int B, int d, float* x, hipStream_t s);
@@ -123,14 +129,20 @@ void skw_dec_embed_ln(const half_t* te, const float* pe, const int* tok, const i
 // self attention for one new token per sequence. q: f16 plain [b][d] (already scaled+rounded), kc/vc: f16 plain [b][n_text_ctx][d];
 // n_kv[b] = pos[b]+1. out f16 [b][kperm(d)]
 // active: &state[0].active of the rows (stride sizeof(SkwSeqState)), rows whose flag is 0 are skipped; may be null
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0},
-                       const int* seq = nullptr, int fastv = 0, int ofrag = 0);      // ofrag: output as a fragment-order A image (skw_afrag_off); fastv: the tolerance precision's P.V (16-byte V pieces, per-lane key shares)   // seq (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active,
+    hipStream_t s, int f32_out = 0, SkwQ8Out q8 = SkwQ8Out{nullptr, nullptr, nullptr, 0},
+                       // ofrag: output as a fragment-order A image (skw_afrag_off); fastv: the tolerance precision's P.V (16-byte V pieces, per-lane key shares)   // seq
+                       //  (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
+                       const int* seq = nullptr, int fastv = 0, int ofrag = 0);
 // cross attention: ck/cv f16 plain [b][n_ctx][d]
 void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int ofrag = 0);   // ofrag (one-pass kernel only): the output rows as the fragment-order A image of the projection that follows; events: stamped at the kernel's own begin / end (the engine's per-kernel profile)
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
+    int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
+                           // ofrag (one-pass kernel only): the output rows as the fragment-order A image of the projection that follows; events: stamped at the kernel's
+                           //  own begin / end (the engine's per-kernel profile)
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int ofrag = 0);
 // the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
 void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s);     // read and discard: warms the Infinity Cache
 bool skw_dec_cross_attn_vt_q_ok(int H, int d);
@@ -162,7 +174,8 @@ struct SkwTokenOut { int32_t id, tid; float p, plog, pt, ptsum, margin; };
 // one sampling decision as the trace / teacher-forced mode records it (skw_full_batch_traced): what this precision would have chosen, what it was made to
 // feed instead (forced_id == chosen_id in a free run), the two largest admissible logits with their owners, the (filtered) logit of the fed token and the
 // log-sum-exp of the admissible logits.  Layout == skw_trace_step of include/skw_engine.h.
-struct SkwTraceStep { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; float temperature; int32_t pad; };      // temperature > 0: chosen_id is a draw, and the logits are the row's divided by it
+// temperature > 0: chosen_id is a draw, and the logits are the row's divided by it
+struct SkwTraceStep { int32_t chosen_id, forced_id, top1_id, top2_id; float top1, top2, forced_logit, lse; float temperature; int32_t pad; };
 struct SkwLogitParams {
     int n_vocab, tok_eot, tok_sot, tok_translate, tok_transcribe, tok_solm, tok_prev, tok_nosp, tok_not, tok_beg;
     int n_lang; int tok_space, tok_sp_dash, tok_sp_quote;
@@ -178,7 +191,8 @@ struct SkwLogitParams {
 size_t skw_static_mask_bytes(int n_vocab);
 __host__ __device__ inline size_t skw_probs_row_floats(int n_vocab) { return (size_t)3 * ((n_vocab + 1) & ~1); }
 void skw_static_mask_pack(const uint8_t* mask, int n_vocab, uint8_t* out);
-// probs: [B][skw_probs_row_floats(n_vocab)] workspace (written only by rows with temperature > 0): n_vocab f32 probabilities, then n_vocab f64 normalised ones; rng: [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
+// probs: [B][skw_probs_row_floats(n_vocab)] workspace (written only by rows with temperature > 0): n_vocab f32 probabilities, then n_vocab f64 normalised ones; rng:
+//  [clips][SKW_RNG_WORDS], row b draws from rng[clip_idx[b]];
 // n_active: [B] live flags (1 while the row decodes; the kernel stores 0 when it completes or fails) — host-mapped memory in the engine
 void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st, SkwTokenOut* toks /*[B][max_tokens]*/, int max_tok, int B, int* n_active,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf /* [B][SKW_PROMPT_CAP]: row b feeds prompt_buf[b][0 .. n_prompt) before it samples */, hipStream_t s,
@@ -189,5 +203,6 @@ void skw_rng_seed(uint32_t* rng, int n_clips, uint32_t seed, hipStream_t s);   /
 // ---------------- resampler (R1) ----------------
 // start / count / offset: [n_chunks + 1] scratch for the per-chunk proposal; flag: 1 int (set when the proposal had to be redone sequentially)
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
-                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal = false);   // host_proposal: start / count / offset already hold the first proposal
+                                // host_proposal: start / count / offset already hold the first proposal
+                                float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal = false);
 void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out, long out_first, long n_out, hipStream_t s);

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_seg(SkwGemmArgs a) {
     // the values, and so every chain, are unchanged.  (Not for the GELU product: its image holds the rows in the f16 kernels' output order.)
     const bool wfrag = a.Wf != nullptr && EPI != EPI_GELU_F16_KPERM && !(a.N & 15);
     const unsigned wstep = wfrag ? 1024u : 64u;
-    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2),
+        0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, abytes, 0x00020000);
     const unsigned oob = 0x7fffff00u;
     const int nkq = (a.K >> 5) >> 2, kb_lo = wave * nkq;                 // host guarantees K % 128 == 0
@@ -506,7 +507,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder(const half_t* Qh, const
             for (int r = 0; r < 4; ++r) {
                 int qi = q0 + qt * 16 + g * 4 + r; int c = ct * 16 + r16;
                 if (qi < n_ctx) att_store(out, ((long)b * n_ctx + qi) * ld_out, h * 64 + c, oacc[qt][ct][r], f32_out);
-                if (dbg && qi < n_ctx && b == 0) { dbg[(long)qi * (H * 64) + h * 64 + c] = oacc[qt][ct][r]; if (ct == 0 && r == 0 && g == 0 && q0 + qt * 16 + r16 < n_ctx) { dbg[(long)n_ctx * H * 64 + (long)h * n_ctx + q0 + qt * 16 + r16] = rmax[qt]; dbg[(long)n_ctx * H * 64 + (long)(H + h) * n_ctx + q0 + qt * 16 + r16] = rinv[qt]; } }
+                if (dbg && qi < n_ctx && b == 0) { dbg[(long)qi * (H * 64) + h * 64 + c] = oacc[qt][ct][r];
+                if (ct == 0 && r == 0 && g == 0 && q0 + qt * 16 + r16 < n_ctx) { dbg[(long)n_ctx * H * 64 + (long)h * n_ctx + q0 + qt * 16 + r16] = rmax[qt];
+                dbg[(long)n_ctx * H * 64 + (long)(H + h) * n_ctx + q0 + qt * 16 + r16] = rinv[qt]; } }
             }
 }
 // ------------------------------------------------------------------ encoder self-attention, single-pass form (K5)
@@ -696,7 +699,8 @@ void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half
     if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg && !getenv("SKW_ATTN_V1")) {     // Whisper's 1500-frame context
         const int qtiles = (n_ctx + 63) / 64;
         constexpr int RT3 = 72;
-        hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qtiles, f32_out);
+        hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad,
+            1.0f / sqrtf(64.0f), qtiles, f32_out);
         return;
     }
     dim3 grid((n_ctx + 127) / 128, H, B);
@@ -1060,13 +1064,16 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
 template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
-                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, SkwXQ xq, const int* seq) {
-    // XCD-aware placement (bit 16 of f32_out; SKW_XATTN_XCD=1, measured: no effect, 54.5 - 55.2 us against 54.3): workgroups are dealt to the 8 XCDs round-robin by linear id, so the (H / HPW) workgroups of one sequence — which together
+                                                           const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride,
+                                                               int f32_out, SkwXQ xq, const int* seq) {
+    // XCD-aware placement (bit 16 of f32_out; SKW_XATTN_XCD=1, measured: no effect, 54.5 - 55.2 us against 54.3): workgroups are dealt to the 8 XCDs round-robin by linear id, so
+    //  the (H / HPW) workgroups of one sequence — which together
     // read every 1536-byte K row of that sequence, a 384-byte piece each — land on different XCDs; remapped, the pieces of a row are requested through one XCD's L2
     int bx = blockIdx.x, by = blockIdx.y;
     if ((f32_out >> 16) & 1) { const int G = gridDim.x, Lid = by * G + bx, j = Lid & 7, k = Lid >> 3; by = j + 8 * (k / G); bx = k % G; }
     if (active && !active[by * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
-    const int probe = (f32_out >> 8) & 0xff; f32_out &= 1;      // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
+    // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
+    const int probe = (f32_out >> 8) & 0xff; f32_out &= 1;
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
     __shared__ float smax[HPW][WPH];
@@ -1076,7 +1083,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     __shared__ __attribute__((aligned(16))) half_t qown[FQ ? HPW * WPH : 1][64];
     __shared__ double lnred[HPW * WPH];
     __shared__ __attribute__((aligned(16))) half_t p16[PV16 ? HPW : 1][PV16 ? MAXT * 64 : 8];      // PV16: the probabilities as f16 in kperm order, the f16 MFMA's second operand
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;   // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
+    // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;
     const int hraw = bx * HPW + hs, b = by;
     const bool valid = hraw < H;               // no early return: the pair meets at workgroup barriers
     const int h = valid ? hraw : H - 1;
@@ -1111,7 +1119,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
           for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; const bool in = i < d; xv[c] = in ? xr[i] : 0.0f; gw[c] = in ? xq.ln_w[i] : 0.0f; gb[c] = in ? xq.ln_b[i] : 0.0f; } }
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's weight rows (channel = 64 h + i*8 + lrow, 16-byte piece lseg of the step's 128 bytes); a step's second block may lie past the segment: it is fetched from inside the row and not used
+        // this wave's weight rows (channel = 64 h + i*8 + lrow, 16-byte piece lseg of the step's 128 bytes); a step's second block may lie past the segment: it is fetched from
+        //  inside the row and not used
         const char* Wseg = (const char*)(xq.W + (long)(h * 64) * xq.ldw + half * nkq * 32);      // wave-uniform base + one 32-bit lane offset: eight loads share the address registers
         const unsigned wlo = (unsigned)((lrow * (int)xq.ldw + (lseg & 3) * 8) * 2);
         auto wfill = [&](u32x4 (&dst)[8], int t) {
@@ -1239,7 +1248,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
     for (int j = 0; j < RD; ++j)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) { ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (j < nkb) ? vo + ct * 16 * Tpad * 2 + j * 64 : 0x7fffff00u, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+        for (int ct = 0; ct < CT; ++ct) { ring[j][ct].v = __builtin_amdgcn_raw_buffer_load_b128(rv, (j < nkb) ? vo + ct * 16 * Tpad * 2 + j * 64 : 0x7fffff00u, 0, 0);
+        __builtin_amdgcn_sched_barrier(0); }
     lmax = skw_wave_max_f32(lmax);
     if (lane == 0) smax[hs][half] = lmax;
     __syncthreads();
@@ -1326,9 +1336,11 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 //            p = exp2((s - m) log2 e) rounded to f16 unnormalised (<= 1: no subnormal loss that 1 / sum would add), per-lane partial sums
 //   P.V      O^T[c][*] += V^T[c][keys] . p, four 16-channel tiles, one MFMA each
 // and the four partial (m, l, O) meet in LDS at the end (one barrier).  RD blocks (8 KB each) are in flight per wave, 12 waves per CU.
-template <int HPW, int RD, bool FRAG = false, int AUX = 0>      // AUX = 2: the K / V^T loads carry the non-temporal policy (experiment: keep the once-read stream out of the Infinity Cache so that the step's weights stay in it)
+// AUX = 2: the K / V^T loads carry the non-temporal policy (experiment: keep the once-read stream out of the Infinity Cache so that the step's weights stay in it)
+template <int HPW, int RD, bool FRAG = false, int AUX = 0>
 __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cross_attn16(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk, const half_t* vtbase,
-                                                                                         int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride, int f32_out, const int* seq, int ofrag_k) {
+                                                                                         int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active,
+                                                                                             int active_stride, int f32_out, const int* seq, int ofrag_k) {
     typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
     const int b = blockIdx.y;
     if (active && !active[b * active_stride]) return;
@@ -1355,7 +1367,8 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
     // one block's loads: K rows of the two score tiles (per-lane row offset — clamped to the last real key —, the d half as the instruction's immediate), then the four V^T tiles
     // (per-lane offset + block, the channel tile in the scalar offset)
     auto issue = [&](u32x4 (&slot)[8], int kb) {
-        if constexpr (FRAG) {      // fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB; pad keys of the last tile hold whatever memory held (masked below)
+        // fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB; pad keys of the last tile hold whatever memory held (masked below)
+        if constexpr (FRAG) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, AUX);
 #pragma unroll
@@ -1412,7 +1425,8 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const half_t ph = f2h(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -mc))); pb[4 * t + r] = ph; l = l + h2f(ph); }      // masked keys: exp2(-inf) = 0; the sum is of the rounded values the MFMA multiplies
+                    // masked keys: exp2(-inf) = 0; the sum is of the rounded values the MFMA multiplies
+                    for (int r = 0; r < 4; ++r) { const half_t ph = f2h(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -mc))); pb[4 * t + r] = ph; l = l + h2f(ph); }
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ring[j][4 + ct]), pb, o[ct], 0, 0, 0);
                 if (n + RD < cnt) issue(ring[j], kb + RD * step);              // the slot's next block (RD - 1 blocks stay in flight while one is consumed)
@@ -1435,11 +1449,14 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
         for (int i = 1; i < 4; ++i) M = fmaxf(M, cmb[hs][i][0]);
         float num = 0.0f, den = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float a = __builtin_amdgcn_exp2f((cmb[hs][i][0] - M) * LOG2E); num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }   // an empty quarter: m = -inf, a = 0
+        // an empty quarter: m = -inf, a = 0
+        for (int i = 0; i < 4; ++i) { const float a = __builtin_amdgcn_exp2f((cmb[hs][i][0] - M) * LOG2E);
+        num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }
         att_store_m(out, b, ldo, h * 64 + lane, num / den, f32_out, ofrag_k);
     }
 }
-void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s, int f32_out, int pv16, const int* seq,
+void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
+    int f32_out, int pv16, const int* seq,
                            hipEvent_t ev_start, hipEvent_t ev_stop, int ofrag) {
     static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
     const int as = (int)(sizeof(SkwSeqState) / 4);
@@ -1457,36 +1474,52 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         const int fo = (f32_out & 1) | (x16il ? 2 : 0);
         const dim3 grid((H + 2) / 3, B), blk(768);
         const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
-        static const int x16nt = getenv("SKW_XATTN16_NT") ? atoi(getenv("SKW_XATTN16_NT")) : 1;      // the once-read K / V^T stream with the non-temporal policy: 47.8 -> 46.0-46.3 us per launch in step (same-box A/B, profiles/r03h/r03h_xattn16_nt_ab.txt; on the two-phase kernel over the row layouts the same policy had cost 2 us)
+        // the once-read K / V^T stream with the non-temporal policy: 47.8 -> 46.0-46.3 us per launch in step (same-box A/B, profiles/r03h/r03h_xattn16_nt_ab.txt; on the
+        //  two-phase kernel over the row layouts the same policy had cost 2 us)
+        static const int x16nt = getenv("SKW_XATTN16_NT") ? atoi(getenv("SKW_XATTN16_NT")) : 1;
         static const int x16rd = getenv("SKW_XATTN16_RD") ? atoi(getenv("SKW_XATTN16_RD")) : 3;
-        static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;      // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
+        // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
+        static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;
         if (pv16 == 2 && x16hpw == 1) {
             const dim3 grid1(H, B), blk1(256);
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
+                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
             else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2 && x16nt && x16rd != 3) {      // (blocks in flight per wave: 2 / 4, measurement)
-            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
+                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H,
+                out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2 && x16nt) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
+                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else if (pv16 == 2) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad,
+                H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         } else {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
+            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad,
+                H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
             else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
         }
         return;
     }
     if (pv16 == 2) pv16 = 1;       // (probe launches with parts switched off exist for the two-phase kernel only)
-    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    // (profiling: hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end — the duration rocprofv3 reports — instead of an event pair around the launch, which adds the dispatch gap)
-    else if (wph == 4 && pv16 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
+        (long)d, active, as, f32_out, none, seq);
+    // (profiling: hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end — the duration rocprofv3 reports —
+    //  instead of an event pair around the launch, which adds the dispatch gap)
+    else if (wph == 4 && pv16 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0,
+        q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else if (wph == 4 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0, q, (long)d, ck,
+        (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d,
+        (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx,
+        Tpad, H, out, (long)d, active, as, f32_out, none, seq);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
+        (long)d, active, as, f32_out, none, seq);
 }
 // ------------------------------------------------------------------ cache warming: read `bytes` of a buffer and keep nothing.  The decode step's small launches leave HBM idle
 // (16.5 MB of weights per layer in ~58 us); a reader that runs beside them moves the next cross attention's K rows into the Infinity Cache (memory side, 256 MiB), from
@@ -1524,11 +1557,13 @@ bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_
     if (!skw_dec_cross_attn_vt_q_ok(H, d)) return false;
     const int as = (int)(sizeof(SkwSeqState) / 4);
     const SkwXQ xq{x, ln_w, ln_b, Wq, ldw, bq, scale, d};
-    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, 0, xq, (const int*)nullptr);
+    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H,
+        out, (long)d, active, as, 0, xq, (const int*)nullptr);
     return true;
 }
 
-void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active, hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv, int ofrag) {
+void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active,
+    hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv, int ofrag) {
     static const int fastv_env = getenv("SKW_DEC_ATTN_FASTV") ? atoi(getenv("SKW_DEC_ATTN_FASTV")) : 1;
     if (fastv && fastv_env && !q8.q && !f32_out) { hipLaunchKernelGGL((k_dec_attn<7, true>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
                        pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq, ofrag ? d : 0); return; }
@@ -1604,7 +1639,8 @@ __device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg,
     if (!trace || i >= max_tok) return;
     int fid = forced ? forced[row * max_tok + i] : -1;
     if (fid < 0 || fid >= p.n_vocab) fid = tk.id;
-    SkwTraceStep ts; ts.chosen_id = tk.id; ts.forced_id = fid; ts.top1_id = i1; ts.top2_id = (t2 > -INFINITY) ? i2 : -1; ts.top1 = t1; ts.top2 = t2; ts.forced_logit = lg[fid]; ts.lse = lse; ts.temperature = temperature; ts.pad = 0;
+    SkwTraceStep ts; ts.chosen_id = tk.id; ts.forced_id = fid; ts.top1_id = i1; ts.top2_id = (t2 > -INFINITY) ? i2 : -1; ts.top1 = t1; ts.top2 = t2;
+    ts.forced_logit = lg[fid]; ts.lse = lse; ts.temperature = temperature; ts.pad = 0;
     trace[row * max_tok + i] = ts;
     if (fid != tk.id) { tk.id = fid; tk.plog = lg[fid] - lse; tk.p = skw_expf(tk.plog); }
 }
@@ -1616,7 +1652,8 @@ __device__ __forceinline__ void smp_trace_step(SkwTokenOut& tk, const float* lg,
 // S + p == S under round-to-nearest whenever 0 <= p < ulp(S) / 2: a 64-element block whose largest element is below that bound cannot move the running sum,
 // whatever the order inside it, and since the sum never decreases it stays immovable — such blocks are skipped WITHOUT changing a bit of the sequential result.
 // (Peaked distributions — most real steps — leave a few dozen elements in the chain; a flat one keeps all 51 865.)
-__device__ __forceinline__ double half_ulp_f64(double s) { const int e = (int)((__double_as_longlong(s) >> 52) & 0x7ff); return e == 0 ? 0.0 : __longlong_as_double((long long)max(e - 53, 1) << 52); }   // 2^(exponent(s) - 53); 0 for s == 0 / subnormal: nothing is skipped then
+// 2^(exponent(s) - 53); 0 for s == 0 / subnormal: nothing is skipped then
+__device__ __forceinline__ double half_ulp_f64(double s) { const int e = (int)((__double_as_longlong(s) >> 52) & 0x7ff); return e == 0 ? 0.0 : __longlong_as_double((long long)max(e - 53, 1) << 52); }
 __device__ int block_discrete_draw(const float* probs, double* q, int n, uint32_t* mt, float* lds, double* s_sum, int* s_hit) {
     const int tid = threadIdx.x, nt = blockDim.x;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -1806,7 +1843,9 @@ struct SmpMain { ArgBest best; float best_logit; ArgBest bts; double sum_ts; flo
 #define SMP_PASS_BEGIN { int tq = tid; asm volatile("" : "+v"(tq));
 #define SMP_PASS_END }
 #define SMP_IDX(c) (tq + SMP_NT * (c))
-template <bool TRACE, bool DRAW>      // TRACE: the trace / teacher-forced form (one more pass for the runner-up's index); DRAW: rows at a temperature > 0 may be present (the workgroup-wide draw and its LDS staging are compiled in); the greedy step's graph holds <false, false>
+// TRACE: the trace / teacher-forced form (one more pass for the runner-up's index); DRAW: rows at a temperature > 0 may be present (the workgroup-wide draw and its LDS
+//  staging are compiled in); the greedy step's graph holds <false, false>
+template <bool TRACE, bool DRAW>
 __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const uint8_t* static_mask, SkwLogitParams p, SkwSeqState* st_all, SkwTokenOut* toks_all,
                                                        int max_tok, int* n_active, float* probs_all, uint32_t* rng_all, const int* clip_idx, const int* prompt_buf,
                                                        const int* forced, SkwTraceStep* trace) {
@@ -1916,7 +1955,8 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     float m_ts = -INFINITY, max_text = -INFINITY;
     SMP_PASS_BEGIN
 #pragma unroll
-    for (int c = 0; c < SMP_PT; ++c) { const float lp = v[c] - lse; if (c < tx) max_text = fmaxf(max_text, lp); else if (SMP_IDX(c) >= p.tok_beg) m_ts = fmaxf(m_ts, lp); else max_text = fmaxf(max_text, lp); }
+    for (int c = 0; c < SMP_PT; ++c) { const float lp = v[c] - lse;
+    if (c < tx) max_text = fmaxf(max_text, lp); else if (SMP_IDX(c) >= p.tok_beg) m_ts = fmaxf(m_ts, lp); else max_text = fmaxf(max_text, lp); }
     SMP_PASS_END
     bmax2(m_ts, max_text, &m_ts, &max_text);
     double acc_ts = 0.0;
@@ -1948,7 +1988,8 @@ __global__ __launch_bounds__(SMP_NT) void k_dec_sample(float* logits_all, const 
     float t1 = -INFINITY, t2 = -INFINITY; int i1 = 0;
     SMP_PASS_BEGIN
 #pragma unroll
-    for (int c = 0; c < SMP_PT; ++c) { const float x = v[c]; const bool gt = x > t1; t2 = gt ? t1 : fmaxf(t2, x); i1 = gt ? c : i1; t1 = gt ? x : t1; }     // (selects, not branches; i1 counts stripes here)
+    // (selects, not branches; i1 counts stripes here)
+    for (int c = 0; c < SMP_PT; ++c) { const float x = v[c]; const bool gt = x > t1; t2 = gt ? t1 : fmaxf(t2, x); i1 = gt ? c : i1; t1 = gt ? x : t1; }
     i1 = SMP_IDX(i1);
     SMP_PASS_END
     for (int o = 32; o > 0; o >>= 1) {
@@ -2062,7 +2103,8 @@ void skw_dec_sample(float* logits, const uint8_t* static_mask, SkwLogitParams p,
                     float* probs, uint32_t* rng, const int* clip_idx, const int* prompt_buf, hipStream_t s, const int* forced, SkwTraceStep* trace) {
     if (!g_force_stream_sampler && p.n_vocab <= SMP_PT * SMP_NT && std::min(p.tok_eot, p.tok_beg) >= SMP_TX * SMP_NT) {
         if (trace) hipLaunchKernelGGL((k_dec_sample<true, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
-        else if (p.any_sampled) hipLaunchKernelGGL((k_dec_sample<false, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
+        else if (p.any_sampled) hipLaunchKernelGGL((k_dec_sample<false, true>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs,
+            rng, clip_idx, prompt_buf, nullptr, nullptr);
         else hipLaunchKernelGGL((k_dec_sample<false, false>), dim3(B), dim3(SMP_NT), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, nullptr, nullptr);
     } else hipLaunchKernelGGL(k_dec_sample_stream, dim3(B), dim3(1024), 0, s, logits, static_mask, p, st, toks, max_tok, n_active, probs, rng, clip_idx, prompt_buf, forced, trace);
 }
@@ -2237,14 +2279,16 @@ __global__ __launch_bounds__(256) void k_resample_polyphase(const float* in, lon
     }
 }
 // outputs [out_first, out_first + n_out) of the stream into out[0 ..]; in = frames [in_base, in_base + n_in), n_total = frames of the stream known so far (beyond: zeros)
-void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out, long out_first, long n_out, hipStream_t s) {
+void skw_resample_polyphase_launch(const float* in, long in_base, long n_in, long n_total, int channels, const float* coef, int L, int M, int T, float* out,
+    long out_first, long n_out, hipStream_t s) {
     if (n_out <= 0) return;
     const int span_max = (int)(((long)(L - 1) + (long)(PP_TILE - 1) * M) / L) + T;
     const size_t x_bytes = (size_t)span_max * channels * 4, h_bytes = (size_t)L * (T | 1) * 4;
     const int coef_in_lds = (x_bytes + h_bytes <= 96 * 1024) ? 1 : 0;
     if (x_bytes + (coef_in_lds ? h_bytes : 0) > 64 * 1024) {      // more dynamic LDS than the default limit: raise it on this device (per device: several GPUs may run in one process)
         static std::atomic<bool> raised[64]; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!raised[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_resample_polyphase, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised[dev].store(true, std::memory_order_release); }
+        if (!raised[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_resample_polyphase, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised[dev].store(true, std::memory_order_release); }
     }
     hipLaunchKernelGGL(k_resample_polyphase, dim3((unsigned)((n_out + PP_TILE - 1) / PP_TILE)), dim3(256), x_bytes + (coef_in_lds ? h_bytes : 0), s,
                        in, in_base, n_in, n_total, channels, coef, L, M, T, coef_in_lds, out, out_first, n_out);

@@ -133,7 +133,8 @@ __device__ __forceinline__ long epi_chunk_offset(const SkwGemmArgs& a, int y, in
         if (EPI == EPI_HEADS_F16) return ((long)(b * a.H + (px >> 6)) * a.Tpad + i) * 64 + (px & 63);
         return ((long)b * (a.n_ctx + 2) + i + 1) * a.ldc + px;
     }
-    if (EPI == EPI_VT_F16) { int kp = rb + dx, b = qb; if (kp >= a.Tpad) { kp -= a.Tpad; b += 1; } if (a.frag) return skw_vtfrag_off(b, a.H, a.Tpad, y, kp); return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
+    if (EPI == EPI_VT_F16) { int kp = rb + dx, b = qb; if (kp >= a.Tpad) { kp -= a.Tpad; b += 1; } if (a.frag) return skw_vtfrag_off(b, a.H, a.Tpad, y, kp);
+    return ((long)(b * a.H + (y >> 6)) * 64 + (y & 63)) * a.Tpad + kp; }
     if (EPI == EPI_F16_PLAIN) { if (a.frag) { int i = rb + dy, b = qb; if (i >= a.n_ctx) { i -= a.n_ctx; b += 1; } return skw_kfrag_off(b, a.H, a.Tpad, i, px); } }
     return (long)y * a.ldc + px;
 }
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
         for (int i = 0; i < A_PIECES; ++i) {
             int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
             int gm = m0 + c; if (PROBE && (a.probe & 256)) gm = c;      // (measurement only: every tile reads the first A panel — what the loop would take with the A operand always in L2)
-            if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }   // virtual -> real token row (pad rows compute on a copy and store zeros)
+            // virtual -> real token row (pad rows compute on a copy and store zeros)
+            if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }
             if (gm > a.M - 1) gm = a.M - 1;             // rows past M are computed on a copy of the last row and never stored
             const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
             gA[i] = a.A + off + pchunk * 8;
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             // The next step is staged unconditionally — the last step re-stages itself into the idle buffer (1/nk more L2 -> LDS traffic) — so that the whole K step is ONE basic block:
             // with the `kb + 1 < nk` branch (and the probe's) in front of the fragment reads, hipcc kept the step's address arithmetic and several accumulators' worth of state live
             // across four code paths and spilled (72-116 B of scratch per lane in three of the eight epilogue variants, none now); same-box A/B per launch: Q/K 175-189 -> 167-177 us,
-            // cross K 175-180 -> 167, O-proj 286-290 -> 243-246, FC1 739-746 -> 722, FC2 686 -> 641-648; encode 40.4-41.0 -> 38.8 ms per batch (profiles/r03g/r03g_gemm16_probe_single_block_k_step.txt)
+            // cross K 175-180 -> 167, O-proj 286-290 -> 243-246, FC1 739-746 -> 722, FC2 686 -> 641-648; encode 40.4-41.0 -> 38.8 ms per batch
+            //  (profiles/r03g/r03g_gemm16_probe_single_block_k_step.txt)
             if (!PROBE) stage((kb + 1) & 1, min(kb + 1, nk - 1));
             else if (kb + 1 < nk && !(a.probe & 1)) stage((kb + 1) & 1, kb + 1);
 #pragma unroll
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
             const int qb = org / div, rb = org % div;                                          // (scalar: once per tile)
             {   // features run along X (weights) except for V^T, where they run along Y
                 constexpr int NB = X_IS_M ? BY : BX;
-                if (tid < NB) { const int pos = (X_IS_M ? Y0 : X0) + tid; const int f = (PERM && !X_IS_M) ? ((pos & ~31) | inv_kperm32(pos & 31)) : pos; bias_l[tid] = (a.bias && f < a.N) ? a.bias[f] : 0.0f; }
+                if (tid < NB) { const int pos = (X_IS_M ? Y0 : X0) + tid; const int f = (PERM && !X_IS_M) ? ((pos & ~31) | inv_kperm32(pos & 31)) : pos;
+                bias_l[tid] = (a.bias && f < a.N) ? a.bias[f] : 0.0f; }
                 __syncthreads();
             }
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             o[r] = RAW ? acc[i][j][r] : epi_value<EPI>(a, p0 + r, acc[i][j][r], bx[r]);
-                            if (X_IS_M) { int key = rb + (((xl + r) & ~31) | inv_kperm32((xl + r) & 31)); if (key >= a.Tpad) key -= a.Tpad; if (key >= a.n_ctx) o[r] = 0.0f; }   // V^T: pad keys stay zero (logical key of this memory position)
+                            // V^T: pad keys stay zero (logical key of this memory position)
+                            if (X_IS_M) { int key = rb + (((xl + r) & ~31) | inv_kperm32((xl + r) & 31)); if (key >= a.Tpad) key -= a.Tpad; if (key >= a.n_ctx) o[r] = 0.0f; }
                         }
                         const int ck = xl / CE;
                         char* dst = stg + ylp * ROWB + ((ck ^ (ylp & (CPR - 1))) << 4);
@@ -305,8 +310,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                         const int y = Y0 + pass * RP + ylp, px = X0 + ck * CE;
                         lofs[u] = ylp * ROWB + (pc << 4);
                         off[u] = (y >= y_lim || px >= x_lim || (PROBE && (a.probe & 8))) ? -1 : epi_chunk_offset<EPI>(a, y, px, pass * RP + ylp, ck * CE, qb, rb);
-                        if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? (SKW_EPI_RES_NT ? __builtin_nontemporal_load((const f32x4*)(a.res + (long)y * a.ldres + px)) : *(const f32x4*)(a.res + (long)y * a.ldres + px)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (EPI == EPI_CONV2) { int i = rb + pass * RP + ylp; if (i >= a.n_ctx) i -= a.n_ctx; opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                        if (EPI == EPI_F32) opnd[u] = (a.res && off[u] >= 0) ? (SKW_EPI_RES_NT ? __builtin_nontemporal_load((const f32x4*)(a.res + (long)y * a.ldres + px))
+                                                                                                : *(const f32x4*)(a.res + (long)y * a.ldres + px))
+                                                                              : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_CONV2) { int i = rb + pass * RP + ylp; if (i >= a.n_ctx) i -= a.n_ctx;
+                        opnd[u] = (off[u] >= 0) ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
                     }
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u) {
@@ -316,7 +324,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN) / 4) void k_gemm16(SkwG
                             if (EPI == EPI_F32) { if (a.res) { v[0] = v[0] + opnd[u][0]; v[1] = v[1] + opnd[u][1]; v[2] = v[2] + opnd[u][2]; v[3] = v[3] + opnd[u][3]; } }
                             else { v[0] = opnd[u][0] + v[0]; v[1] = opnd[u][1] + v[1]; v[2] = opnd[u][2] + v[2]; v[3] = opnd[u][3] + v[3]; }
                             if (SKW_EPI_ST_NT) __builtin_nontemporal_store(v, (f32x4*)((float*)a.C + off[u])); else *(f32x4*)((float*)a.C + off[u]) = v;
-                        } else { const u32x4 o16 = *(const u32x4*)(stg + lofs[u]); if (SKW_EPI_ST_NT) __builtin_nontemporal_store(o16, (u32x4*)((half_t*)a.C + off[u])); else *(u32x4*)((half_t*)a.C + off[u]) = o16; }
+                        } else { const u32x4 o16 = *(const u32x4*)(stg + lofs[u]); if (SKW_EPI_ST_NT) __builtin_nontemporal_store(o16, (u32x4*)((half_t*)a.C + off[u]));
+                        else *(u32x4*)((half_t*)a.C + off[u]) = o16; }
                     }
                 }
                 __syncthreads();
@@ -344,7 +353,8 @@ template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_
     const int cus = skw_cu_count() & ~7;
     const SkwGemmArgs& a = a_in;
     static const int oldloop = getenv("SKW_GEMM16_OLDLOOP") ? atoi(getenv("SKW_GEMM16_OLDLOOP")) : 0;      // (A/B: the K loop with the staging branch, as it was)
-    if (big && (a.probe || oldloop)) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4, true>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
+    if (big && (a.probe || oldloop)) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4, true>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else { const int nblk = ((Mv + 127) / 128) * ((a.N + 127) / 128); hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(std::min(nblk, 2 * cus)), dim3(256), 0, s, a); }
 }
@@ -376,7 +386,8 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // XP — the prompt pass's cross attention (skw_engine.hip, prefill): the same kernel with the queries of a SEQUENCE'S prompt tokens (rows row0 .. row0 + nq of the pass, plain
 // [row][d] f16 in natural k order, as the cross-query GEMM leaves them) against that sequence's cross K (plain rows [key][d], natural order: both operands of the score MFMA
 // then agree on which k sits in which slot) and V^T (already this kernel's layout).  One read of a sequence's K / V^T serves up to 128 of its prompt tokens instead of one.
-struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };   // frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
+// frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
+struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };
 template <bool XP>
 __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
                                                            int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
@@ -417,7 +428,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (((row & 1) << 2) | ((row >> 2) & 3))) << 4));
         st_k[i] = (unsigned)((row * krow + pos * 8) * 2);            // + kb * 64 rows; rows past Tpad (XP: past n_ctx) fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
-        if (frag) {      // the same 16-byte chunks at their fragment-order addresses: a 64-key block is 8 KiB of either image (K: key tile row >> 4 of the block, row 4 (r & 3) + (r >> 2), d half pos >> 2; V^T: 32-key block pos >> 2, channel tile row >> 4)
+        // the same 16-byte chunks at their fragment-order addresses: a 64-key block is 8 KiB of either image (K: key tile row >> 4 of the block, row 4 (r & 3) + (r >>
+        //  2), d half pos >> 2; V^T: 32-key block pos >> 2, channel tile row >> 4)
+        if (frag) {
             const int r = row & 15;
             st_k[i] = (unsigned)((((row >> 4) * 2 + (pos >> 2)) * 1024) + (4 * (r & 3) + (r >> 2) + 16 * (pos & 3)) * 16);
             st_v[i] = (unsigned)((((pos >> 2) * 4 + (row >> 4)) * 1024) + (r + 16 * (pos & 3)) * 16);
@@ -430,7 +443,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * (frag ? 8192u : (unsigned)(krow * 128)), 0, 0);      // (keys past the end lie outside the descriptor: zeros, masked below)
+        // (keys past the end lie outside the descriptor: zeros, masked below)
+        for (int i = 0; i < 2; ++i) sk[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, st_k[i] + (unsigned)kb * (frag ? 8192u : (unsigned)(krow * 128)), 0, 0);
     };
     auto load_v = [&](int kb) {
 #pragma unroll
@@ -528,7 +542,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int pk = skw_kperm(h * 64 + ct * 16 + 4 * g + r); if (XP && xp.ofrag_k) out[skw_afrag_off((int)(qrow0 + qi), pk, xp.ofrag_k)] = (half_t)(oacc[qt][ct][r] * inv); else op[pk] = (half_t)(oacc[qt][ct][r] * inv); }
+                for (int r = 0; r < 4; ++r) { const int pk = skw_kperm(h * 64 + ct * 16 + 4 * g + r);
+                if (XP && xp.ofrag_k) out[skw_afrag_off((int)(qrow0 + qi), pk, xp.ofrag_k)] = (half_t)(oacc[qt][ct][r] * inv);
+                else op[pk] = (half_t)(oacc[qt][ct][r] * inv); }
         }
     }
 }
@@ -551,7 +567,8 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
     if (EPI == EPI_F32) {
         if ((a.ldc & 3) || p0 + 3 >= a.N) {            // logits: ldc = n_vocab is odd and the last strip is ragged
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r]; if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
+            for (int r = 0; r < 4; ++r) if (p0 + r < a.N) { float x = v[r];
+            if (a.bias) x = x + a.bias[p0 + r]; if (a.res) x = x + a.res[(long)m * a.ldres + p0 + r]; ((float*)a.C)[(long)m * a.ldc + p0 + r] = x; }
         } else {
             if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
             if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
@@ -659,20 +676,26 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;                  // k-blocks (of 32) per wave; host guarantees K % (32 NW) == 0
     int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
-    __amdgpu_buffer_rsrc_t rw = a.Wf ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.a_frag ? (unsigned)((long)((a.M + 15) & ~15) * a.K * 2) : (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = a.Wf ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2),
+        0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0,
+        a.a_frag ? (unsigned)((long)((a.M + 15) & ~15) * a.K * 2) : (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
     const unsigned oob = 0x7fffff00u;
     // a.probe (tools/dec_gemm_probe.py only): 1 = no weight loads, 2 = no activation loads (out-of-range offsets: zeros without memory traffic),
     // 4 = no partial-sum exchange and no epilogue, 8 = no stores
     // fragment-order weights (a.Wf): strip blockIdx.x's k-blocks are consecutive KiB, lane l's 16 bytes at l * 16 — the row permutation of the GELU epilogues is in the image
     const bool wfrag = a.Wf != nullptr;
     const unsigned wstep = wfrag ? 1024u : 64u;
-    const unsigned wo = (a.probe & 1) ? oob : wfrag ? (n0 + 15 < a.N ? (unsigned)(((long)blockIdx.x * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob) : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    const unsigned wo = (a.probe & 1) ? oob
+                      : wfrag ? (n0 + 15 < a.N ? (unsigned)(((long)blockIdx.x * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob)
+                      : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
     unsigned ao[MT];
     // a.a_frag: the activations are a fragment-order image (written that way by the product before, SkwGemmArgs::c_frag): a row tile's k-blocks are consecutive KiB
     const bool afrag = a.a_frag != 0; const unsigned astep = afrag ? 1024u : 64u;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16; ao[t] = (m < a.M && !(a.probe & 2)) ? (afrag ? (unsigned)(((long)(blockIdx.y * MT + t) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2)) : oob; }
+    for (int t = 0; t < MT; ++t) { const int m = my0 + t * 16 + r16;
+    ao[t] = (m < a.M && !(a.probe & 2)) ? (afrag ? (unsigned)(((long)(blockIdx.y * MT + t) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : (unsigned)(((long)m * a.lda + kb_lo * 32 + g * 8) * 2)) : oob;
+    }
     u32x4 fw[RD], fa[RD][MT];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
@@ -746,7 +769,8 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int nkw = (a.K >> 5) / NW, kb_lo = w * nkw;               // host: nkw <= NKW
     const bool wfrag = a.Wf != nullptr;      // fragment-order image of the natural-k weight (see k_gemm16_small)
-    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2), 0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = wfrag ? __builtin_amdgcn_make_buffer_rsrc((void*)a.Wf, 0, (unsigned)((long)a.N * a.K * 2),
+        0x00020000) : __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
     const unsigned wstep = wfrag ? 1024u : 64u;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_x, 0, (unsigned)((long)a.M * a.K * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_w, 0, (unsigned)(a.K * 4), 0x00020000);
@@ -754,7 +778,10 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
     const unsigned oob = 0x7fffff00u;
     unsigned wo[NT];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) { int wn = n0 + 16 * q + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31); wo[q] = wfrag ? (n0 + 16 * q + 15 < a.N ? (unsigned)(((long)(blockIdx.x * NT + q) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob) : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob; }
+    for (int q = 0; q < NT; ++q) { int wn = n0 + 16 * q + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
+    wo[q] = wfrag ? (n0 + 16 * q + 15 < a.N ? (unsigned)(((long)(blockIdx.x * NT + q) * (a.K >> 5) + kb_lo) * 1024 + lane * 16) : oob)
+          : wn < a.N ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
+    }
     const unsigned ko = (unsigned)((kb_lo * 32 + g * 8) * 4);          // byte offset of this lane's eight k inside an f32 row (x, gain, bias)
     unsigned xo[MT];
 #pragma unroll
@@ -793,7 +820,8 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NKW; ++j)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { fg[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rg, j < nkw ? ko + j * 128 + h * 16 : oob, 0, 0); fb[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rb, j < nkw ? ko + j * 128 + h * 16 : oob, 0, 0); }
+        for (int h = 0; h < 2; ++h) { fg[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rg, j < nkw ? ko + j * 128 + h * 16 : oob, 0, 0);
+        fb[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rb, j < nkw ? ko + j * 128 + h * 16 : oob, 0, 0); }
     __syncthreads();
     float sa[MT], sb[MT];                                               // x -> x * sa + sb = (x - mean) * rstd
 #pragma unroll
@@ -817,7 +845,8 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
                 const f32x4 x0 = __builtin_bit_cast(f32x4, fx[j][t][0]), x1 = __builtin_bit_cast(f32x4, fx[j][t][1]);
                 f16x8 xa;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { xa[e] = (half_t)__builtin_fmaf(__builtin_fmaf(x0[e], sa[t], sb[t]), g0[e], b0[e]); xa[4 + e] = (half_t)__builtin_fmaf(__builtin_fmaf(x1[e], sa[t], sb[t]), g1[e], b1[e]); }
+                for (int e = 0; e < 4; ++e) { xa[e] = (half_t)__builtin_fmaf(__builtin_fmaf(x0[e], sa[t], sb[t]), g0[e], b0[e]);
+                xa[4 + e] = (half_t)__builtin_fmaf(__builtin_fmaf(x1[e], sa[t], sb[t]), g1[e], b1[e]); }
 #pragma unroll
                 for (int q = 0; q < NT; ++q) acc[t][q] = MFMA16X32(__builtin_bit_cast(f16x8, fw[j][q]), xa, acc[t][q]);
             }
@@ -1071,7 +1100,9 @@ __global__ __launch_bounds__(64 * NWV) void k_gemm16_vocab(SkwGemmArgs a, int st
 template <int MT, int RD, int NWV> static void launch_gemm16_vocab_n(const SkwGemmArgs& a, hipStream_t s) {
     const int lds = 16 * MT * (a.K * 2 + 16);
     static std::atomic<bool> once[64];      // the attribute is per device
-    { const int dev = skw_cur_device(); if (!once[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once[dev].store(true, std::memory_order_release); } }
+    { const int dev = skw_cur_device(); if (!once[dev].load(std::memory_order_acquire)) { hipFuncSetAttribute((const void*)k_gemm16_vocab<MT, RD, NWV>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once[dev].store(true, std::memory_order_release); } }
     const int n_strips = (a.N + 15) / 16, rows = (a.M + 16 * MT - 1) / (16 * MT);
     const int slots = std::max(1, skw_cu_count() / rows);
     const int spw = (n_strips + slots - 1) / slots;
@@ -1105,7 +1136,8 @@ template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStre
     static const int mt_vocab = getenv("SKW_DEC_MT_VOCAB") ? atoi(getenv("SKW_DEC_MT_VOCAB")) : 4;   // the logits product: thousands of strips, W read once
     static const int nw_deep = getenv("SKW_DEC_NW_DEEP") ? atoi(getenv("SKW_DEC_NW_DEEP")) : 4;      // K >= 2048 (fc2); eight waves measured slower: a launch costs ~0.8 us per 1000 waves
     static const int nw_env = getenv("SKW_DEC_NW") ? atoi(getenv("SKW_DEC_NW")) : 4;
-    static const int rd_deep = getenv("SKW_DEC_RD_DEEP") ? atoi(getenv("SKW_DEC_RD_DEEP")) : 12;     // fc2: 24 = the whole K quarter of a wave in flight at once instead of two rounds of 12 k-blocks; measured slower (decode 167.6 vs 166.3 ms)
+    // fc2: 24 = the whole K quarter of a wave in flight at once instead of two rounds of 12 k-blocks; measured slower (decode 167.6 vs 166.3 ms)
+    static const int rd_deep = getenv("SKW_DEC_RD_DEEP") ? atoi(getenv("SKW_DEC_RD_DEEP")) : 12;
     const int mt = a.N >= 8192 ? mt_vocab : (a.N >= 2048 ? mt_wide : mt_env);
     const int nw = (a.K >= 2048 ? nw_deep : nw_env) == 8 && !(a.K & 255) && mt == 1 ? 8 : 4;
     if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);

@@ -34,7 +34,8 @@ namespace {
 
 thread_local std::string g_last_error;      // conversions.rs:441-461: thread-local, borrowed until the next error on this thread
 CResult ok_result() { CResult r; r.success = true; r.error_message = nullptr; return r; }
-CResult err_result(const std::string& msg) { g_last_error = msg; for (auto& ch : g_last_error) if (ch == '\0') ch = ' '; CResult r; r.success = false; r.error_message = g_last_error.c_str(); return r; }
+CResult err_result(const std::string& msg) { g_last_error = msg; for (auto& ch : g_last_error) if (ch == '\0') ch = ' '; CResult r;
+r.success = false; r.error_message = g_last_error.c_str(); return r; }
 CResult err_null() { CResult r; r.success = false; r.error_message = nullptr; return r; }
 template <typename F> CResult guarded(F&& f) {      // nothing unwinds into the host's Rust frames
     try { return f(); }
@@ -61,7 +62,9 @@ bool parse_config(const skw::JsonValue& v, KokoroTtsConfig* c, std::string* err)
     c->model_dir = md->str;
     auto integer = [&](const char* k, double lo, double hi, double* dst) {
         const skw::JsonValue* x = v.get(k); if (!x) return true;
-        if (x->type != skw::JsonValue::Number || x->num != std::floor(x->num) || x->num < lo || x->num > hi) { *err = std::string("Config parse error: invalid value for `") + k + "`, expected an integer"; return false; }
+        if (x->type != skw::JsonValue::Number || x->num != std::floor(x->num) || x->num < lo
+            || x->num > hi) { *err = std::string("Config parse error: invalid value for `") + k + "`, expected an integer";
+        return false; }
         *dst = x->num; return true;
     };
     double d;
@@ -70,9 +73,12 @@ bool parse_config(const skw::JsonValue& v, KokoroTtsConfig* c, std::string* err)
     d = (double)c->min_sentence_length; if (!integer("min_sentence_length", 0.0, 9007199254740992.0, &d)) return false; c->min_sentence_length = (size_t)d;
     d = (double)c->telemetry_preview_chars; if (!integer("telemetry_preview_chars", 0.0, 9007199254740992.0, &d)) return false; c->telemetry_preview_chars = (size_t)d;
     d = c->gpu_device; if (!integer("gpu_device", 0.0, 1024.0, &d)) return false; c->gpu_device = (int)d;
-    if (const skw::JsonValue* x = v.get("speed")) { if (x->type != skw::JsonValue::Number) { *err = "Config parse error: invalid type for `speed`, expected a number"; return false; } c->speed = (float)x->num; }
-    if (const skw::JsonValue* x = v.get("execution_provider")) { if (x->type != skw::JsonValue::String) { *err = "Config parse error: invalid type for `execution_provider`, expected a string"; return false; } c->execution_provider = x->str; }
-    if (const skw::JsonValue* x = v.get("emit_telemetry")) { if (x->type != skw::JsonValue::Bool) { *err = "Config parse error: invalid type for `emit_telemetry`, expected a boolean"; return false; } c->emit_telemetry = x->b; }
+    if (const skw::JsonValue* x = v.get("speed")) { if (x->type != skw::JsonValue::Number) { *err = "Config parse error: invalid type for `speed`, expected a number";
+    return false; } c->speed = (float)x->num; }
+    if (const skw::JsonValue* x = v.get("execution_provider")) { if (x->type != skw::JsonValue::String) { *err = "Config parse error: invalid type for `execution_provider`, expected a string";
+    return false; } c->execution_provider = x->str; }
+    if (const skw::JsonValue* x = v.get("emit_telemetry")) { if (x->type != skw::JsonValue::Bool) { *err = "Config parse error: invalid type for `emit_telemetry`, expected a boolean";
+    return false; } c->emit_telemetry = x->b; }
     return true;
 }
 
@@ -99,7 +105,8 @@ std::shared_ptr<Engine> create_engine(const std::string& dir, const KokoroTtsCon
 struct KokoroTtsNode {
     std::shared_ptr<Engine> engine; KokoroTtsConfig config; std::string text_buffer; skw::kokoro::SentenceSplitter splitter;
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
-    void log(CLogLevel lv, const char* fmt, ...) { if (!log_cb) return; char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); log_cb(lv, "kokoro::kokoro_node", buf, log_ud); }
+    void log(CLogLevel lv, const char* fmt, ...) { if (!log_cb) return; char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap); log_cb(lv, "kokoro::kokoro_node", buf, log_ud); }
 };
 
 // KokoroTtsNode::new (kokoro_node.rs:258-441)

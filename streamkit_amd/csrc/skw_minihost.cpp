@@ -25,7 +25,8 @@
 namespace {
 std::string jq(const std::string& s) {
     std::string o = "\""; char buf[8];
-    for (unsigned char c : s) { switch (c) { case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break; case '\r': o += "\\r"; break; case '\t': o += "\\t"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
+    for (unsigned char c : s) { switch (c) { case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break;
+    case '\r': o += "\\r"; break; case '\t': o += "\\t"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
         default: if (c < 0x20) { snprintf(buf, sizeof buf, "\\u%04x", c); o += buf; } else o += (char)c; } }
     return o + "\"";
 }
@@ -50,24 +51,30 @@ mh_plugin* mh_load(const char* path, char* err, size_t errlen) {
     if (!get) { snprintf(err, errlen, "Failed to find symbol %s", STREAMKIT_PLUGIN_API_SYMBOL); dlclose(lib); return nullptr; }
     const CNativePluginAPI* api = get();
     if (!api) { snprintf(err, errlen, "Plugin returned null API pointer"); dlclose(lib); return nullptr; }
-    if (api->version != STREAMKIT_NATIVE_PLUGIN_API_VERSION) { snprintf(err, errlen, "Plugin API version mismatch: expected %u, got %u", STREAMKIT_NATIVE_PLUGIN_API_VERSION, api->version); dlclose(lib); return nullptr; }
+    if (api->version != STREAMKIT_NATIVE_PLUGIN_API_VERSION) { snprintf(err, errlen, "Plugin API version mismatch: expected %u, got %u", STREAMKIT_NATIVE_PLUGIN_API_VERSION, api->version);
+    dlclose(lib); return nullptr; }
     const CNodeMetadata* md = api->get_metadata();
     if (!md || !md->kind) { snprintf(err, errlen, "Plugin returned null metadata"); dlclose(lib); return nullptr; }
     mh_plugin* p = new mh_plugin(); p->lib = lib; p->api = api; p->kind = md->kind;
     if (p->kind.find("::") != std::string::npos) { snprintf(err, errlen, "plugin kind must not contain '::'"); delete p; dlclose(lib); return nullptr; }   // plugin-native lib.rs:307-333
-    std::string j = "{\"kind\":" + jq(md->kind) + ",\"registered_as\":" + jq("plugin::native::" + p->kind) + ",\"description\":" + (md->description ? jq(md->description) : std::string("null")) + ",\"inputs\":[";
+    std::string j = "{\"kind\":" + jq(md->kind) + ",\"registered_as\":" + jq("plugin::native::" + p->kind);
+    j += ",\"description\":" + (md->description ? jq(md->description) : std::string("null")) + ",\"inputs\":[";
     for (size_t i = 0; i < md->inputs_count; ++i) {
         if (i) j += ","; j += "{\"name\":" + jq(md->inputs[i].name) + ",\"accepts\":[";
         for (size_t k = 0; k < md->inputs[i].accepts_types_count; ++k) {
             const CPacketTypeInfo& t = md->inputs[i].accepts_types[k]; if (k) j += ",";
             j += "{\"type\":" + std::to_string((int)t.type_discriminant);
-            if (t.audio_format) j += ",\"sample_rate\":" + std::to_string(t.audio_format->sample_rate) + ",\"channels\":" + std::to_string(t.audio_format->channels) + ",\"sample_format\":" + std::to_string((int)t.audio_format->sample_format);
+            if (t.audio_format) {
+                j += ",\"sample_rate\":" + std::to_string(t.audio_format->sample_rate) + ",\"channels\":" + std::to_string(t.audio_format->channels);
+                j += ",\"sample_format\":" + std::to_string((int)t.audio_format->sample_format);
+            }
             j += "}";
         }
         j += "]}";
     }
     j += "],\"outputs\":[";
-    for (size_t i = 0; i < md->outputs_count; ++i) { if (i) j += ","; j += "{\"name\":" + jq(md->outputs[i].name) + ",\"type\":" + std::to_string((int)md->outputs[i].produces_type.type_discriminant) + "}"; }
+    for (size_t i = 0; i < md->outputs_count; ++i) { if (i) j += ",";
+    j += "{\"name\":" + jq(md->outputs[i].name) + ",\"type\":" + std::to_string((int)md->outputs[i].produces_type.type_discriminant) + "}"; }
     j += "],\"categories\":[";
     for (size_t i = 0; i < md->categories_count; ++i) { if (i) j += ","; j += jq(md->categories[i]); }
     j += "],\"param_schema\":" + std::string(md->param_schema ? md->param_schema : "null") + "}";
@@ -90,7 +97,8 @@ static CResult out_shim(const char* pin, const CPacket* pk, void* ud) {
     mh_output o; o.pin = pin; o.packet_type = (int)pk->packet_type;
     if (pk->packet_type == SK_PACKET_TRANSCRIPTION || pk->packet_type == SK_PACKET_BINARY) o.payload.assign((const char*)pk->data, pk->len);
     else if (pk->packet_type == SK_PACKET_TEXT) o.payload = (const char*)pk->data;
-    else if (pk->packet_type == SK_PACKET_RAW_AUDIO) { const CAudioFrame* f = (const CAudioFrame*)pk->data; o.payload.assign((const char*)f->samples, f->sample_count * sizeof(float)); o.sample_rate = f->sample_rate; o.channels = f->channels; }
+    else if (pk->packet_type == SK_PACKET_RAW_AUDIO) { const CAudioFrame* f = (const CAudioFrame*)pk->data;
+    o.payload.assign((const char*)f->samples, f->sample_count * sizeof(float)); o.sample_rate = f->sample_rate; o.channels = f->channels; }
     else { n->cb_error = "Failed to convert packet: Unsupported packet type"; r.success = false; return r; }
     n->outputs.push_back(std::move(o)); r.success = true; return r;
 }
@@ -133,7 +141,8 @@ int mh_process_binary(mh_node* n, const void* data, size_t len) {
     CResult res = n->plugin->api->process_packet(n->handle, "in", &pk, out_shim, n, tel_shim, n);
     if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; return -1; } return 0;
 }
-int mh_output_audio_format(mh_node* n, size_t i, uint32_t* rate, uint16_t* channels) { if (i >= n->outputs.size()) return -1; *rate = n->outputs[i].sample_rate; *channels = n->outputs[i].channels; return 0; }
+int mh_output_audio_format(mh_node* n, size_t i, uint32_t* rate, uint16_t* channels) { if (i >= n->outputs.size()) return -1;
+*rate = n->outputs[i].sample_rate; *channels = n->outputs[i].channels; return 0; }
 // The Transcription -> Text step of the voice-agent pipelines (samples/pipelines/dynamic/voice-agent-openai.yaml:86-95, a core::script node): output i of
 // `src` (a Transcription packet) becomes a Text packet into `dst`; an empty / missing text produces nothing (returns 1).  skw_kokoro_text.h.
 int mh_forward_transcription_as_text(mh_node* src, size_t i, mh_node* dst) {
@@ -141,13 +150,18 @@ int mh_forward_transcription_as_text(mh_node* src, size_t i, mh_node* dst) {
     std::string text; if (!skw::kokoro::transcription_to_text(src->outputs[i].payload, &text)) return 1;
     return mh_process_text(dst, text.c_str());
 }
-int mh_process_null(mh_node* n) { CResult res = n->plugin->api->process_packet(n->handle, nullptr, nullptr, out_shim, n, tel_shim, n); if (!res.success) { n->last_error = res.error_message ? res.error_message : "(null message)"; return -1; } return 0; }
+int mh_process_null(mh_node* n) { CResult res = n->plugin->api->process_packet(n->handle, nullptr, nullptr, out_shim, n, tel_shim, n);
+if (!res.success) { n->last_error = res.error_message ? res.error_message : "(null message)"; return -1; } return 0; }
 int mh_update_params(mh_node* n, const char* json) {
-    CResult res; std::string emsg; std::thread t([&] { res = n->plugin->api->update_params(n->handle, json); if (!res.success) emsg = res.error_message ? res.error_message : "Failed to update parameters"; }); t.join();
+    CResult res; std::string emsg; std::thread t([&] { res = n->plugin->api->update_params(n->handle, json);
+        if (!res.success) emsg = res.error_message ? res.error_message : "Failed to update parameters"; });
+    t.join();
     if (!emsg.empty()) { n->last_error = emsg; return -1; } return 0;   // only logged by the host (wrapper.rs:297-299)
 }
 int mh_flush(mh_node* n) {
-    CResult res; std::string emsg; std::thread t([&] { res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n); if (!res.success) emsg = res.error_message ? res.error_message : "Plugin flush failed"; }); t.join();
+    CResult res; std::string emsg; std::thread t([&] { res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n);
+        if (!res.success) emsg = res.error_message ? res.error_message : "Plugin flush failed"; });
+    t.join();
     if (!emsg.empty()) { n->last_error = emsg; return -1; } return 0;
 }
 // Oneshot batch driver (BASELINE config 2): one pipeline task (thread) per node feeds its clip in `packet`-sample RawAudio packets and
@@ -168,7 +182,8 @@ int mh_run_oneshot(mh_node** nodes, int n_nodes, const float* const* pcm, const 
             if (!res.success) { n->last_error = res.error_message ? res.error_message : "Unknown plugin error"; n->failed = true; rc[i] = -1; }
             else if (!n->cb_error.empty()) { n->last_error = n->cb_error; n->failed = true; rc[i] = -1; }
         }
-        if (rc[i] == 0) { CResult res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n); if (!res.success) { n->last_error = res.error_message ? res.error_message : "Plugin flush failed"; rc[i] = -1; } }
+        if (rc[i] == 0) { CResult res = n->plugin->api->flush(n->handle, out_shim, n, tel_shim, n);
+        if (!res.success) { n->last_error = res.error_message ? res.error_message : "Plugin flush failed"; rc[i] = -1; } }
     });
     for (auto& t : th) t.join();
     clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -223,7 +238,8 @@ struct FastFixedInLinear {
     int ch, chunk; double last_index, ratio; std::vector<std::vector<float>> buf;
     FastFixedInLinear(double r, int chunk_frames, int channels) : ch(channels), chunk(chunk_frames), last_index(-4.0), ratio(r), buf(channels, std::vector<float>(chunk_frames + 16, 0.0f)) {}
     void process(const std::vector<std::vector<float>>& in, std::vector<std::vector<float>>& out) {
-        for (int c = 0; c < ch; ++c) { std::copy(buf[c].begin() + chunk, buf[c].begin() + chunk + 16, buf[c].begin()); std::copy(in[c].begin(), in[c].begin() + chunk, buf[c].begin() + 16); out[c].clear(); }
+        for (int c = 0; c < ch; ++c) { std::copy(buf[c].begin() + chunk, buf[c].begin() + chunk + 16, buf[c].begin());
+        std::copy(in[c].begin(), in[c].begin() + chunk, buf[c].begin() + 16); out[c].clear(); }
         double idx = last_index; const double t_ratio = 1.0 / ratio; const double end_idx = (double)(chunk - 9) - std::ceil(t_ratio);
         while (idx < end_idx) {
             idx += t_ratio; const double fl = std::floor(idx); const long start = (long)fl; const float frac = (float)(idx - fl);
@@ -239,19 +255,25 @@ struct mh_resampler {
     std::vector<mh_rs_packet> out; std::string err;
     ~mh_resampler() { delete rs; }
     static uint64_t dur_us(uint32_t rate, size_t frames) { if (!rate) return 0; return ((uint64_t)frames * 1000000ull) / rate; }   // resampler.rs:108-116
-    void emit(const float* d, size_t n) { mh_rs_packet p; p.samples.assign(d, d + n); p.duration_us = dur_us(target, n / channels); p.has_ts = has_ts; p.timestamp_us = ts; p.sequence = seq++; if (has_ts) ts += p.duration_us; out.push_back(std::move(p)); }   // next_metadata :286-297
-    void drain_output_frames() { const size_t fs = out_frame * channels; size_t off = 0; while (output_buffer.size() - off >= fs) { emit(output_buffer.data() + off, fs); off += fs; } output_buffer.erase(output_buffer.begin(), output_buffer.begin() + off); }
+    // next_metadata :286-297
+    void emit(const float* d, size_t n) { mh_rs_packet p; p.samples.assign(d, d + n); p.duration_us = dur_us(target, n / channels); p.has_ts = has_ts;
+    p.timestamp_us = ts; p.sequence = seq++; if (has_ts) ts += p.duration_us; out.push_back(std::move(p)); }
+    void drain_output_frames() { const size_t fs = out_frame * channels;
+    size_t off = 0; while (output_buffer.size() - off >= fs) { emit(output_buffer.data() + off, fs);
+    off += fs; } output_buffer.erase(output_buffer.begin(), output_buffer.begin() + off); }
 };
 mh_resampler* mh_resampler_new(uint32_t target_rate, size_t chunk_frames, size_t output_frame_size, char* err, size_t errlen) {
     if (target_rate == 0) { snprintf(err, errlen, "target_sample_rate must be greater than 0"); return nullptr; }
     if (chunk_frames == 0) { snprintf(err, errlen, "chunk_frames must be greater than 0"); return nullptr; }
-    if (output_frame_size != 0) { const size_t ok[] = {120, 240, 480, 960, 1920, 2880}; bool f = false; for (size_t v : ok) f = f || v == output_frame_size; if (!f) { snprintf(err, errlen, "output_frame_size must be 0 (disabled) or a valid Opus frame size: [120, 240, 480, 960, 1920, 2880]"); return nullptr; } }
+    if (output_frame_size != 0) { const size_t ok[] = {120, 240, 480, 960, 1920, 2880}; bool f = false; for (size_t v : ok) f = f || v == output_frame_size;
+    if (!f) { snprintf(err, errlen, "output_frame_size must be 0 (disabled) or a valid Opus frame size: [120, 240, 480, 960, 1920, 2880]"); return nullptr; } }
     mh_resampler* r = new mh_resampler(); r->target = target_rate; r->chunk_frames = chunk_frames; r->out_frame = output_frame_size; return r;
 }
 int mh_resampler_push(mh_resampler* r, const float* samples, size_t count, uint32_t rate, uint16_t channels, int has_ts, uint64_t ts_us) {
     if (!r->init) { r->init = true; r->needs = rate != r->target; r->rate = rate; r->channels = channels; if (has_ts) { r->has_ts = true; r->ts = ts_us; }
         if (r->needs) r->rs = new FastFixedInLinear((double)r->target / (double)rate, (int)r->chunk_frames, channels); }
-    if (rate != r->rate || channels != r->channels) { char b[160]; snprintf(b, sizeof b, "Audio format changed mid-stream: expected %uHz/%uch, got %uHz/%uch", r->rate, r->channels, rate, channels); r->err = b; return -1; }
+    if (rate != r->rate || channels != r->channels) { char b[160];
+    snprintf(b, sizeof b, "Audio format changed mid-stream: expected %uHz/%uch, got %uHz/%uch", r->rate, r->channels, rate, channels); r->err = b; return -1; }
     if (!r->needs) {   // R2: pass-through / re-chunk (resampler.rs:299-373)
         if (r->out_frame == 0) { r->emit(samples, count); return 0; }   // forwarded unchanged (metadata of the input packet in the reference)
         r->output_buffer.insert(r->output_buffer.end(), samples, samples + count); r->drain_output_frames(); return 0;
@@ -304,7 +326,9 @@ int mh_segment_sim(const float* prob, int n_frames, float threshold, uint64_t mi
     std::vector<float> frame(512, 0.25f);
     for (int f = 0; f < n_frames; ++f) {
         seg.push(frame.data(), 512, vad, [](const skw::SpeechStart&) {}, [&](const skw::SegmentCut& c) {
-            if (n_cuts < max_cuts) { long long* o = cuts + 6 * n_cuts; o[0] = (long long)c.start_time_ms; o[1] = (long long)c.end_time_ms; o[2] = (long long)c.samples.size(); o[3] = strcmp(c.reason, "silence") == 0 ? 1 : 0; o[4] = c.has_silence_duration ? (long long)c.silence_duration_ms : -1; o[5] = f; }
+            if (n_cuts < max_cuts) { long long* o = cuts + 6 * n_cuts; o[0] = (long long)c.start_time_ms;
+            o[1] = (long long)c.end_time_ms; o[2] = (long long)c.samples.size();
+            o[3] = strcmp(c.reason, "silence") == 0 ? 1 : 0; o[4] = c.has_silence_duration ? (long long)c.silence_duration_ms : -1; o[5] = f; }
             n_cuts++; return true; }, &err);
     }
     return n_cuts;
@@ -368,7 +392,9 @@ int mh_kokoro_extract_sentence(char* buffer, size_t cap, size_t min_length, char
     std::string b = buffer, s; const bool got = skw::kokoro::SentenceSplitter(min_length).extract_sentence(&b, &s);
     snprintf(buffer, cap, "%s", b.c_str()); if (got) snprintf(sentence, sentence_cap, "%s", s.c_str()); return got ? 1 : 0;
 }
-int mh_kokoro_flush(char* buffer, size_t cap, char* out, size_t out_cap) { std::string b = buffer, s; const bool got = skw::kokoro::SentenceSplitter::flush(&b, &s); snprintf(buffer, cap, "%s", b.c_str()); if (got) snprintf(out, out_cap, "%s", s.c_str()); return got ? 1 : 0; }
+int mh_kokoro_flush(char* buffer, size_t cap, char* out, size_t out_cap) { std::string b = buffer, s;
+const bool got = skw::kokoro::SentenceSplitter::flush(&b, &s); snprintf(buffer, cap, "%s", b.c_str()); if (got) snprintf(out, out_cap, "%s", s.c_str());
+return got ? 1 : 0; }
 const char* mh_kokoro_preview(const char* s, size_t max_chars) { static thread_local std::string r; if (!skw::kokoro::text_preview(s, max_chars, &r)) return nullptr; return r.c_str(); }
 const char* mh_json_quote(const char* s) { static thread_local std::string r; r = skw::json_quote(s); return r.c_str(); }
 const char* mh_json_f32(float f) { static thread_local std::string r; r = skw::json_f32(f); return r.c_str(); }

@@ -80,23 +80,36 @@ bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
     if (!skw::json_parse(json, &v, &perr)) { *err = "Invalid config: " + perr; return false; }
     if (v.type == skw::JsonValue::Null) return true;
     if (v.type != skw::JsonValue::Object) { *err = "Invalid config: expected a JSON object"; return false; }
-    auto str = [&](const char* k, std::string* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::String) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a string"; return false; } *dst = x->str; return true; };
-    auto num = [&](const char* k, double* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Number) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a number"; return false; } *dst = x->num; return true; };
-    auto boo = [&](const char* k, bool* dst) { const skw::JsonValue* x = v.get(k); if (!x) return true; if (x->type != skw::JsonValue::Bool) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a boolean"; return false; } *dst = x->b; return true; };
+    auto str = [&](const char* k, std::string* dst) { const skw::JsonValue* x = v.get(k);
+    if (!x) return true; if (x->type != skw::JsonValue::String) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a string";
+    return false; } *dst = x->str; return true; };
+    auto num = [&](const char* k, double* dst) { const skw::JsonValue* x = v.get(k);
+    if (!x) return true; if (x->type != skw::JsonValue::Number) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a number";
+    return false; } *dst = x->num; return true; };
+    auto boo = [&](const char* k, bool* dst) { const skw::JsonValue* x = v.get(k);
+    if (!x) return true; if (x->type != skw::JsonValue::Bool) { *err = std::string("Invalid config: invalid type for `") + k + "`, expected a boolean";
+    return false; } *dst = x->b; return true; };
     double d;
-    if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode) || !str("precision", &cfg->precision)) return false;
+    if (!str("model_path", &cfg->model_path) || !str("language", &cfg->language) || !str("vad_model_path", &cfg->vad_model_path) || !str("vad_mode", &cfg->vad_mode)
+        || !str("precision", &cfg->precision)) return false;
     if (cfg->precision != "exact" && cfg->precision != "f16_mfma") { *err = "Invalid config: precision must be \"exact\" or \"f16_mfma\""; return false; }
     if (!str("input_resample_mode", &cfg->input_resample_mode)) return false;
     if (cfg->input_resample_mode != "linear" && cfg->input_resample_mode != "polyphase") { *err = "Invalid config: input_resample_mode must be \"linear\" or \"polyphase\""; return false; }
-    d = cfg->input_sample_rate; if (!num("input_sample_rate", &d)) return false; if (d < 1000 || d > 768000 || d != std::floor(d)) { *err = "Invalid config: input_sample_rate must be an integer between 1000 and 768000"; return false; } cfg->input_sample_rate = (uint32_t)d;
+    d = cfg->input_sample_rate; if (!num("input_sample_rate", &d)) return false;
+    if (d < 1000 || d > 768000 || d != std::floor(d)) { *err = "Invalid config: input_sample_rate must be an integer between 1000 and 768000";
+    return false; } cfg->input_sample_rate = (uint32_t)d;
     d = cfg->vad_threshold; if (!num("vad_threshold", &d)) return false; cfg->vad_threshold = (float)d;
-    d = (double)cfg->min_silence_duration_ms; if (!num("min_silence_duration_ms", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: min_silence_duration_ms must be a non-negative integer"; return false; } cfg->min_silence_duration_ms = (uint64_t)d;
+    d = (double)cfg->min_silence_duration_ms; if (!num("min_silence_duration_ms", &d)) return false;
+    if (d < 0 || d != std::floor(d)) { *err = "Invalid config: min_silence_duration_ms must be a non-negative integer";
+    return false; } cfg->min_silence_duration_ms = (uint64_t)d;
     d = cfg->max_segment_duration_secs; if (!num("max_segment_duration_secs", &d)) return false; cfg->max_segment_duration_secs = (float)d;
-    d = (double)cfg->n_threads; if (!num("n_threads", &d)) return false; if (d < 0 || d != std::floor(d)) { *err = "Invalid config: n_threads must be a non-negative integer"; return false; } cfg->n_threads = (uint64_t)d;
+    d = (double)cfg->n_threads; if (!num("n_threads", &d)) return false;
+    if (d < 0 || d != std::floor(d)) { *err = "Invalid config: n_threads must be a non-negative integer"; return false; } cfg->n_threads = (uint64_t)d;
     {   // gpu_device: an integer as in the reference (lib.rs:31-33), or (additive) the string "auto": instances are dealt round-robin over the visible GPUs
         const skw::JsonValue* x = v.get("gpu_device");
         if (x && x->type == skw::JsonValue::String) { if (x->str != "auto") { *err = "Invalid config: gpu_device must be an integer or \"auto\""; return false; } cfg->gpu_device_auto = true; }
-        else { d = cfg->gpu_device; if (!num("gpu_device", &d)) return false; if (d != std::floor(d)) { *err = "Invalid config: gpu_device must be an integer"; return false; } cfg->gpu_device = (int)d; }
+        else { d = cfg->gpu_device; if (!num("gpu_device", &d)) return false; if (d != std::floor(d)) { *err = "Invalid config: gpu_device must be an integer";
+        return false; } cfg->gpu_device = (int)d; }
     }
     d = cfg->batch_window_ms; if (!num("batch_window_ms", &d)) return false; cfg->batch_window_ms = (int)d;
     d = cfg->max_batch; if (!num("max_batch", &d)) return false; cfg->max_batch = std::max(1, (int)d);
@@ -214,7 +227,8 @@ std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, WhisperPlugin
     auto it = cache.map.find(key);
     if (it != cache.map.end()) {
         g_cache_hits.fetch_add(1);
-        { std::lock_guard<std::mutex> le(it->second->mu); it->second->batch_limit = cfg.max_batch; it->second->window_ms = cfg.batch_window_ms; }      // additive scheduler params: the most recent instance's
+        // additive scheduler params: the most recent instance's
+        { std::lock_guard<std::mutex> le(it->second->mu); it->second->batch_limit = cfg.max_batch; it->second->window_ms = cfg.batch_window_ms; }
         if (who) who->log(SK_LOG_INFO, "CACHE HIT: Reusing cached Whisper context (model_path=%s, gpu_device=%d, precision=%s)", cfg.model_path.c_str(), cfg.gpu_device, cfg.precision.c_str());
         return it->second;
     }
@@ -415,7 +429,8 @@ CPluginHandle create_instance_impl(const char* params, CLogCallback log_cb, void
     p->seg.configure(p->config.vad_threshold, p->config.min_silence_duration_ms, p->config.max_segment_duration_secs);
     if (p->config.input_sample_rate != 16000) {
         p->front.reset(new skw::ResamplerCore());
-        p->front->target = 16000; p->front->chunk_frames = 960; p->front->out_frame = 0; p->front->gpu_device = p->config.gpu_device; p->front->polyphase = p->config.input_resample_mode == "polyphase";
+        p->front->target = 16000; p->front->chunk_frames = 960; p->front->out_frame = 0;
+        p->front->gpu_device = p->config.gpu_device; p->front->polyphase = p->config.input_resample_mode == "polyphase";
     }
     return (CPluginHandle)p.release();
 }

@@ -65,7 +65,8 @@ struct ResamplerCore {
                 if (!dsp) { *err = std::string("Failed to create resampler: ") + eb; return false; }
                 skw_resampler_init(&st, (double)target / (double)rate, (int)chunk_frames, channels);
                 { long a = rate, b = target; while (b) { long t2 = a % b; a = b; b = t2; } L = (int)(target / a); M = (int)(rate / a); T = 32 * std::max(1, (M + L - 1) / L); }
-                if (polyphase) { pp = skw_polyphase_stream_create(dsp, channels, (int)rate, (int)target); if (!pp) { *err = std::string("Failed to create resampler: ") + skw_dsp_last_error(dsp); return false; } }
+                if (polyphase) { pp = skw_polyphase_stream_create(dsp, channels, (int)rate, (int)target);
+                if (!pp) { *err = std::string("Failed to create resampler: ") + skw_dsp_last_error(dsp); return false; } }
             }
         }
         if (in_rate != rate || in_channels != channels) {

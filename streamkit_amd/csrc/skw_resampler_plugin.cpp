@@ -68,9 +68,13 @@ CPluginHandle create_instance(const char* params, CLogCallback log_cb, void* log
         const double t = num("target_sample_rate", 0), cf = num("chunk_frames", 960), of = num("output_frame_size", 960);
         if (t < 1) return fail("target_sample_rate must be greater than 0");
         if (cf < 1) return fail("chunk_frames must be greater than 0");
-        if (of != 0) { const double okv[] = {120, 240, 480, 960, 1920, 2880}; bool okf = false; for (double x : okv) okf = okf || x == of; if (!okf) return fail("output_frame_size must be 0 (disabled) or a valid Opus frame size: [120, 240, 480, 960, 1920, 2880]"); }
+        if (of != 0) { const double okv[] = {120, 240, 480, 960, 1920, 2880};
+        bool okf = false; for (double x : okv) okf = okf || x == of; if (!okf) return fail("output_frame_size must be 0 (disabled) or a valid Opus frame size: [120, 240, 480, 960, 1920, 2880]");
+        }
         r->core.target = (uint32_t)t; r->core.chunk_frames = (size_t)cf; r->core.out_frame = (size_t)of; r->core.gpu_device = (int)num("gpu_device", 0);
-        { const skw::JsonValue* x = v.get("mode"); if (x) { if (x->type != skw::JsonValue::String || (x->str != "linear" && x->str != "polyphase")) return fail("mode must be \"linear\" or \"polyphase\""); r->core.polyphase = x->str == "polyphase"; } }
+        { const skw::JsonValue* x = v.get("mode"); if (x) { if (x->type != skw::JsonValue::String || (x->str != "linear"
+            && x->str != "polyphase")) return fail("mode must be \"linear\" or \"polyphase\"");
+        r->core.polyphase = x->str == "polyphase"; } }
         return (CPluginHandle)r.release();
     } catch (const std::exception& e) { return fail(std::string("resampler plugin: ") + e.what()); }
     catch (...) { return fail("resampler plugin: unknown C++ exception"); }

@@ -30,7 +30,9 @@ inline void put_utf8(std::string& o, unsigned cp) {
     else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
     else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
 }
-inline bool hex4(P& p, unsigned* out) { if (p.e - p.s < 4) return false; unsigned v = 0; for (int i = 0; i < 4; ++i) { char c = p.s[i]; v <<= 4; if (c >= '0' && c <= '9') v |= c - '0'; else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10; else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10; else return false; } p.s += 4; *out = v; return true; }
+inline bool hex4(P& p, unsigned* out) { if (p.e - p.s < 4) return false; unsigned v = 0; for (int i = 0; i < 4; ++i) { char c = p.s[i];
+v <<= 4; if (c >= '0' && c <= '9') v |= c - '0'; else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10;
+else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10; else return false; } p.s += 4; *out = v; return true; }
 inline bool str(P& p, std::string* out) {
     if (p.s >= p.e || *p.s != '"') return fail(p, "expected string"); ++p.s;
     while (p.s < p.e && *p.s != '"') {
@@ -43,7 +45,9 @@ inline bool str(P& p, std::string* out) {
             case '"': *out += '"'; break; case '\\': *out += '\\'; break; case '/': *out += '/'; break; case 'b': *out += '\b'; break; case 'f': *out += '\f'; break;
             case 'n': *out += '\n'; break; case 'r': *out += '\r'; break; case 't': *out += '\t'; break;
             case 'u': { unsigned cp; if (!hex4(p, &cp)) return fail(p, "invalid unicode escape");
-                if (cp >= 0xD800 && cp < 0xDC00) { unsigned lo; if (p.e - p.s < 6 || p.s[0] != '\\' || p.s[1] != 'u') return fail(p, "lone surrogate"); p.s += 2; if (!hex4(p, &lo) || lo < 0xDC00 || lo > 0xDFFF) return fail(p, "invalid surrogate"); cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); }
+                if (cp >= 0xD800 && cp < 0xDC00) { unsigned lo; if (p.e - p.s < 6 || p.s[0] != '\\' || p.s[1] != 'u') return fail(p, "lone surrogate");
+                p.s += 2; if (!hex4(p, &lo) || lo < 0xDC00 || lo > 0xDFFF) return fail(p, "invalid surrogate");
+                cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); }
                 else if (cp >= 0xDC00 && cp < 0xE000) return fail(p, "lone surrogate");
                 put_utf8(*out, cp); break; }
             default: return fail(p, "invalid escape");
@@ -56,10 +60,12 @@ inline bool value(P& p, JsonValue* v, int depth) {
     ws(p); if (p.s >= p.e) return fail(p, "EOF while parsing a value");
     char c = *p.s;
     if (c == '{') { ++p.s; v->type = JsonValue::Object; ws(p); if (p.s < p.e && *p.s == '}') { ++p.s; return true; }
-        for (;;) { ws(p); std::string k; if (!str(p, &k)) return false; ws(p); if (p.s >= p.e || *p.s != ':') return fail(p, "expected `:`"); ++p.s; JsonValue x; if (!value(p, &x, depth + 1)) return false; v->obj.emplace_back(std::move(k), std::move(x)); ws(p);
+        for (;;) { ws(p); std::string k; if (!str(p, &k)) return false; ws(p); if (p.s >= p.e || *p.s != ':') return fail(p, "expected `:`");
+        ++p.s; JsonValue x; if (!value(p, &x, depth + 1)) return false; v->obj.emplace_back(std::move(k), std::move(x)); ws(p);
             if (p.s < p.e && *p.s == ',') { ++p.s; continue; } if (p.s < p.e && *p.s == '}') { ++p.s; return true; } return fail(p, "expected `,` or `}`"); } }
     if (c == '[') { ++p.s; v->type = JsonValue::Array; ws(p); if (p.s < p.e && *p.s == ']') { ++p.s; return true; }
-        for (;;) { JsonValue x; if (!value(p, &x, depth + 1)) return false; v->arr.push_back(std::move(x)); ws(p); if (p.s < p.e && *p.s == ',') { ++p.s; continue; } if (p.s < p.e && *p.s == ']') { ++p.s; return true; } return fail(p, "expected `,` or `]`"); } }
+        for (;;) { JsonValue x; if (!value(p, &x, depth + 1)) return false; v->arr.push_back(std::move(x)); ws(p); if (p.s < p.e && *p.s == ',') { ++p.s;
+        continue; } if (p.s < p.e && *p.s == ']') { ++p.s; return true; } return fail(p, "expected `,` or `]`"); } }
     if (c == '"') { v->type = JsonValue::String; return str(p, &v->str); }
     if (c == 't' && p.e - p.s >= 4 && !strncmp(p.s, "true", 4)) { p.s += 4; v->type = JsonValue::Bool; v->b = true; return true; }
     if (c == 'f' && p.e - p.s >= 5 && !strncmp(p.s, "false", 5)) { p.s += 5; v->type = JsonValue::Bool; v->b = false; return true; }
@@ -77,7 +83,8 @@ inline bool json_parse(const char* text, JsonValue* out, std::string* err) {
 inline std::string json_quote(const std::string& s) {
     std::string o = "\""; char buf[8];
     for (unsigned char c : s) {
-        switch (c) { case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break; case '\n': o += "\\n"; break; case '\r': o += "\\r"; break; case '\t': o += "\\t"; break;
+        switch (c) { case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
+        case '\n': o += "\\n"; break; case '\r': o += "\\r"; break; case '\t': o += "\\t"; break;
             default: if (c < 0x20) { snprintf(buf, sizeof buf, "\\u%04x", c); o += buf; } else o += (char)c; }
     }
     return o + "\"";
@@ -97,12 +104,18 @@ inline bool utf8_valid(const std::string& s) {
         if ((len == 2 && cp < 0x80) || (len == 3 && cp < 0x800) || (len == 4 && cp < 0x10000) || cp > 0x10FFFF || (cp >= 0xD800 && cp < 0xE000)) return false; i += len; }
     return true;
 }
-inline bool is_ws_cp(unsigned cp) { return (cp >= 9 && cp <= 13) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) || cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000; }
+inline bool is_ws_cp(unsigned cp) { return (cp >= 9 && cp <= 13) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A)
+    || cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
 // str::trim() on valid UTF-8 (White_Space code points)
 inline std::string utf8_trim(const std::string& s) {
     const unsigned char* p = (const unsigned char*)s.data(); size_t n = s.size(), b = 0, e = n;
-    while (b < n) { unsigned char c = p[b]; int len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : 4; unsigned cp = len == 1 ? c : c & (0xFF >> (len + 1)); for (int k = 1; k < len; ++k) cp = (cp << 6) | (p[b + k] & 0x3F); if (!is_ws_cp(cp)) break; b += len; }
-    while (e > b) { size_t st = e - 1; while (st > b && (p[st] & 0xC0) == 0x80) --st; unsigned char c = p[st]; int len = (int)(e - st); unsigned cp = len == 1 ? c : c & (0xFF >> (len + 1)); for (int k = 1; k < len; ++k) cp = (cp << 6) | (p[st + k] & 0x3F); if (!is_ws_cp(cp)) break; e = st; }
+    while (b < n) { unsigned char c = p[b]; int len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : 4;
+    unsigned cp = len == 1 ? c : c & (0xFF >> (len + 1)); for (int k = 1; k < len; ++k) cp = (cp << 6) | (p[b + k] & 0x3F);
+    if (!is_ws_cp(cp)) break; b += len; }
+    while (e > b) { size_t st = e - 1; while (st > b && (p[st] & 0xC0) == 0x80) --st;
+    unsigned char c = p[st]; int len = (int)(e - st); unsigned cp = len == 1 ? c : c & (0xFF >> (len + 1));
+    for (int k = 1; k < len; ++k) cp = (cp << 6) | (p[st + k] & 0x3F); if (!is_ws_cp(cp)) break; e = st; }
     return s.substr(b, e - b);
 }
 
@@ -166,7 +179,8 @@ public:
     bool take_tail(SegmentCut* out) {
         if (speech_buffer_.empty()) return false;
         speech_buffer_.insert(speech_buffer_.end(), frame_buffer_.begin(), frame_buffer_.end()); frame_buffer_.clear();
-        out->samples.swap(speech_buffer_); speech_buffer_.clear(); out->start_time_ms = segment_start_time_ms_; out->end_time_ms = absolute_time_ms_; out->reason = "flush"; out->segment_id = current_segment_id_;
+        out->samples.swap(speech_buffer_); speech_buffer_.clear(); out->start_time_ms = segment_start_time_ms_;
+        out->end_time_ms = absolute_time_ms_; out->reason = "flush"; out->segment_id = current_segment_id_;
         current_segment_id_.clear(); silence_frame_count_ = 0; return true;
     }
     uint64_t absolute_time_ms() const { return absolute_time_ms_; }

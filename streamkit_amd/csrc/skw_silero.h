@@ -65,10 +65,14 @@ inline bool parse_tensor(Buf b, Tensor* t, std::string* err) {
     std::vector<float> fdata; std::vector<uint16_t> hdata; std::vector<double> ddata; Buf raw{nullptr, nullptr}; Field f;
     while (b.p < b.e) {
         if (!next_field(b, &f)) { *err = "corrupt TensorProto"; return false; }
-        if (f.num == 1) { if (f.wt == 2) { Buf s = f.sub; uint64_t v; while (s.p < s.e) { if (!varint(s, &v)) { *err = "corrupt dims"; return false; } t->dims.push_back((int64_t)v); } } else t->dims.push_back((int64_t)f.val); }
+        if (f.num == 1) { if (f.wt == 2) { Buf s = f.sub; uint64_t v; while (s.p < s.e) { if (!varint(s, &v)) { *err = "corrupt dims";
+        return false; } t->dims.push_back((int64_t)v); } } else t->dims.push_back((int64_t)f.val); }
         else if (f.num == 2) t->data_type = (int)f.val;
-        else if (f.num == 4) { if (f.wt == 2) { const size_t n = (f.sub.e - f.sub.p) / 4; const size_t o = fdata.size(); fdata.resize(o + n); memcpy(fdata.data() + o, f.sub.p, n * 4); } else { uint32_t v = (uint32_t)f.val; float x; memcpy(&x, &v, 4); fdata.push_back(x); } }
-        else if (f.num == 5) { if (f.wt == 2) { Buf s = f.sub; uint64_t v; while (s.p < s.e) { if (!varint(s, &v)) { *err = "corrupt int32_data"; return false; } hdata.push_back((uint16_t)v); } } else hdata.push_back((uint16_t)f.val); }
+        else if (f.num == 4) { if (f.wt == 2) { const size_t n = (f.sub.e - f.sub.p) / 4;
+        const size_t o = fdata.size(); fdata.resize(o + n); memcpy(fdata.data() + o, f.sub.p, n * 4);
+        } else { uint32_t v = (uint32_t)f.val; float x; memcpy(&x, &v, 4); fdata.push_back(x); } }
+        else if (f.num == 5) { if (f.wt == 2) { Buf s = f.sub; uint64_t v; while (s.p < s.e) { if (!varint(s, &v)) { *err = "corrupt int32_data";
+        return false; } hdata.push_back((uint16_t)v); } } else hdata.push_back((uint16_t)f.val); }
         else if (f.num == 8 && f.wt == 2) t->name.assign((const char*)f.sub.p, f.sub.e - f.sub.p);
         else if (f.num == 9 && f.wt == 2) raw = f.sub;
         else if (f.num == 10 && f.wt == 2) { const size_t n = (f.sub.e - f.sub.p) / 8; ddata.resize(n); memcpy(ddata.data(), f.sub.p, n * 8); }
@@ -82,9 +86,14 @@ inline bool parse_tensor(Buf b, Tensor* t, std::string* err) {
         n *= (size_t)d;
         if (n > (size_t)(64u << 20)) { *err = "tensor '" + t->name + "': more than 64M elements"; return false; }
     }
-    if (t->data_type == 1) { if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 4) { *err = "tensor '" + t->name + "': raw_data size"; return false; } t->data.resize(n); memcpy(t->data.data(), raw.p, n * 4); } else t->data = fdata; }
-    else if (t->data_type == 10) { t->data.resize(raw.p ? n : hdata.size()); if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 2) { *err = "tensor '" + t->name + "': raw_data size"; return false; } for (size_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, raw.p + 2 * i, 2); t->data[i] = f16_bits_to_f32(h); } } else for (size_t i = 0; i < hdata.size(); ++i) t->data[i] = f16_bits_to_f32(hdata[i]); }
-    else if (t->data_type == 11) { if (raw.p) { ddata.resize(n); if ((size_t)(raw.e - raw.p) != n * 8) { *err = "tensor '" + t->name + "': raw_data size"; return false; } memcpy(ddata.data(), raw.p, n * 8); } t->data.assign(ddata.begin(), ddata.end()); }
+    if (t->data_type == 1) { if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 4) { *err = "tensor '" + t->name + "': raw_data size";
+    return false; } t->data.resize(n); memcpy(t->data.data(), raw.p, n * 4); } else t->data = fdata; }
+    else if (t->data_type == 10) { t->data.resize(raw.p ? n : hdata.size());
+    if (raw.p) { if ((size_t)(raw.e - raw.p) != n * 2) { *err = "tensor '" + t->name + "': raw_data size";
+    return false; } for (size_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, raw.p + 2 * i, 2);
+    t->data[i] = f16_bits_to_f32(h); } } else for (size_t i = 0; i < hdata.size(); ++i) t->data[i] = f16_bits_to_f32(hdata[i]); }
+    else if (t->data_type == 11) { if (raw.p) { ddata.resize(n); if ((size_t)(raw.e - raw.p) != n * 8) { *err = "tensor '" + t->name + "': raw_data size";
+    return false; } memcpy(ddata.data(), raw.p, n * 8); } t->data.assign(ddata.begin(), ddata.end()); }
     // other element types (int64 shapes, bools) carry no weights: kept with empty data
     if (!t->data.empty() && t->data.size() != n) { *err = "tensor '" + t->name + "': element count does not match dims"; return false; }
     return true;
@@ -103,8 +112,11 @@ inline bool parse_node(Buf b, int gid, Model* m, std::string* err, int depth) {
     for (Buf a : attrs) {
         while (a.p < a.e) {
             if (!next_field(a, &f)) { *err = "corrupt AttributeProto"; return false; }
-            if ((f.num == 5 || f.num == 10) && f.wt == 2) { Tensor t; t.graph = gid; t.order = (int)m->tensors.size(); if (!parse_tensor(f.sub, &t, err)) return false; if (t.name.empty()) t.name = out0; m->tensors.push_back(std::move(t)); }
-            else if ((f.num == 6 || f.num == 11) && f.wt == 2) { if (depth > 8) { *err = "sub-graphs nested too deeply"; return false; } const int sub = m->n_graphs++; if (!parse_graph(f.sub, sub, m, err, depth + 1)) return false; }
+            if ((f.num == 5 || f.num == 10) && f.wt == 2) { Tensor t; t.graph = gid;
+            t.order = (int)m->tensors.size(); if (!parse_tensor(f.sub, &t, err)) return false;
+            if (t.name.empty()) t.name = out0; m->tensors.push_back(std::move(t)); }
+            else if ((f.num == 6 || f.num == 11) && f.wt == 2) { if (depth > 8) { *err = "sub-graphs nested too deeply";
+            return false; } const int sub = m->n_graphs++; if (!parse_graph(f.sub, sub, m, err, depth + 1)) return false; }
         }
     }
     return true;
@@ -174,12 +186,14 @@ inline bool silero_bind(const onnx::Model& m, SileroWeights* w, std::string* err
         if (!take({512}, "ih", p0, &w->b_ih, "LSTM bias_ih [512]", nullptr) || !take({512}, "hh", p1, &w->b_hh, "LSTM bias_hh [512]", nullptr)) return false;
     } else {                                          // ONNX LSTM operator: W, R [1, 4H, H] and B [1, 8H], gate order i, o, f, c
         std::vector<float> W, R, Bv; size_t p0 = 0;
-        if (!take({1, 512, 128}, "W", 0, &W, "LSTM W [1,512,128]", &p0) || !take({1, 512, 128}, "R", p0, &R, "LSTM R [1,512,128]", nullptr) || !take({1, 1024}, nullptr, 0, &Bv, "LSTM B [1,1024]", nullptr)) return false;
+        if (!take({1, 512, 128}, "W", 0, &W, "LSTM W [1,512,128]", &p0) || !take({1, 512, 128}, "R", p0, &R, "LSTM R [1,512,128]", nullptr) || !take({1, 1024}, nullptr,
+            0, &Bv, "LSTM B [1,1024]", nullptr)) return false;
         static const int from_iofc[4] = {0, 2, 3, 1};                       // PyTorch block (i, f, g, o) <- ONNX block (i, o, f, c)
         w->w_ih.resize(512 * 128); w->w_hh.resize(512 * 128); w->b_ih.resize(512); w->b_hh.resize(512);
         for (int gt = 0; gt < 4; ++gt) {
             const int src = from_iofc[gt];
-            memcpy(&w->w_ih[(size_t)gt * 128 * 128], &W[(size_t)src * 128 * 128], sizeof(float) * 128 * 128); memcpy(&w->w_hh[(size_t)gt * 128 * 128], &R[(size_t)src * 128 * 128], sizeof(float) * 128 * 128);
+            memcpy(&w->w_ih[(size_t)gt * 128 * 128], &W[(size_t)src * 128 * 128], sizeof(float) * 128 * 128);
+            memcpy(&w->w_hh[(size_t)gt * 128 * 128], &R[(size_t)src * 128 * 128], sizeof(float) * 128 * 128);
             memcpy(&w->b_ih[gt * 128], &Bv[src * 128], sizeof(float) * 128); memcpy(&w->b_hh[gt * 128], &Bv[512 + src * 128], sizeof(float) * 128);
         }
     }
@@ -200,7 +214,8 @@ public:
         while ((n = fread(buf, 1, sizeof buf, f)) > 0) { bytes.insert(bytes.end(), buf, buf + n); if (bytes.size() > (64u << 20)) break; }
         fclose(f);
         onnx::Model m; std::string e;
-        if (bytes.size() > (64u << 20) || !onnx::parse_model(bytes, &m, &e) || !silero_bind(m, w, &e)) { *err = "Failed to load VAD model from '" + path + "': " + (e.empty() ? "file too large" : e); return false; }
+        if (bytes.size() > (64u << 20) || !onnx::parse_model(bytes, &m, &e) || !silero_bind(m, w, &e)) { *err = "Failed to load VAD model from '" + path + "': " + (e.empty() ? "file too large" : e);
+        return false; }
         return true;
     }
     explicit SileroVad(std::shared_ptr<const SileroWeights> w) : w_(std::move(w)) { reset(); }

@@ -40,14 +40,16 @@
 static void set_err(char* err, size_t n, const char* fmt, ...) { if (!err || !n) return; va_list ap; va_start(ap, fmt); vsnprintf(err, n, fmt, ap); va_end(ap); }
 
 // ------------------------------------------------------------------ kernels (activations are [time][channel] f32 rows)
-__global__ void k_tts_embed(const float* emb, const int* ids, int d, float* x) { const int t = blockIdx.x; for (int c = threadIdx.x; c < d; c += blockDim.x) x[(long)t * d + c] = emb[(long)ids[t] * d + c]; }
+__global__ void k_tts_embed(const float* emb, const int* ids, int d, float* x) { const int t = blockIdx.x;
+for (int c = threadIdx.x; c < d; c += blockDim.x) x[(long)t * d + c] = emb[(long)ids[t] * d + c]; }
 
 // out[t][co] = bias[co] + sum_k sum_ci w[k][ci][co] * in[t + k - K/2][ci]   (zero padding; weight pre-transposed on the host so a wave reads it coalesced)
 // pre: 0 none, 1 LeakyReLU(slope) on the input as it is read.  f64 accumulation, ascending (k, ci); one thread per (t, co).
 __global__ __launch_bounds__(256) void k_tts_conv1d(const float* in, int T, int Cin, const float* w, const float* bias, int K, int Cout, float* out, int pre, float slope) {
     const int t = blockIdx.x, pad = K / 2;
     extern __shared__ float sh_in[];                           // [K][Cin] window of the input
-    for (int i = threadIdx.x; i < K * Cin; i += blockDim.x) { const int k = i / Cin, ci = i % Cin, tt = t + k - pad; float v = (tt >= 0 && tt < T) ? in[(long)tt * Cin + ci] : 0.0f; if (pre == 1) v = v > 0.0f ? v : v * slope; sh_in[i] = v; }
+    for (int i = threadIdx.x; i < K * Cin; i += blockDim.x) { const int k = i / Cin, ci = i % Cin, tt = t + k - pad;
+    float v = (tt >= 0 && tt < T) ? in[(long)tt * Cin + ci] : 0.0f; if (pre == 1) v = v > 0.0f ? v : v * slope; sh_in[i] = v; }
     __syncthreads();
     for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
         double acc = 0.0;
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(256) void k_tts_duration(const float* h, int d, con
     if (threadIdx.x == 0) { const float ds = (float)tot; dsum_out[t] = ds; const float r = rintf(ds * scale); dur[t] = r < 1.0f ? 1 : (int)r; }
 }
 // per frame: f0 = 60 + 340 sigmoid(w_f0 . h[tok] + v_f0 . s_pr + b), energy = w_n . h[tok] + b_n
-__global__ __launch_bounds__(256) void k_tts_f0n(const float* h, int d, const int* tok, const float* wf, const float* vf, const float* bf, const float* wn, const float* bn, const float* s_pr, float* f0, float* en) {
+__global__ __launch_bounds__(256) void k_tts_f0n(const float* h, int d, const int* tok, const float* wf, const float* vf, const float* bf, const float* wn,
+    const float* bn, const float* s_pr, float* f0, float* en) {
     __shared__ double sh[4]; const int f = blockIdx.x; const float* hr = h + (long)tok[f] * d;
     double a = 0.0, e = 0.0; for (int c = threadIdx.x; c < d; c += 256) { a += (double)wf[c] * (double)hr[c]; e += (double)wn[c] * (double)hr[c]; }
     double sv = 0.0; for (int j = threadIdx.x; j < TTS_STYLE; j += 256) sv += (double)vf[j] * (double)s_pr[j];
@@ -120,7 +123,8 @@ __global__ void k_tts_adain(const float* z, long n, int C, const float* stats, c
     out[i] = res ? (res[i] + v) * 0.70710678118654752f : v;
 }
 // running phase of the source in cycles at the start of every frame: Phi[f] = frac(sum_{j<f} U * f0[j] / 4800), f64, one lane (F <= 6000)
-__global__ void k_tts_phase_scan(const float* f0, int F, double* phi) { double a = 0.0; for (int f = 0; f < F; ++f) { phi[f] = a; a += (double)TTS_U * (double)f0[f] / (double)TTS_SUBRATE; a -= floor(a); } }
+__global__ void k_tts_phase_scan(const float* f0, int F, double* phi) { double a = 0.0;
+for (int f = 0; f < F; ++f) { phi[f] = a; a += (double)TTS_U * (double)f0[f] / (double)TTS_SUBRATE; a -= floor(a); } }
 // generator input at sub-frame p = f * U + u: g[p][cg] = b[cg] + sum_c wup[u][c][cg] * z[f][c] + sum_h wsrc[h][cg] * har_h(p);
 // har_h = sin(2 pi frac((h + 1) * (Phi[f] + u * f0[f] / 4800))) for (h + 1) * f0[f] < 2400 Hz, else 0   (phase in f64)
 __global__ __launch_bounds__(64) void k_tts_gen_in(const float* z, int C, int G, const float* wup, const float* bup, const float* wsrc, const float* f0, const double* phi, float* g) {
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(64) void k_tts_gen_in(const float* z, int C, int G,
     }
 }
 // snake activation: x + sin^2(alpha_c x) / alpha_c
-__global__ void k_tts_snake(const float* g, long n, int G, const float* alpha, float* out) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const float a = alpha[i % G]; const float s = sinf(a * g[i]); out[i] = g[i] + s * s / a; }
+__global__ void k_tts_snake(const float* g, long n, int G, const float* alpha, float* out) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+if (i >= n) return; const float a = alpha[i % G]; const float s = sinf(a * g[i]); out[i] = g[i] + s * s / a; }
 __global__ void k_tts_add(const float* a, const float* b, long n, float* out) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = a[i] + b[i]; }
 // ISTFTNet head: o[p][0..11) -> magnitude exp, o[p][11..22) -> phase sin; inverse real DFT of each sub-frame (N = 20), periodic Hann window,
 // overlap-add with hop 5 normalised by the summed squared window, centre-trimmed: sample n (0 <= n < 5 (P - 1)) sits at n + 10 of the untrimmed signal.
@@ -174,7 +179,9 @@ struct skw_tts {
     // scratch (grown on demand)
     std::vector<std::pair<void**, size_t>> scratch;
 };
-static float* upload(skw_tts* t, const float* h, size_t n) { float* d = nullptr; if (hipMalloc((void**)&d, std::max<size_t>(1, n) * 4) != hipSuccess) return nullptr; if (n && hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; } t->allocs.push_back(d); return d; }
+static float* upload(skw_tts* t, const float* h, size_t n) { float* d = nullptr;
+if (hipMalloc((void**)&d, std::max<size_t>(1, n) * 4) != hipSuccess) return nullptr;
+if (n && hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; } t->allocs.push_back(d); return d; }
 
 static bool read_file(const char* path, std::vector<uint8_t>* out, size_t limit) {
     FILE* f = fopen(path, "rb"); if (!f) return false; uint8_t buf[65536]; size_t n;
@@ -210,7 +217,8 @@ static void load_lexicon(skw_tts* t, const char* list) {      // "word ph ph ...
             size_t le = s.find('\n', j); if (le == std::string::npos) le = s.size(); std::string line = s.substr(j, le - j); j = le + 1;
             const size_t sp = line.find_first_of(" \t"); if (sp == std::string::npos || sp == 0) continue;
             const std::string word = lower_ascii(line.substr(0, sp)); if (t->lexicon.count(word)) continue;       // first entry wins
-            std::vector<int> ids; for (size_t k = sp; k < line.size();) { const unsigned cp = next_cp(line, &k); if (cp == ' ' || cp == '\t' || cp == '\r') continue; auto it = t->sym2id.find(cp); if (it != t->sym2id.end()) ids.push_back(it->second); }
+            std::vector<int> ids; for (size_t k = sp; k < line.size();) { const unsigned cp = next_cp(line, &k);
+            if (cp == ' ' || cp == '\t' || cp == '\r') continue; auto it = t->sym2id.find(cp); if (it != t->sym2id.end()) ids.push_back(it->second); }
             if (!ids.empty()) t->lexicon[word] = ids;
         }
     }
@@ -258,7 +266,8 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
     if (!cfg || !cfg->model || !cfg->voices || !cfg->tokens) { set_err(err, errlen, "skw_tts_create: model, voices and tokens paths are required"); return nullptr; }
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     if (ndev <= 0) { set_err(err, errlen, "no HIP device available: libskw_tts requires an MI355X (gfx950); there is no CPU fallback"); return nullptr; }
-    if (cfg->gpu_device < 0 || cfg->gpu_device >= ndev || hipSetDevice(cfg->gpu_device) != hipSuccess) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", cfg->gpu_device, ndev); return nullptr; }
+    if (cfg->gpu_device < 0 || cfg->gpu_device >= ndev || hipSetDevice(cfg->gpu_device) != hipSuccess) { set_err(err, errlen, "gpu_device %d out of range (%d devices)", cfg->gpu_device, ndev);
+    return nullptr; }
     skw_tts* t = new skw_tts(); t->device = cfg->gpu_device; t->length_scale = cfg->length_scale > 0.0f ? cfg->length_scale : 1.0f;
     auto fail = [&](const std::string& m) -> skw_tts* { set_err(err, errlen, "%s", m.c_str()); skw_tts_destroy(t); return nullptr; };
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream creation failed");
@@ -268,7 +277,8 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
     std::vector<uint8_t> bytes; if (!read_file(cfg->model, &bytes, 1024u << 20)) return fail(std::string("cannot read model file ") + cfg->model);
     skw::onnx::Model m; if (!skw::onnx::parse_model(bytes, &m, &e)) return fail(std::string("model file ") + cfg->model + ": " + e);
     const skw::onnx::Tensor* emb = find_t(m, "text_encoder.embedding.weight");
-    if (!emb || emb->dims.size() != 2) return fail("model file: no text_encoder.embedding.weight [n_sym, d] (this build reads its own reduced Kokoro-shaped network, DESIGN.md section 7; a Kokoro-82M export is not supported yet)");
+    if (!emb || emb->dims.size() != 2) return fail("model file: no text_encoder.embedding.weight [n_sym, d] (this build reads its own reduced Kokoro-shaped network, DESIGN.md section 7; "
+                                                       "a Kokoro-82M export is not supported yet)");
     t->n_sym = (int)emb->dims[0]; t->d = (int)emb->dims[1];
     if (t->d < 16 || t->d > 1024 || t->n_sym < 2) return fail("model file: implausible embedding shape");
     for (auto& kv : t->sym2id) if (kv.second < 0 || kv.second >= t->n_sym) return fail("tokens file names an id outside the embedding table");
@@ -286,10 +296,12 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
     const skw::onnx::Tensor* de = find_t(m, "decoder.encode.weight"); if (ok && (!de || de->dims.size() != 3)) { ok = false; e = "missing tensor 'decoder.encode.weight'"; }
     if (ok) t->C = (int)de->dims[0];
     const int C = t->C;
-    ok = ok && want(t, m, "decoder.encode.weight", {C, d + 2, 3}, &e, true) && want(t, m, "decoder.encode.bias", {C}, &e) && want(t, m, "decoder.encode.fc.weight", {2 * C, TTS_STYLE}, &e) && want(t, m, "decoder.encode.fc.bias", {2 * C}, &e);
+    ok = ok && want(t, m, "decoder.encode.weight", {C, d + 2, 3}, &e, true) && want(t, m, "decoder.encode.bias", {C}, &e) && want(t, m, "decoder.encode.fc.weight",
+        {2 * C, TTS_STYLE}, &e) && want(t, m, "decoder.encode.fc.bias", {2 * C}, &e);
     while (ok && find_t(m, "decoder.decode." + std::to_string(t->n_dec) + ".weight")) {
         const std::string p = "decoder.decode." + std::to_string(t->n_dec) + ".";
-        ok = want(t, m, p + "weight", {C, C, 3}, &e, true) && want(t, m, p + "bias", {C}, &e) && want(t, m, p + "fc.weight", {2 * C, TTS_STYLE}, &e) && want(t, m, p + "fc.bias", {2 * C}, &e); t->n_dec++;
+        ok = want(t, m, p + "weight", {C, C, 3}, &e, true) && want(t, m, p + "bias", {C}, &e) && want(t, m, p + "fc.weight", {2 * C, TTS_STYLE}, &e) && want(t, m, p + "fc.bias", {2 * C}, &e);
+        t->n_dec++;
     }
     const skw::onnx::Tensor* up = find_t(m, "decoder.generator.ups.weight"); if (ok && (!up || up->dims.size() != 3)) { ok = false; e = "missing tensor 'decoder.generator.ups.weight'"; }
     if (ok) t->G = (int)up->dims[1];
@@ -312,7 +324,8 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
 extern "C" skw_tts* skw_tts_create(const skw_tts_config* cfg, char* err, size_t errlen) {
     try { return create_impl(cfg, err, errlen); } catch (const std::exception& e) { set_err(err, errlen, "skw_tts_create: %s", e.what()); return nullptr; }
 }
-extern "C" void skw_tts_destroy(skw_tts* t) { if (!t) return; hipSetDevice(t->device); if (t->stream) { hipStreamSynchronize(t->stream); hipStreamDestroy(t->stream); } for (void* p : t->allocs) hipFree(p); delete t; }
+extern "C" void skw_tts_destroy(skw_tts* t) { if (!t) return; hipSetDevice(t->device); if (t->stream) { hipStreamSynchronize(t->stream);
+hipStreamDestroy(t->stream); } for (void* p : t->allocs) hipFree(p); delete t; }
 extern "C" const char* skw_tts_last_error(const skw_tts* t) { return t->errbuf; }
 extern "C" int32_t skw_tts_num_speakers(const skw_tts* t) { return t->n_spk; }
 extern "C" int32_t skw_tts_sample_rate(const skw_tts*) { return TTS_RATE; }
@@ -321,10 +334,13 @@ extern "C" int32_t skw_tts_tokenize(skw_tts* t, const char* text, int32_t* ids, 
     try { std::vector<int> v = tokenize(t, text ? text : ""); const int n = std::min((int)v.size(), (int)cap); for (int i = 0; i < n; ++i) ids[i] = v[i]; return n; } catch (...) { return -1; }
 }
 extern "C" long skw_tts_debug_get(skw_tts* t, int what, float* out, long cap) {
-    if (what < 0 || what > 4) return -1; std::lock_guard<std::mutex> l(t->mu); const auto& v = t->dbg[what]; if (out) memcpy(out, v.data(), sizeof(float) * std::min<long>(cap, (long)v.size())); return (long)v.size();
+    if (what < 0 || what > 4) return -1; std::lock_guard<std::mutex> l(t->mu);
+    const auto& v = t->dbg[what]; if (out) memcpy(out, v.data(), sizeof(float) * std::min<long>(cap, (long)v.size())); return (long)v.size();
 }
 
-struct Scratch { std::vector<void*> p; ~Scratch() { for (void* q : p) hipFree(q); } template <typename T> T* get(size_t n) { T* d = nullptr; if (hipMalloc((void**)&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(d); return d; } };
+struct Scratch { std::vector<void*> p; ~Scratch() { for (void* q : p) hipFree(q);
+} template <typename T> T* get(size_t n) { T* d = nullptr; if (hipMalloc((void**)&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
+p.push_back(d); return d; } };
 #define TCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(t->errbuf, 512, "HIP error '%s' at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); return nullptr; } } while (0)
 #define TNULL(p) do { if (!(p)) { snprintf(t->errbuf, 512, "device allocation failed at %s:%d", __FILE__, __LINE__); return nullptr; } } while (0)
 
@@ -355,16 +371,20 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
     hipLaunchKernelGGL(k_tts_ln, dim3(T), dim3(256), 0, s, x, d, nullptr, nullptr, ada, 1, h);
     hipLaunchKernelGGL(k_tts_duration, dim3(T), dim3(256), 0, s, h, d, W("predictor.duration_proj.weight"), W("predictor.duration_proj.bias"), K, t->length_scale / speed, d_dur, d_dsum);
     std::vector<int> dur(T); std::vector<float> dsum(T);
-    TCHK(hipMemcpyAsync(dur.data(), d_dur, sizeof(int) * T, hipMemcpyDeviceToHost, s)); TCHK(hipMemcpyAsync(dsum.data(), d_dsum, sizeof(float) * T, hipMemcpyDeviceToHost, s)); TCHK(hipStreamSynchronize(s));
+    TCHK(hipMemcpyAsync(dur.data(), d_dur, sizeof(int) * T, hipMemcpyDeviceToHost, s));
+    TCHK(hipMemcpyAsync(dsum.data(), d_dsum, sizeof(float) * T, hipMemcpyDeviceToHost, s)); TCHK(hipStreamSynchronize(s));
     // length regulation on the host (T <= 510 integers): frame f belongs to token tok[f]
     std::vector<int> tok; for (int i = 0; i < T; ++i) for (int k = 0; k < dur[i] && (int)tok.size() < TTS_MAX_FRAMES; ++k) tok.push_back(i);
     const int F = (int)tok.size(); const long P = (long)F * TTS_U; const long n_out = TTS_HOP * (P - 1);
     int* d_tok = sc.get<int>(F); float* f0 = sc.get<float>(F); float* en = sc.get<float>(F); float* u = sc.get<float>((size_t)F * (d + 2));
-    float* z = sc.get<float>((size_t)F * C); float* r = sc.get<float>((size_t)F * C); float* z2 = sc.get<float>((size_t)F * C); float* stats = sc.get<float>(2 * (size_t)C); double* phi = sc.get<double>(F);
-    float* g = sc.get<float>((size_t)P * G); float* g1 = sc.get<float>((size_t)P * G); float* g2 = sc.get<float>((size_t)P * G); float* o = sc.get<float>((size_t)P * 2 * TTS_BINS); float* yv = sc.get<float>((size_t)n_out);
+    float* z = sc.get<float>((size_t)F * C); float* r = sc.get<float>((size_t)F * C);
+    float* z2 = sc.get<float>((size_t)F * C); float* stats = sc.get<float>(2 * (size_t)C); double* phi = sc.get<double>(F);
+    float* g = sc.get<float>((size_t)P * G); float* g1 = sc.get<float>((size_t)P * G);
+    float* g2 = sc.get<float>((size_t)P * G); float* o = sc.get<float>((size_t)P * 2 * TTS_BINS); float* yv = sc.get<float>((size_t)n_out);
     TNULL(d_tok && f0 && en && u && z && r && z2 && stats && phi && g && g1 && g2 && o && yv);
     TCHK(hipMemcpyAsync(d_tok, tok.data(), sizeof(int) * F, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_tts_f0n, dim3(F), dim3(256), 0, s, h, d, d_tok, W("predictor.F0_proj.weight"), W("predictor.F0_proj.style"), W("predictor.F0_proj.bias"), W("predictor.N_proj.weight"), W("predictor.N_proj.bias"), s_pr, f0, en);
+    hipLaunchKernelGGL(k_tts_f0n, dim3(F), dim3(256), 0, s, h, d, d_tok, W("predictor.F0_proj.weight"), W("predictor.F0_proj.style"), W("predictor.F0_proj.bias"),
+        W("predictor.N_proj.weight"), W("predictor.N_proj.bias"), s_pr, f0, en);
     hipLaunchKernelGGL(k_tts_dec_in, dim3(F), dim3(128), 0, s, x, d, d_tok, f0, en, u);
     hipLaunchKernelGGL(k_tts_conv1d, dim3(F), dim3(256), sizeof(float) * 3 * (d + 2), s, u, F, d + 2, W("decoder.encode.weight"), W("decoder.encode.bias"), 3, C, r, 0, 0.0f);
     const long nz = (long)F * C;
@@ -383,13 +403,16 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
     hipLaunchKernelGGL(k_tts_gen_in, dim3((unsigned)P), dim3(64), 0, s, z, C, G, W("decoder.generator.ups.weight"), W("decoder.generator.ups.bias"), W("decoder.generator.source.weight"), f0, phi, g);
     const long ng = P * G;
     hipLaunchKernelGGL(k_tts_snake, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, g, ng, G, W("decoder.generator.resblock.alpha"), g1);
-    hipLaunchKernelGGL(k_tts_conv1d, dim3((unsigned)P), dim3(64), sizeof(float) * 3 * G, s, g1, (int)P, G, W("decoder.generator.resblock.weight"), W("decoder.generator.resblock.bias"), 3, G, g2, 0, 0.0f);
+    hipLaunchKernelGGL(k_tts_conv1d, dim3((unsigned)P), dim3(64), sizeof(float) * 3 * G, s, g1, (int)P, G, W("decoder.generator.resblock.weight"),
+        W("decoder.generator.resblock.bias"), 3, G, g2, 0, 0.0f);
     hipLaunchKernelGGL(k_tts_add, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, g, g2, ng, g1);
-    hipLaunchKernelGGL(k_tts_conv1d, dim3((unsigned)P), dim3(64), sizeof(float) * 7 * G, s, g1, (int)P, G, W("decoder.generator.conv_post.weight"), W("decoder.generator.conv_post.bias"), 7, 2 * TTS_BINS, o, 1, 0.01f);
+    hipLaunchKernelGGL(k_tts_conv1d, dim3((unsigned)P), dim3(64), sizeof(float) * 7 * G, s, g1, (int)P, G, W("decoder.generator.conv_post.weight"),
+        W("decoder.generator.conv_post.bias"), 7, 2 * TTS_BINS, o, 1, 0.01f);
     hipLaunchKernelGGL(k_tts_istft, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, o, (int)P, yv, n_out);
     TCHK(hipEventRecord(e1, s));
     float* host = (float*)malloc(sizeof(float) * (size_t)std::max<long>(1, n_out)); if (!host) { snprintf(t->errbuf, 512, "out of memory"); return nullptr; }
-    if (hipMemcpyAsync(host, yv, sizeof(float) * (size_t)n_out, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { free(host); snprintf(t->errbuf, 512, "synthesis kernels failed"); return nullptr; }
+    if (hipMemcpyAsync(host, yv, sizeof(float) * (size_t)n_out, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { free(host);
+    snprintf(t->errbuf, 512, "synthesis kernels failed"); return nullptr; }
     hipEventElapsedTime(&t->last_ms, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
     {   // stage taps for the parity tests (small: a sentence)
         t->dbg[0].assign(dur.begin(), dur.end());

@@ -7,7 +7,8 @@ struct skw_vad { std::shared_ptr<const skw::SileroWeights> w; skw::SileroVad v; 
 extern "C" skw_vad* skw_vad_create(const char* path, char* err, size_t errlen) {
     try {
         auto w = std::make_shared<skw::SileroWeights>(); std::string e;
-        if (!path || !skw::SileroVad::load_weights(path, w.get(), &e)) { if (err && errlen) snprintf(err, errlen, "%s", path ? e.c_str() : "Failed to load VAD model from '': no path"); return nullptr; }
+        if (!path || !skw::SileroVad::load_weights(path, w.get(), &e)) { if (err && errlen) snprintf(err, errlen, "%s", path ? e.c_str() : "Failed to load VAD model from '': no path");
+        return nullptr; }
         return new skw_vad(w);
     } catch (const std::exception& ex) { if (err && errlen) snprintf(err, errlen, "Failed to load VAD model from '%s': %s", path ? path : "", ex.what()); return nullptr; }
 }
