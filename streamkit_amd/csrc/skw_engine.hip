@@ -1223,9 +1223,18 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         const int n_groups = c->n_groups > 0 ? c->n_groups : 1;   // one row group in both precisions (exact: 194 ms against 213 with two, since the segmented decode GEMMs; f16_mfma: 178 against 204)
         // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
         const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;
-        const int G = std::max(1, std::min(n_groups, Bw / 8));      // (also while profiling: the event pairs then time the launch shapes the timed run uses)
+        // Groups are cut at multiples of 16 rows: the f16_mfma step keeps its attention / FC1 outputs as fragment-order images (skw_afrag_off), which
+        // scatter a group's rows over whole 16-row tiles of its scratch — two groups sharing a tile would overwrite each other.
         int g_r0[skw_ctx::MAX_GROUPS], g_n[skw_ctx::MAX_GROUPS]; bool g_live[skw_ctx::MAX_GROUPS];
-        for (int g = 0; g < G; ++g) { g_r0[g] = (int)((long)Bw * g / G); g_n[g] = (int)((long)Bw * (g + 1) / G) - g_r0[g]; g_live[g] = true; }
+        int G = 0;
+        {
+            const int Gw = std::max(1, std::min(n_groups, Bw / 8));
+            int prev = 0;
+            for (int g = 1; g <= Gw; ++g) {
+                const int cut = g == Gw ? Bw : std::min(Bw, (int)(((long)Bw * g / Gw + 8) & ~15L));
+                if (cut > prev) { g_r0[G] = prev; g_n[G] = cut - prev; g_live[G] = true; ++G; prev = cut; }
+            }
+        }
         for (int j = 0; j < Bw; ++j) c->h_row_live[j] = 1;      // (every kernel of the previous window has drained: c->stream was synchronised at its end)
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
