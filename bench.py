@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-plugin-path", action="store_true", help="skip the SURVEY 8(d) config-2 leg through libwhisper.so (N plugin instances fed 960-sample packets)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     return ap.parse_args()
@@ -75,6 +76,43 @@ def launch_ranks(args):
         return 1
     print(line[-1], flush=True)
     return 0
+
+
+def plugin_path_leg(args, model_path, host_pcm, B, reps=3):
+    """SURVEY.md 8(d) config 2 as written: B concurrent plugin instances (libwhisper.so through the StreamKit native ABI v2, driven by the C++ mini-host that
+    replays wrapper.rs's call sequence), each fed its 30 s clip from host memory in 960-sample RawAudio packets and flushed; wall clock from the first packet
+    to the last Transcription packet.  Includes packet feeding, the 512-sample VAD framing (vad_mode: always), batch formation across instances, H2D copies,
+    JSON building.  Model load is excluded the way the reference excludes it: the process-global context cache (a throw-away first round warms it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import minihost
+    plug = minihost.Plugin()
+    pcms = [host_pcm[i] for i in range(B)]
+    params = {"model_path": model_path, "vad_mode": "always", "flush_tail": True, "max_batch": B, "batch_window_ms": 40, "precision": args.precision, "suppress_non_speech_tokens": True}
+    best, n_seg, log0 = None, 0, ""
+    for rep in range(reps + 1):
+        nodes = [plug.create_node(params) for _ in range(B)]
+        if rep == 0:
+            log0 = " | ".join(l for l in nodes[0].logs() if "CACHE" in l or "loaded and cached" in l)
+        ms = minihost.run_oneshot(nodes, pcms, 960)
+        outs = [n.outputs() for n in nodes]
+        okp = all(len(o) == 1 and o[0][1] == 3 for o in outs)
+        for n in nodes:
+            n.destroy()
+        if not okp:
+            return {"value_plugin_path": None, "plugin_path": {"error": "an instance did not emit exactly one Transcription packet: %s" % [len(o) for o in outs]}}
+        n_seg = sum(len(json.loads(o[0][2].decode())["segments"]) for o in outs)
+        if rep > 0:
+            best = ms if best is None else min(best, ms)
+    L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libwhisper.so"))
+    loads, hits = C.c_int(), C.c_int()
+    L.skw_whisper_plugin_cache_stats(C.byref(loads), C.byref(hits))
+    audio_s = sum(p.size for p in pcms) / 16000.0
+    return {"value_plugin_path": round(audio_s / (best * 1e-3), 1),
+            "plugin_path": {"what": "%d libwhisper.so instances (native plugin ABI v2, mini-host), each fed one 30 s clip as 960-sample packets from host memory, then flushed: "
+                                    "first packet in -> last Transcription JSON out; best of %d rounds" % (B, reps),
+                            "wall_ms": round(best, 2), "instances": B, "packet_samples": 960, "batch_window_ms": 40, "vad_mode": "always", "precision": args.precision,
+                            "segments": n_seg, "model_loads_in_process": loads.value, "context_cache_hits": hits.value, "first_create_log": log0}}
 
 
 def main():
@@ -127,11 +165,16 @@ def main():
         dist.barrier()          # every rank of this node sees rank 0's file from here on (one node: the driver's launch shape)
     if not os.path.exists(path):
         raise SystemExit("rank %d: model file %s was not written" % (rank, path))
-    model = engine.Model(path, device=local_rank)
+    t_load = time.perf_counter()
+    model = engine.Model(path, device=local_rank)          # GGML file -> HBM: weights, kperm / natural-k copies, fragment-order images (outside the timed region, as the
+    torch.cuda.synchronize()                               # reference excludes it through its context cache / prewarm: lib.rs:330-374, plugins.rs:265-306)
+    model_load_ms = 1000.0 * (time.perf_counter() - t_load)
     hp = model.hp
     B = args.clips
     n_samples = 480000
+    t_ctx = time.perf_counter()
     ctx = engine.Context(model, max_batch=B, max_samples=n_samples)
+    ctx_create_ms = 1000.0 * (time.perf_counter() - t_ctx)
     params = ctx.default_params()
     params.suppress_nst = 1   # the reference node's default (lib.rs:634, suppress_non_speech_tokens = true)
 
@@ -216,13 +259,18 @@ def main():
     parity = None
     if not args.no_other_mode:
         from streamkit_amd.parity import teacher_forced_compare
-        tf = teacher_forced_compare(ctx, None, params, device_ptrs=ptrs, n_samples=ns)
-        parity = {k: tf[k] for k in ("steps_checked", "sampled_steps", "sampled_draws_that_differ", "argmax_disagreements", "disagreements_on_exact_runner_up", "max_margin_at_disagreement", "max_logit_err", "logit_err_bound", "margin_bound", "ok")}
-        parity["clips_checked"] = len(tf["per_clip"])
-        parity["what"] = ("f16_mfma fed the exact precision's tokens: each of its greedy decisions, on every clip and step of this batch, equals the exact one "
-                          "or sits where the exact top1 - top2 logit margin is below margin_bound; deciding logits agree within logit_err_bound")
-        if identical is not None:
-            parity["free_running_identical_clips"] = identical["identical_clips"]; parity["of"] = identical["of"]
+        try:
+            tf = teacher_forced_compare(ctx, None, params, device_ptrs=ptrs, n_samples=ns)
+            parity = {k: tf[k] for k in ("steps_checked", "sampled_steps", "sampled_draws_that_differ", "argmax_disagreements", "disagreements_on_exact_runner_up", "max_margin_at_disagreement", "max_logit_err", "logit_err_bound", "margin_bound", "ok")}
+            parity["clips_checked"] = len(tf["per_clip"])
+            parity["what"] = ("f16_mfma fed the exact precision's tokens: each of its greedy decisions, on every clip and step of this batch, equals the exact one "
+                              "or sits where the exact top1 - top2 logit margin is below margin_bound; deciding logits agree within logit_err_bound")
+            if identical is not None:
+                parity["free_running_identical_clips"] = identical["identical_clips"]; parity["of"] = identical["of"]
+        except (AssertionError, RuntimeError) as e:
+            # the two precisions' CONTROL FLOW diverged under forcing (a fallback or an EOT decision on a near-tie): the instrument could not run to the end.
+            # The metric line is still printed, carrying the failure, and the process exits non-zero after it.
+            parity = {"ok": False, "error": "%s: %s" % (type(e).__name__, e), "max_margin_at_disagreement": None, "max_logit_err": None}
         ctx.set_precision(args.precision)
 
     fast = args.precision == "f16_mfma"
@@ -235,7 +283,9 @@ def main():
                                "random-init weights in GGML f16 container" % (args.size, B),
                    "precision": args.precision + (": f16 operands on v_mfma_f32_16x16x32_f16, f32 accumulate" if fast else ": f16 operands widened to f32, k-ordered chains on v_mfma_f32_16x16x4_f32"),
                    "clips_per_gpu": B, "sharding": "clip c -> rank c mod N; one RCCL all_gather of int32 [%d x 226] token buffers" % B,
-                   "vad": "none (engine-level full(); the plugin path is measured by tools/bench_plugin.py)",
+                   "vad": "none (engine-level full(); the plugin path, 64 libwhisper.so instances fed 960-sample packets, is value_plugin_path)",
+                   "identical_clips_f16_vs_exact": ("%d/%d" % (identical["identical_clips"], identical["of"])) if identical else None,
+                   "model_load_ms": round(model_load_ms, 1), "ctx_create_ms": round(ctx_create_ms, 1),
                    "last_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timing.items()},
                    "fallback_requested": int(sum(r["fallback_requested"] for r in res))},
         "modes": modes,
@@ -243,6 +293,7 @@ def main():
         "parity_f16_vs_exact_teacher_forced": parity,
         "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
         "value_pcie_inclusive": round(pcie_value, 2),
+        "model_load_ms": round(model_load_ms, 1), "ctx_create_ms": round(ctx_create_ms, 1),
     }
 
     if rank == 0 and not args.no_roofline:
@@ -322,6 +373,9 @@ def main():
         roof["profiled_step_ms"] = {"encode": round(tprof["encode_ms"], 2), "decode": round(tprof["decode_ms"], 2),
                                     "note": "the step the per-kernel event pairs were taken in (eager launches, an event pair per kernel): its wall time is not the benchmark's"}
         out["roofline"] = roof
+
+    if rank == 0 and world == 1 and not args.no_plugin_path:
+        out.update(plugin_path_leg(args, path, host, B))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (a port) on the host cores, bounded sample of the same workload
