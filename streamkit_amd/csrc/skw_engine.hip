@@ -348,6 +348,7 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
                     }
                 };
                 mk(L.qkv, 0); mk(L.o, 0); mk(L.cq, 0); mk(L.co, 0); mk(L.fc1, 1); mk(L.fc2, 0);
+                mk(L.ck, 0); mk(L.cv, 0);      // the encoder pass's cross K / V^T products (k_gemm16w streams its weights from these images)
             }
             if (ok && m->quant) {   // the same concatenation in the integer form
                 HostQ hq, hk, hv, all; host_q(*find_t(ts, p + "attn.query.weight"), &hq); host_q(*find_t(ts, p + "attn.key.weight"), &hk); host_q(*find_t(ts, p + "attn.value.weight"), &hv);
@@ -357,6 +358,29 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
                 ok = up_q(m, all, m->quant, &L.qkv);
             }
         }
+    }
+    // Encoder weights as fragment-order images too (k_gemm16w, the f16_mfma precision's big GEMM: weights go from these straight into MFMA operands).  Rows in the
+    // order of the epilogue that consumes the product: the kperm'ed-output epilogues (Q / K heads, FC1 and conv1 GELU) want strip row p = logical feature kperm^-1(p).
+    if (ok && !(getenv("SKW_ENC_WFRAG") && atoi(getenv("SKW_ENC_WFRAG")) == 0)) {
+        auto mke = [&](DevLin& X, int perm) {
+            if ((X.n_out & 15) || (X.k_pad & 63) || !X.w) return;
+            half_t* img = nullptr;
+            if (hipMalloc((void**)&img, (size_t)X.n_out * X.k_pad * 2) != hipSuccess) return;      // (no image: k_gemm16 stages the rows through LDS)
+            m->allocs.push_back(img);
+            skw_make_wfrag(X.w, X.k_pad, X.n_out, X.k_pad, perm, img, nullptr);
+            X.w_frag = img;
+        };
+        mke(m->conv1, 1);
+        mke(m->conv2, 0);
+        for (EncLayer& L : m->enc) {
+            mke(L.q, 1);
+            mke(L.k, 1);
+            mke(L.v, 0);
+            mke(L.o, 0);
+            mke(L.fc1, 1);
+            mke(L.fc2, 0);
+        }
+        if (hipDeviceSynchronize() != hipSuccess) ok = false;
     }
     if (!ok) return fail2();
     if ((m->hp.n_audio_state / m->hp.n_audio_head) != 64 || (m->hp.n_text_state / m->hp.n_text_head) != 64 || m->hp.n_audio_state % 64 || m->hp.n_audio_state > 1536) {
@@ -786,7 +810,7 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
             SkwGemmArgs a{}; a.A = L.v.w; a.lda = L.v.k_pad; a.W = c->y16; a.ldw = d; a.M = L.v.n_out; a.N = M; a.K = L.v.k_pad; a.C = c->Vt;
             a.bias = L.v.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = H; a.Tpad = c->Tpad; a.scale = 1.0f;
             // the f16 kernel takes V^T in the natural orientation (tokens x features)
-            if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.v.w; a.ldw = L.v.k_pad; a.M = M; a.N = L.v.n_out; }
+            if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.v.w; a.Wf = L.v.w_frag; a.ldw = L.v.k_pad; a.M = M; a.N = L.v.n_out; }
             GEMM(c, a, d);
         }
         if (l == 0) { tap(c, "l0.q", c->Qh, nc, d, TAP_HEADS); tap(c, "l0.k", c->Kh, nc, d, TAP_HEADS); tap(c, "l0.v", c->Vt, nc, d, TAP_VT); }
@@ -821,7 +845,7 @@ static void run_encoder(skw_ctx* c, int Bw_all, bool want_f32_out, bool cross, i
             { // cross V^T through the operand-swapped product (rows = features, columns = tokens), as for the encoder's V
                 SkwGemmArgs a{}; a.A = L.cv.w; a.lda = L.cv.k_pad; a.W = c->y16; a.ldw = d; a.M = L.cv.n_out; a.N = M; a.K = L.cv.k_pad; a.C = cv;
                 a.bias = L.cv.b; a.epi = EPI_VT_F16; a.n_ctx = nc; a.H = hp.n_text_head; a.Tpad = c->Tpad; a.scale = 1.0f;
-                if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; a.frag = c->kv_frag(); }
+                if (c->precision == SKW_PRECISION_F16_MFMA) { a.A = c->y16; a.lda = d; a.W = L.cv.w; a.ldw = L.cv.k_pad; a.M = M; a.N = L.cv.n_out; a.Wf = L.cv.w_frag; a.frag = c->kv_frag(); }
                 GEMM(c, a, d);
             }
         }
@@ -1565,6 +1589,12 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     if (small && (probe & 32) && !(N & 15)) { HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2 * wcycle));
     for (int w = 0; w < wcycle; ++w) skw_make_wfrag(W + (size_t)w * N * K, K, N, K, epi == EPI_GELU_F16_KPERM, Wfrag + (size_t)w * N * K, c->stream);
     a.Wf = Wfrag; a.probe &= ~32; }
+    // probe bit 9 (big shapes): the weights also as a fragment-order image and no measurement hooks — the launch takes k_gemm16w, as the encoder's do
+    if (!small && (probe & 512) && !(N & 15)) {
+        HIPCHK(hipMalloc((void**)&Wfrag, (size_t)N * K * 2));
+        skw_make_wfrag(W, K, N, K, epi == EPI_GELU_F16_KPERM || epi == EPI_HEADS_F16, Wfrag, c->stream);
+        a.Wf = Wfrag; a.probe = probe & ~1023;
+    }
     for (int i = 0; i < 3; ++i) { if (small) skw_gemm16_small(a, c->stream); else skw_gemm16(a, c->stream); }
     HIPCHK(hipEventRecord(e0, c->stream));
     // (a launch that also touched the NEXT launch's copy of W — LDS-DMA into a scratch slab, so the bytes sit in the Infinity Cache when wanted — measured no gain:

@@ -344,6 +344,240 @@ static int skw_cu_count() {
     if (!v) { hipDeviceProp_t p; v = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; n[dev].store(v, std::memory_order_relaxed); }
     return v;
 }
+// ------------------------------------------------------------------ big-M GEMM, f16 MFMA, weights from a fragment-order image: k_gemm16w
+// Round 4.  k_gemm16's 256 x 256 tile keeps one 8-wave workgroup per CU, all of whose waves are in the same phase: its epilogue (HBM-bound for the f32
+// residual outputs, VALU-bound for FC1's GELU) runs with the matrix cores idle — 60 of a Q-shape launch's 174 us.  This form is built so that TWO
+// independent workgroups share a CU (4 waves each, 2 waves per SIMD as before): one's epilogue, barriers and staging run under the other's MFMAs.
+//   tile 128 (tokens) x 256 (features); a wave owns 128 x 64 (32 MFMA tiles, 128 accumulator registers), the four waves side by side along the features;
+//   tokens (A) go through LDS as in k_gemm16 — LDS-DMA pieces of 8 rows x 128 B, XOR swizzle on the source address — in a ring of three 16-KiB K-step
+//   slots, one barrier per K step, the DMA of step k + 2 issued after the barrier of step k (it overwrites the slot every wave read in step k - 1);
+//   weights never touch LDS: a wave's four 16-feature strips come straight from the weight's FRAGMENT-ORDER image (skw_make_wfrag: per strip and 32-k
+//   block one contiguous KiB in MFMA lane order — the decode kernels' format) into registers, one 32-k block ahead of the MFMAs that consume them.
+//   A wave's weight columns are its own, so nothing is loaded twice within a workgroup; the weight matrix (1.2 - 4.7 MB) is L2-resident.
+// 64 KiB of LDS per workgroup: the ring (48 KiB; its first 32 KiB are the epilogue's staging area once the K loop is over), the tile's bias values.
+// Epilogues, layouts and per-element arithmetic are k_gemm16's (the same helpers); the summation order inside an MFMA is the hardware's either way.
+// workgroup barrier for LDS hand-overs only: every LDS operation of this wave has completed, but global stores (and loads) stay in flight across it —
+// __syncthreads() is a fence too, and hipcc drains vmcnt(0) for it: every epilogue pass then waited for its own stores to reach memory
+#define SKW_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int EPI, bool PROBE = false>      // PROBE: measurement hooks (tools/gemm16w_probe.py; a.probe bit 10 no epilogue, bit 12 no MFMAs, bit 13 no weight loads, bit 14 no A staging)
+__global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
+    constexpr int BM = 128, BN = 256, NW = 4, WTN = 64, TMT = BM / 16, TNT = WTN / 16, SLOT = BM * 128, NSLOT = 3, PARK = 32768;
+    constexpr bool X_IS_M = Epi16<EPI>::X_IS_M, PERM = Epi16<EPI>::PERM;
+    constexpr int TX = X_IS_M ? TMT : TNT, TY = X_IS_M ? TNT : TMT;
+    constexpr int A_PIECES = BM / 8 / NW;                                                   // 1-KiB pieces per wave per K step
+    __shared__ __attribute__((aligned(1024))) char lds[65536];                              // ring 3 x 16 KiB (its first 32 KiB double as the waves' epilogue staging) | every feature's bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Mv = X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
+    const int nbn = (a.N + BN - 1) / BN, nbm = (Mv + BM - 1) / BM, nblk = nbn * nbm;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+    const int nk = a.K >> 6, nk32 = a.K >> 5, nstrip = a.N >> 4;
+    const half_t* gA[A_PIECES];
+    unsigned woff[TNT];                                                                     // byte offset of this lane's 16 bytes in k-block 0 of each of the wave's strips
+    auto tile_origin = [&](int tile, int& m0, int& n0) {
+        int q = nblk >> 3, r = nblk & 7, x = tile & 7, y = tile >> 3;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        m0 = (bid / nbn) * BM; n0 = (bid % nbn) * BN;
+    };
+    auto tile_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            int c = (wave * A_PIECES + i) * 8 + prow; if (X_IS_M && PERM) c = (c & ~31) | inv_kperm32(c & 31);
+            int gm = m0 + c;
+            if (PROBE && (a.probe & 32768)) gm = c;      // (measurement only: every tile reads the first A panel — the loop with the A operand always in L2)
+            if (X_IS_M) { const int b = gm / a.Tpad, key = gm % a.Tpad; gm = min(b, a.M / a.n_ctx - 1) * a.n_ctx + min(key, a.n_ctx - 1); }
+            if (gm > a.M - 1) gm = a.M - 1;
+            const long off = a.a_rows_per_batch ? (long)(gm / a.a_rows_per_batch) * a.a_batch_stride + (long)(gm % a.a_rows_per_batch) * a.lda : (long)gm * a.lda;
+            gA[i] = a.A + off + pchunk * 8;
+        }
+#pragma unroll
+        for (int t = 0; t < TNT; ++t) {
+            int s = (n0 + wave * WTN + 16 * t) >> 4; if (s > nstrip - 1) s = nstrip - 1;       // strips past N are computed on a copy of the last one and never stored
+            woff[t] = (unsigned)(s * nk32) * 1024u + lane * 16;
+        }
+    };
+    auto stage = [&](int slot, int kb) {
+        char* base = lds + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(gA[i] + kb * 64), (lptr_t)(base + (wave * A_PIECES + i) * 1024), 16, 0, 0);
+    };
+    // The weight loads are inline asm: beside LDS-DMA in flight hipcc waits vmcnt(0) for any ordinary load result (it drained the ring's DMA at every K step's
+    // first MFMA), and it does not count asm loads at all — so BOTH queues are counted by hand below.  A load's result is only touched after the wait that names it.
+    auto loadw = [&](f16x8 (&w)[TNT], int kb32) {
+#pragma unroll
+        for (int t = 0; t < TNT; ++t) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[t]) : "v"(woff[t] + (unsigned)kb32 * 1024u), "s"(a.Wf) : "memory");
+    };
+    const int fo0 = ((g ^ (r16 & 7)) << 4), fo1 = fo0 ^ 64;
+    const int aoff = r16 * 128;
+    const int x_lim = X_IS_M ? Mv : a.N, y_lim = X_IS_M ? a.N : a.M;
+    // The bias of every feature, in the order the epilogue meets them (memory order of the output: the kperm'ed-output epilogues' position p holds logical feature
+    // kperm^-1(p)), once per workgroup into the LDS the ring does not use: a tile's epilogue then takes its lanes' values with ds_reads instead of a round trip to L2.
+    constexpr int BIAS_OFF = NSLOT * SLOT, BIAS_MAX = (65536 - BIAS_OFF) / 4;
+    const bool bias_lds = a.N <= BIAS_MAX;
+    if (bias_lds) {
+        float* bl = (float*)(lds + BIAS_OFF);
+        for (int p = tid; p < a.N; p += 256) { const int f = (PERM && !X_IS_M) ? ((p & ~31) | inv_kperm32(p & 31)) : p; bl[p] = a.bias ? a.bias[f] : 0.0f; }
+        SKW_LDS_BARRIER();
+    }
+    for (int tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
+        int m0, n0; tile_origin(tile, m0, n0); tile_sources(m0, n0);
+        f16x8 w0[TNT], w1[TNT];
+        // vector-memory queue of this wave, in issue order (G = the four DMA pieces of a K step, W = the four weight loads of a 32-k block):
+        //   G(0) G(1) W0(0) | W1(0) G(2) W0(1) | W1(1) G(3) W0(2) | ...        step kb issues W1(kb), G(kb + 2), W0(kb + 1)
+        // first half of step kb uses W0(kb): younger are W1(kb), G(kb + 2) -> vmcnt(8), which also retires G(kb + 1) — a full step after its issue;
+        // second half uses W1(kb): younger are G(kb + 2), W0(kb + 1) -> vmcnt(8).  G(kb) itself was retired by the first-half wait of step kb - 1.
+        stage(0, 0);
+        stage(1, min(1, nk - 1));
+        loadw(w0, 0);
+        f32x4 acc[TX][TY];
+#pragma unroll
+        for (int i = 0; i < TX; ++i)
+#pragma unroll
+            for (int j = 0; j < TY; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                    // G(0) has landed (this wave's pieces)
+        for (int kb = 0; kb < nk; ++kb) {
+            // every wave's pieces of this step's slot are visible, and every wave has finished reading step kb - 1's slot (which G(kb + 2) overwrites)
+            __builtin_amdgcn_s_barrier();
+            const char* base = lds + (kb % NSLOT) * SLOT;
+            if (!(PROBE && (a.probe & 8192))) loadw(w1, 2 * kb + 1);
+            if (!(PROBE && (a.probe & 16384))) stage((kb + 2) % NSLOT, min(kb + 2, nk - 1));
+            {
+                f16x8 fa[TMT];
+#pragma unroll
+                for (int t = 0; t < TMT; ++t) fa[t] = *(const f16x8*)(base + aoff + t * 2048 + fo0);
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]) :: "memory");
+                if (PROBE && (a.probe & 4096)) { asm volatile("" :: "v"(fa[0]), "v"(fa[7]), "v"(w0[0])); } else
+#pragma unroll
+                for (int i = 0; i < TX; ++i)
+#pragma unroll
+                    for (int j = 0; j < TY; ++j) acc[i][j] = X_IS_M ? MFMA16X32(fa[i], w0[j], acc[i][j]) : MFMA16X32(w0[i], fa[j], acc[i][j]);
+            }
+            if (!(PROBE && (a.probe & 8192))) loadw(w0, min(2 * kb + 2, nk32 - 1));
+            {
+                f16x8 fa[TMT];
+#pragma unroll
+                for (int t = 0; t < TMT; ++t) fa[t] = *(const f16x8*)(base + aoff + t * 2048 + fo1);
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]) :: "memory");
+                if (PROBE && (a.probe & 4096)) { asm volatile("" :: "v"(fa[0]), "v"(fa[7]), "v"(w1[0])); } else
+#pragma unroll
+                for (int i = 0; i < TX; ++i)
+#pragma unroll
+                    for (int j = 0; j < TY; ++j) acc[i][j] = X_IS_M ? MFMA16X32(fa[i], w1[j], acc[i][j]) : MFMA16X32(w1[i], fa[j], acc[i][j]);
+            }
+        }
+        // the re-staged copies of the last step have landed and every wave is done with the ring before it becomes the staging area.  The wait NAMES the weight
+        // registers: the last step's look-ahead load is never consumed, and a register the compiler considers dead while an asm load is still in flight would be
+        // handed to the epilogue and then overwritten by the late data (seen: a wild residual address, a memory fault).
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]) :: "memory");
+        __syncthreads();
+        const int X0 = X_IS_M ? m0 : n0, Y0 = X_IS_M ? n0 : m0;
+        if (PROBE && (a.probe & 1024)) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TX - 1][TY - 1])); }
+        else {
+            // Epilogue, per wave and without workgroup barriers: the wave's 128 x 64 sub-tile goes through ITS OWN 16 KiB of the (now idle) ring — written in the
+            // MFMA's layout (a lane holds 4 adjacent X positions of one Y), read back as whole rows of the output (128 B of f16 / 256 B of f32 per row, 16 bytes per
+            // lane, 1 KiB per wave-instruction) — so the four waves drift apart and one's stores run under another's arithmetic; LDS operations of one wave
+            // execute in order, so a wait on lgkmcnt is all the synchronisation a fill needs.  Row-wise operands (residual, positional embedding) are requested
+            // before the fill they are added to.  Values and rounding are k_gemm16's (epi_value, f2h): the two kernels' outputs are bit-identical.
+            constexpr bool F32OUT = Epi16Out<EPI>::F32OUT;
+            constexpr int ESZ = F32OUT ? 4 : 2, CE = 16 / ESZ;
+            constexpr int WX = X_IS_M ? BM : WTN, WY = X_IS_M ? WTN : BM;                  // the wave's extent along memory (X) and across it (Y): 64 x 128, V^T 128 x 64
+            constexpr int RB = WX * ESZ, CPRW = RB / 16;                                   // bytes and 16-byte chunks per staged row
+            constexpr int FILLB = 8192;                                                    // bytes per fill and wave: 8 chunks of 16 bytes per lane (and 8 row-wise operand requests in flight for the f32 outputs)
+            constexpr int RH = FILLB / RB < WY ? FILLB / RB : WY, NFILL = WY / RH;         // rows per fill, fills per tile
+            constexpr int NCH = RH * CPRW / 64, TYF = RH / 16;                             // chunks per lane per fill, Y tiles per fill
+            static_assert(WY % RH == 0 && (RH * CPRW) % 64 == 0 && RH % 16 == 0, "whole fills");
+            char* wl = lds + wave * FILLB;
+            const int xw = X_IS_M ? 0 : wave * WTN, yw = X_IS_M ? wave * WTN : 0;          // the wave's origin inside the tile
+            const int div = X_IS_M ? a.Tpad : (a.n_ctx > 0 ? a.n_ctx : 1), org = X_IS_M ? X0 : Y0;
+            const int qb = org / div, rb = org % div;
+            const bool has_pad = X_IS_M && (rb + BM > a.n_ctx);                            // (uniform) V^T: the tile holds pad keys (positions n_ctx .. Tpad of a clip), which stay zero
+            // bias of this lane's elements: 4 adjacent X positions per X tile (features, in memory order), or one feature per Y tile for V^T
+            f32x4 bx[X_IS_M ? 1 : TX]; float by[X_IS_M ? TY : 1];
+            const float* bl = (const float*)(lds + BIAS_OFF);
+            if (!X_IS_M) {
+#pragma unroll
+                for (int i = 0; i < TX; ++i) {
+                    const int p0 = X0 + xw + i * 16 + 4 * g;
+                    if (bias_lds) bx[i] = (p0 < a.N) ? *(const f32x4*)(bl + p0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const int pos = p0 + r, f = PERM ? ((pos & ~31) | inv_kperm32(pos & 31)) : pos; bx[i][r] = (a.bias && f < a.N) ? a.bias[f] : 0.0f; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TY; ++j) { const int f = Y0 + yw + j * 16 + r16; by[j] = (f < a.N) ? (bias_lds ? bl[f] : (a.bias ? a.bias[f] : 0.0f)) : 0.0f; }
+            }
+#pragma unroll
+            for (int fill = 0; fill < NFILL; ++fill) {
+                // the row-wise operands this lane's chunks of the fill will meet, requested before the fill
+                f32x4 opnd[F32OUT ? NCH : 1];
+                if (F32OUT) {
+#pragma unroll
+                    for (int u = 0; u < NCH; ++u) {
+                        const int cid = lane + 64 * u, rho = cid / CPRW, pc = cid % CPRW, ck = pc ^ (rho & (CPRW - 1));
+                        const int dy = yw + fill * RH + rho, y = Y0 + dy, px = X0 + xw + ck * CE;
+                        const bool in = y < y_lim && px < x_lim && !(PROBE && (a.probe & 65536));
+                        if (EPI == EPI_F32) opnd[u] = (a.res && in) ? *(const f32x4*)(a.res + (long)y * a.ldres + px) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (EPI == EPI_CONV2) { int i = rb + dy; if (i >= a.n_ctx) i -= a.n_ctx;
+                                                opnd[u] = in ? *(const f32x4*)(a.pe + (long)i * a.N + px) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    }
+                }
+                // fill: the lane's 4 adjacent X positions of row (Y) j * 16 + r16, chunk position XOR-ed with the row so that the 16 rows of a wave-instruction spread over the banks
+#pragma unroll
+                for (int jj = 0; jj < TYF; ++jj) {
+                    const int j = fill * TYF + jj, rho = jj * 16 + r16;
+#pragma unroll
+                    for (int i = 0; i < TX; ++i) {
+                        const int xl = i * 16 + 4 * g;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o[r] = epi_value<EPI>(a, 0, acc[i][j][r], X_IS_M ? by[j] : bx[i][r]);
+                            if (X_IS_M && has_pad) { int key = rb + (((xl + r) & ~31) | inv_kperm32((xl + r) & 31)); if (key >= a.Tpad) key -= a.Tpad; if (key >= a.n_ctx) o[r] = 0.0f; }
+                        }
+                        const int ck = xl / CE;
+                        char* dst = wl + rho * RB + ((ck ^ (rho & (CPRW - 1))) << 4);
+                        if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
+                        else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);      // (the write-out's address arithmetic stays below the fill: hoisted above it, it was held in registers the accumulators still need)
+                // whole rows out
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) {
+                    const int cid = lane + 64 * u, rho = cid / CPRW, pc = cid % CPRW, ck = pc ^ (rho & (CPRW - 1));
+                    const int dy = yw + fill * RH + rho, dx = xw + ck * CE, y = Y0 + dy, px = X0 + dx;
+                    if (y >= y_lim || px >= x_lim || (PROBE && (a.probe & 65536))) continue;
+                    const long off = epi_chunk_offset<EPI>(a, y, px, dy, dx, qb, rb);
+                    const char* src = wl + cid * 16;
+                    if (F32OUT) {
+                        f32x4 v = *(const f32x4*)src;
+                        if (EPI == EPI_F32) { if (a.res) { v[0] = v[0] + opnd[u][0]; v[1] = v[1] + opnd[u][1]; v[2] = v[2] + opnd[u][2]; v[3] = v[3] + opnd[u][3]; } }
+                        else { v[0] = opnd[u][0] + v[0]; v[1] = opnd[u][1] + v[1]; v[2] = opnd[u][2] + v[2]; v[3] = opnd[u][3] + v[3]; }
+                        *(f32x4*)((float*)a.C + off) = v;
+                    } else { const u32x4 o16 = *(const u32x4*)src; *(u32x4*)((half_t*)a.C + off) = o16; }
+                }
+                if (fill + 1 < NFILL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads have the rows before the next fill overwrites them
+            }
+            // every wave has read its rows back before the next tile's first K steps land in the ring
+            SKW_LDS_BARRIER();
+        }
+    }
+}
+template <int EPI> static void launch_gemm16w(const SkwGemmArgs& a, hipStream_t s) {
+    const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
+    const int nblk = ((Mv + 127) / 128) * ((a.N + 255) / 256);
+    const int slots = ((a.probe & 2048) ? 1 : 2) * (skw_cu_count() & ~7);      // (probe bit 11: one workgroup per CU)
+    if (a.probe) hipLaunchKernelGGL((k_gemm16w<EPI, true>), dim3(std::min(nblk, slots)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm16w<EPI>), dim3(std::min(nblk, slots)), dim3(256), 0, s, a);
+}
+// the weights-from-image form applies when the weight has an image, the K axis is whole 64-steps and the feature count whole strips
+static bool gemm16w_ok(const SkwGemmArgs& a) {
+    static const int on = getenv("SKW_GEMM16W") ? atoi(getenv("SKW_GEMM16W")) : 1;
+    return on && a.Wf && !(a.probe & 1023) && (a.K & 63) == 0 && (a.N & 15) == 0 && a.M >= 128;      // (probe bits 0-9 are k_gemm16's; 10+ this kernel's)
+}
 template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves, one workgroup per CU) when both extents fill it, 128 x 128 (4 waves, two per CU) otherwise;
     // persistent workgroups: one grid slot per resident workgroup (rounded to the 8 XCDs), each walks tile ids slot, slot + grid, ...
@@ -362,6 +596,19 @@ template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_
 // EPI_VT_F16 is called in the NATURAL orientation here (A = tokens [M][K], W = weights [N][K], bias per n), unlike the exact
 // kernel's operand-swapped call: the output is the same V^T image.
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
+    if (gemm16w_ok(a)) {
+        switch (a.epi) {
+            case EPI_F32: launch_gemm16w<EPI_F32>(a, s); return;
+            case EPI_F16_KPERM: launch_gemm16w<EPI_F16_KPERM>(a, s); return;
+            case EPI_GELU_F16_KPERM: launch_gemm16w<EPI_GELU_F16_KPERM>(a, s); return;
+            case EPI_GELU_F16_KPERM_ROWPAD: launch_gemm16w<EPI_GELU_F16_KPERM_ROWPAD>(a, s); return;
+            case EPI_CONV2: launch_gemm16w<EPI_CONV2>(a, s); return;
+            case EPI_HEADS_F16: launch_gemm16w<EPI_HEADS_F16>(a, s); return;
+            case EPI_VT_F16: launch_gemm16w<EPI_VT_F16>(a, s); return;
+            case EPI_F16_PLAIN: launch_gemm16w<EPI_F16_PLAIN>(a, s); return;
+            default: break;
+        }
+    }
     switch (a.epi) {
         case EPI_F32: launch_gemm16<EPI_F32>(a, s); break;
         case EPI_F16_KPERM: launch_gemm16<EPI_F16_KPERM>(a, s); break;
