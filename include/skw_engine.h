@@ -107,8 +107,11 @@ const char* skw_ctx_last_error(const skw_ctx*);
  *                           logit margin at that step is below twice the measured logit error (checked step by step under teacher
  *                           forcing, skw_full_batch_traced).  A free-running transcript is therefore identical to the exact mode's
  *                           up to its first such near-tie and may differ after it (on the synthetic benchmark model about a quarter
- *                           of the 30 s clips contain one; bench.py reports the count).  log-mel, LayerNorm statistics, GELU and the
- *                           logit rules are the exact kernels in both modes. */
+ *                           of the 30 s clips contain one; bench.py reports the count).  log-mel and the logit rules are the exact
+ *                           kernels in both modes, and so are the encoder's LayerNorms; GELU is evaluated (exp2 / rcp) instead of looked
+ *                           up, and the DECODE step folds its LayerNorms into the consuming GEMMs (k_gemm16_small_lnA: one-pass
+ *                           E[x^2] - mean^2 statistics in f64, f32 rstd — within the mode's tolerance of k_layernorm's two-pass
+ *                           arithmetic, not identical to it; SKW_DEC_LN_STATS=0 restores the LayerNorm kernels). */
 #define SKW_PRECISION_EXACT 0
 #define SKW_PRECISION_F16_MFMA 1
 int skw_ctx_set_precision(skw_ctx*, int precision);   /* 0 on success; takes effect from the next call on this context */

@@ -655,6 +655,7 @@ struct ProfScope {
     ProfScope(skw_ctx* c_, int cls, double flops, double bytes, bool ext_ = false);
     ~ProfScope();
     hipEvent_t ev_a() const; hipEvent_t ev_b() const;
+    void cancel() { if (ps) { ps->recs[idx].flops = 0.0; ps->recs[idx].bytes = 0.0; ps->recs[idx].cls = PC_OTHER; } }      // the launch did not happen: book nothing for it
 };
 
 // ------------------------------------------------------------------ GEMM helpers
@@ -935,8 +936,11 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         }
         if (lnA && site >= 0) {
             a.W = Lw.w_nat; a.Wf = Lw.w_nat_frag; a.ln_x = dx; a.ln_w = ln.w; a.ln_b = ln.b;
-            ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
-            if (skw_gemm16_small_lnA(a, c->cur)) return;
+            {   // (the scope ends before the fall-back below books the same product a second time: ADVICE r3)
+                ProfScope p(c, PC_GEMM_SMALL, 2.0 * a.M * a.N * a.K, 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N);
+                if (skw_gemm16_small_lnA(a, c->cur)) return;
+                p.cancel();
+            }
             a.W = Lw.w; a.Wf = Lw.w_frag; a.ln_x = nullptr;
         }
         GEMM_LN(c, a, dx, ln, dy16, s, normalised);

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
             constexpr int ESZ = F32OUT ? 4 : 2, CE = 16 / ESZ;
             constexpr int WX = X_IS_M ? BM : WTN, WY = X_IS_M ? WTN : BM;                  // the wave's extent along memory (X) and across it (Y): 64 x 128, V^T 128 x 64
             constexpr int RB = WX * ESZ, CPRW = RB / 16;                                   // bytes and 16-byte chunks per staged row
-            constexpr int FILLB = 8192;                                                    // bytes per fill and wave: 8 chunks of 16 bytes per lane (and 8 row-wise operand requests in flight for the f32 outputs)
+            constexpr int FILLB = 8192;                                                    // bytes per fill and wave: 8 chunks of 16 bytes per lane (f32 outputs: 8 row-wise operand requests in flight)
             constexpr int RH = FILLB / RB < WY ? FILLB / RB : WY, NFILL = WY / RH;         // rows per fill, fills per tile
             constexpr int NCH = RH * CPRW / 64, TYF = RH / 16;                             // chunks per lane per fill, Y tiles per fill
             static_assert(WY % RH == 0 && (RH * CPRW) % 64 == 0 && RH % 16 == 0, "whole fills");
@@ -566,7 +566,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
                         const int ck = xl / CE;
                         char* dst = wl + rho * RB + ((ck ^ (rho & (CPRW - 1))) << 4);
                         if (F32OUT) *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
-                        else *(f16x4*)(dst + ((xl % CE) >= 4 ? 8 : 0)) = (f16x4){f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
+                        // (f16: the lane's 8 bytes are one half of a 16-byte chunk.  The 16 lanes a ds_write_b64 serves together hold rows rho .. rho + 15 at one chunk
+                        //  index: the XOR spreads them over 8 chunk positions, two rows each — rows 8 apart then take OPPOSITE halves, and the reader swaps them back:
+                        //  without this SQ_LDS_BANK_CONFLICT was 40 % of the f16-output variants' LDS-active cycles, profiles/r04c)
+                        else *(f16x4*)(dst + ((((xl % CE) >= 4) != (((rho >> 3) & 1) != 0)) ? 8 : 0)) = (f16x4){f2h(o[0]), f2h(o[1]), f2h(o[2]), f2h(o[3])};
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
                         if (EPI == EPI_F32) { if (a.res) { v[0] = v[0] + opnd[u][0]; v[1] = v[1] + opnd[u][1]; v[2] = v[2] + opnd[u][2]; v[3] = v[3] + opnd[u][3]; } }
                         else { v[0] = opnd[u][0] + v[0]; v[1] = opnd[u][1] + v[1]; v[2] = opnd[u][2] + v[2]; v[3] = opnd[u][3] + v[3]; }
                         *(f32x4*)((float*)a.C + off) = v;
-                    } else { const u32x4 o16 = *(const u32x4*)src; *(u32x4*)((half_t*)a.C + off) = o16; }
+                    } else { u32x4 o16 = *(const u32x4*)src; if ((rho >> 3) & 1) o16 = (u32x4){o16[2], o16[3], o16[0], o16[1]}; *(u32x4*)((half_t*)a.C + off) = o16; }
                 }
                 if (fill + 1 < NFILL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads have the rows before the next fill overwrites them
             }
@@ -677,7 +680,7 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };
 template <bool XP>
 __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
+                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp, int ksw_r3) {
     __shared__ __attribute__((aligned(1024))) char lds[2][2][64 * 128];   // [buffer][K | V^T][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = gridDim.x; int bid = blockIdx.x;
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     for (int i = 0; i < 2; ++i) {
         const int c = tid + 256 * i, row = c >> 3, pos = c & 7;
         st_lds[i] = (unsigned)(row * 128 + ((pos ^ (row & 7)) << 4));
-        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ ((row >> 1) & 6)) << 4));
+        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (ksw_r3 ? (((row & 1) << 2) | ((row >> 2) & 3)) : ((row >> 1) & 6))) << 4));      // (ksw_r3: round 3's swizzle, SKW_ATTN_KSW_R3=1, for the A/B)
         st_k[i] = (unsigned)((row * krow + pos * 8) * 2);            // + kb * 64 rows; rows past Tpad (XP: past n_ctx) fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
         // the same 16-byte chunks at their fragment-order addresses: a 64-key block is 8 KiB of either image (K: key tile row >> 4 of the block, row 4 (r & 3) + (r >>
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
     }
     const int nkb = (Tpad + 63) >> 6;
     const int kappa = 4 * (r16 & 3) + (r16 >> 2);
-    const int k_off = kappa * 128, k_sw = (r16 & 3) << 1, v_off = r16 * 128, v_sw = r16 & 7;      // k_sw = (kappa >> 1) & 6: the stored swizzle of the row this lane reads
+    const int k_off = kappa * 128, k_sw = ksw_r3 ? (r16 & 7) : ((r16 & 3) << 1), v_off = r16 * 128, v_sw = r16 & 7;      // k_sw = (kappa >> 1) & 6: the stored swizzle of the row this lane reads
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
@@ -837,16 +840,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
         }
     }
 }
+static int attn_ksw_r3() { static const int v = getenv("SKW_ATTN_KSW_R3") ? atoi(getenv("SKW_ATTN_KSW_R3")) : 0; return v; }
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s) {
     const int qblocks = (n_ctx + A16_QB - 1) / A16_QB;
-    hipLaunchKernelGGL(k_attn_encoder16<false>, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{});
+    hipLaunchKernelGGL(k_attn_encoder16<false>, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{}, attn_ksw_r3());
 }
 // the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
                          int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag, int ofrag) {
     const int qblocks = (nq_max + A16_QB - 1) / A16_QB;
     const SkwXPrefill xp{row0, nq, slot, (long)d, (long)(frag ? Tpad : n_ctx) * d, (long)d, frag, ofrag ? d : 0};
-    hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp);
+    hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp, attn_ksw_r3());
 }
 
 // what a wave does with a finished 16 x 16 tile: lane (r16, g) holds rows-of-W 4g .. 4g+3 (four adjacent outputs) of row m

@@ -14,12 +14,12 @@ for f in glob.glob("/tmp/pmc16_%s/*counter_collection.csv" % tag):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        for key in ("k_gemm16<", "k_attn_encoder16", "k_dec_cross_attn", "k_gemm16_small<0", "k_layernorm"):
+        for key in ("k_gemm16w<", "k_gemm16<", "k_attn_encoder16", "k_dec_cross_attn", "k_gemm16_small<0", "k_layernorm"):
             if key in n:
                 short = n.split("(")[0]
-                if key == "k_gemm16<": short = short[short.index("k_gemm16<"):][:28]
+                if key in ("k_gemm16<", "k_gemm16w<"): short = short[short.index(key):][:28]
                 else: short = key
-                k = (short, r["Counter_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+                k = (short, r["Counter_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"]); break
     for k, v in sorted(agg.items()): print("%-30s %-28s launches=%-6d avg=%.6g" % (k[0], k[1], v[0], v[1] / v[0]))
 PY
   rm -rf /tmp/pmc16_$tag

@@ -4,7 +4,7 @@ rocprofv3 counter_collection CSVs: one --pmc FETCH_SIZE pass and one --pmc WRITE
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; FETCH_SIZE tallies 128-B requests at 64 B -> x2.
 usage: pmc_traffic.py fetch.csv write.csv out.json [precision]   (the result is stored under that precision's key; other keys of an existing out.json are kept)"""
 import csv, collections, json, sys
-CLASSES = [("k_mel", "k_mel"), ("k_gemm_smallm", "k_gemm_smallm"), ("k_gemm16_small", "k_gemm_smallm"), ("k_gemm16_vocab", "k_gemm_smallm"), ("k_gemm<", "k_gemm"), ("k_gemm16<", "k_gemm"), ("k_attn_encoder", "k_attn_encoder"), ("k_layernorm", "k_layernorm"),
+CLASSES = [("k_mel", "k_mel"), ("k_gemm_smallm", "k_gemm_smallm"), ("k_gemm16_small", "k_gemm_smallm"), ("k_gemm16_vocab", "k_gemm_smallm"), ("k_gemm<", "k_gemm"), ("k_gemm16<", "k_gemm"), ("k_gemm16w<", "k_gemm"), ("k_attn_encoder", "k_attn_encoder"), ("k_layernorm", "k_layernorm"),
            ("k_dec_cross_attn", "k_dec_cross_attn"), ("k_dec_attn", "k_dec_self_attn"), ("k_dec_sample", "k_dec_sample")]
 def cls(name):
     for pat, c in CLASSES:
