@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
             constexpr int ESZ = F32OUT ? 4 : 2, CE = 16 / ESZ;
             constexpr int WX = X_IS_M ? BM : WTN, WY = X_IS_M ? WTN : BM;                  // the wave's extent along memory (X) and across it (Y): 64 x 128, V^T 128 x 64
             constexpr int RB = WX * ESZ, CPRW = RB / 16;                                   // bytes and 16-byte chunks per staged row
-            constexpr int FILLB = 8192;                                                    // bytes per fill and wave: 8 chunks of 16 bytes per lane (f32 outputs: 8 row-wise operand requests in flight)
+            constexpr int FILLB = 8192;                                                    // bytes per fill and wave: 8 chunks of 16 bytes per lane (f32 outputs: 8 operand requests in flight)
             constexpr int RH = FILLB / RB < WY ? FILLB / RB : WY, NFILL = WY / RH;         // rows per fill, fills per tile
             constexpr int NCH = RH * CPRW / 64, TYF = RH / 16;                             // chunks per lane per fill, Y tiles per fill
             static_assert(WY % RH == 0 && (RH * CPRW) % 64 == 0 && RH % 16 == 0, "whole fills");
