@@ -17,9 +17,11 @@
  * Plain pointers and sizes only.  There is no CPU fallback: without a gfx950 device skw_tts_create fails and says so.
  *
  * PARITY UNPINNED: the arithmetic the reference runs is Kokoro-82M's ONNX graph inside onnxruntime, neither of which exists in
- * /root/reference or offline.  What this library evaluates is a reduced network of the same shape: text encoder ->
- * style-conditioned duration / F0 / energy predictors -> length regulation -> AdaIN decoder -> harmonic-plus-noise ISTFTNet head
- * (n_fft 20, hop 5, 24 kHz), its weights read by NAME from the initializers of `model`, checked against oracle/skw_kokoro_oracle.c.
+ * /root/reference or offline.  What this library evaluates is the published Kokoro-82M architecture as recalled (include/skw_kokoro_net.h:
+ * ALBERT text encoder -> BiLSTM / AdaLayerNorm duration predictor -> length regulation -> AdainResBlk1d F0 / energy curves -> acoustic text
+ * encoder -> AdaIN decoder -> ISTFTNet generator with a harmonic-plus-noise source, n_fft 20, hop 5, 24 kHz), all widths read from the tensor
+ * shapes, its weights read by PyTorch module NAME from the initializers of `model`, checked operator by operator against
+ * oracle/skw_kokoro_oracle.cpp.  A sherpa-onnx export names its initializers by graph node: create() rejects such a file and says which name it missed.
  */
 #ifndef SKW_TTS_H
 #define SKW_TTS_H
@@ -55,7 +57,13 @@ int32_t skw_tts_sample_rate(const skw_tts*);                                    
 
 /* ---- stage taps for the parity tests (tests/test_gpu_kokoro.py): the host-side text -> token ids step, and the last call's intermediates ---- */
 int32_t skw_tts_tokenize(skw_tts*, const char* text, int32_t* ids, int32_t cap);        /* ids incl. the pad token at both ends; returns the count (<= cap) */
-/* what: 0 durations [T] (as floats), 1 f0 [F], 2 energy [F], 3 decoder output [F][C], 4 spectrum+phase [P][22]; returns the element count, copies min(count, cap) */
+/* the same from token ids (incl. the pad id at both ends): a chosen number of tokens whatever the lexicon (tests, bench) */
+const skw_tts_audio* skw_tts_generate_ids(skw_tts*, const int32_t* ids, int32_t n_ids, int32_t sid, float speed);
+/* taps are copied to the host only after skw_tts_debug_enable(tts, 1) (off by default: a product call pays nothing for them) */
+void skw_tts_debug_enable(skw_tts*, int on);
+/* what: 0 durations [T] (as floats), 1 F0 curve [2 F], 2 energy curve [2 F], 3 decoder output [2 F][C], 4 log-magnitude + phase [120 F + 1][22], 5 ALBERT output [T][hid],
+ * 6 bert_encoder output [T][d], 7 acoustic text encoder output [T][d], 8 the source's STFT magnitude + phase [120 F + 1][22];
+ * returns the element count of the last call with taps on, copies min(count, cap) */
 long skw_tts_debug_get(skw_tts*, int what, float* out, long cap);
 /* timing of the last generate (GPU events): milliseconds */
 float skw_tts_last_ms(const skw_tts*);

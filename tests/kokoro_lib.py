@@ -1,5 +1,5 @@
 """Test-side access to the Kokoro path: the product's synthesiser (libskw_tts.so, include/skw_tts.h) and the oracle
-(oracle/skw_kokoro_oracle.c fed by tests/onnx_mini.py), a Python restatement of the text -> token ids step, and the seeded model
+(oracle/skw_kokoro_oracle.cpp fed by tests/onnx_mini.py), a Python restatement of the text -> token ids step, and the seeded model
 directory all of them read (tools/make_synth_kokoro.py)."""
 import ctypes as C
 import os
@@ -11,7 +11,7 @@ import numpy as np
 import onnx_mini
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-U, BINS, STYLE, MAX_TOKENS, MAX_FRAMES = 120, 11, 128, 510, 6000
+BINS, STYLE, MAX_TOKENS, MAX_FRAMES = 11, 128, 510, 3000
 
 
 def synth_kokoro_dir(size="micro", seed=1234):
@@ -70,46 +70,49 @@ def tokenize(text, model_dir):
     return ids
 
 
-class _Dims(C.Structure):
-    _fields_ = [("T", C.c_int), ("d", C.c_int), ("n_te", C.c_int), ("K", C.c_int), ("C", C.c_int), ("n_dec", C.c_int), ("G", C.c_int), ("scale", C.c_float), ("max_frames", C.c_int)]
+class _TensorRef(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("n_dims", C.c_int32), ("dims", C.c_int64 * 4)]
 
 
 class OracleTts:
+    """oracle/skw_kokoro_oracle.cpp: the Kokoro network (include/skw_kokoro_net.h) with every operator a CPU loop, fed the tensors tests/onnx_mini.py reads from model.onnx"""
+
     def __init__(self, model_dir):
         self.dir = model_dir
         self.w = {name: np.ascontiguousarray(a, np.float32) for _, name, a in onnx_mini.read_tensors(os.path.join(model_dir, "model.onnx"))}
         self.voices = np.fromfile(os.path.join(model_dir, "voices.bin"), "<f4").reshape(-1, MAX_TOKENS, 2 * STYLE)
-        w = self.w
-        self.d = w["text_encoder.embedding.weight"].shape[1]
-        self.n_te = sum(1 for k in w if k.startswith("text_encoder.cnn.") and k.endswith(".weight"))
-        self.n_dec = sum(1 for k in w if k.startswith("decoder.decode.") and k.endswith(".weight") and ".fc." not in k)
-        self.K = w["predictor.duration_proj.weight"].shape[0]; self.Cc = w["decoder.encode.weight"].shape[0]; self.G = w["decoder.generator.ups.weight"].shape[1]
-        order = ["text_encoder.embedding.weight"]
-        for i in range(self.n_te):
-            order += ["text_encoder.cnn.%d.%s" % (i, s) for s in ("weight", "bias", "norm.gamma", "norm.beta")]
-        order += ["predictor.text_encoder.fc.weight", "predictor.text_encoder.fc.bias", "predictor.duration_proj.weight", "predictor.duration_proj.bias",
-                  "predictor.F0_proj.weight", "predictor.F0_proj.style", "predictor.F0_proj.bias", "predictor.N_proj.weight", "predictor.N_proj.bias",
-                  "decoder.encode.weight", "decoder.encode.bias", "decoder.encode.fc.weight", "decoder.encode.fc.bias"]
-        for i in range(self.n_dec):
-            order += ["decoder.decode.%d.%s" % (i, s) for s in ("weight", "bias", "fc.weight", "fc.bias")]
-        order += ["decoder.generator.ups.weight", "decoder.generator.ups.bias", "decoder.generator.source.weight", "decoder.generator.resblock.alpha",
-                  "decoder.generator.resblock.weight", "decoder.generator.resblock.bias", "decoder.generator.conv_post.weight", "decoder.generator.conv_post.bias"]
-        self._ptrs = (C.c_void_p * len(order))(*[w[k].ctypes.data for k in order])
+        self.hid = self.w["bert_encoder.weight"].shape[1]; self.d = self.w["bert_encoder.weight"].shape[0]
+        self.gen_c0 = self.w["decoder.generator.ups.0.weight"].shape[0]
+        names = sorted(self.w)
+        self._keep = [n.encode() for n in names]
+        self._refs = (_TensorRef * len(names))()
+        for i, n in enumerate(names):
+            a = self.w[n]; r = self._refs[i]
+            r.name = self._keep[i]; r.data = a.ctypes.data; r.n_dims = a.ndim
+            for k in range(a.ndim):
+                r.dims[k] = a.shape[k]
         self._lib = C.CDLL(os.path.join(ROOT, "oracle", "libskw_oracle.so"))
-        self._lib.skwo_tts_synth.restype = C.c_long
-        self._lib.skwo_tts_synth.argtypes = [C.POINTER(_Dims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)] + [C.c_void_p] * 5 + [C.c_long]
+        self._lib.skwo_kokoro_forward.restype = C.c_long
+        self._lib.skwo_kokoro_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int32)] + [C.c_void_p] * 6 + \
+                                                [C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_char_p, C.c_int]
 
-    def synth(self, text, sid=0, speed=1.0, length_scale=1.0):
-        ids = np.asarray(tokenize(text, self.dir), np.int32); T = ids.size
+    def synth(self, text, sid=0, speed=1.0, length_scale=1.0, ids=None):
+        ids = np.asarray(tokenize(text, self.dir) if ids is None else ids, np.int32); T = ids.size
         style = np.ascontiguousarray(self.voices[sid, max(0, min(T - 2, MAX_TOKENS - 1))])
-        dims = _Dims(T, self.d, self.n_te, self.K, self.Cc, self.n_dec, self.G, np.float32(length_scale) / np.float32(speed), MAX_FRAMES)
-        dur = np.zeros(T, np.int32); F = C.c_int()
-        cap_f = MAX_FRAMES; cap_p = cap_f * U
-        f0 = np.zeros(cap_f, np.float32); en = np.zeros(cap_f, np.float32); z = np.zeros(cap_f * self.Cc, np.float32); o = np.zeros(cap_p * 2 * BINS, np.float32); y = np.zeros(5 * cap_p, np.float32)
-        n = self._lib.skwo_tts_synth(C.byref(dims), ids.ctypes.data, style.ctypes.data, self._ptrs, dur.ctypes.data, C.byref(F), f0.ctypes.data, en.ctypes.data, z.ctypes.data, o.ctypes.data, y.ctypes.data, y.size)
-        assert n >= 0
+        dur = np.zeros(T, np.int32); F = C.c_int32()
+        cap_f = MAX_FRAMES
+        bert = np.zeros(T * self.hid, np.float32); d_en = np.zeros(T * self.d, np.float32); t_en = np.zeros(T * self.d, np.float32)
+        f0 = np.zeros(2 * cap_f, np.float32); en = np.zeros(2 * cap_f, np.float32)
+        dec = np.zeros(2 * cap_f * self.gen_c0, np.float32); post = np.zeros((2 * cap_f * 60 + 1) * 22, np.float32); y = np.zeros(600 * cap_f, np.float32); har = np.zeros_like(post)
+        err = C.create_string_buffer(512)
+        n = self._lib.skwo_kokoro_forward(self._refs, len(self._refs), ids.ctypes.data, T, style.ctypes.data, np.float32(length_scale) / np.float32(speed), cap_f,
+                                          dur.ctypes.data, C.byref(F), bert.ctypes.data, d_en.ctypes.data, t_en.ctypes.data, f0.ctypes.data, en.ctypes.data,
+                                          dec.ctypes.data, dec.size, post.ctypes.data, post.size, y.ctypes.data, y.size, har.ctypes.data, har.size, err, 512)
+        if n < 0:
+            raise RuntimeError(err.value.decode())
         Fv = F.value
-        return dict(ids=ids, dur=dur, f0=f0[:Fv].copy(), en=en[:Fv].copy(), z=z[:Fv * self.Cc].reshape(Fv, self.Cc).copy(), o=o[:Fv * U * 2 * BINS].reshape(Fv * U, 2 * BINS).copy(), y=y[:n].copy())
+        return dict(ids=ids, dur=dur, F=Fv, bert=bert.reshape(T, self.hid), d_en=d_en.reshape(T, self.d), t_en=t_en.reshape(T, self.d), f0=f0[:2 * Fv].copy(), en=en[:2 * Fv].copy(),
+                    dec=dec[:2 * Fv * self.gen_c0].reshape(2 * Fv, self.gen_c0).copy(), post=post[:(2 * Fv * 60 + 1) * 22].reshape(-1, 22).copy(), har=har[:(2 * Fv * 60 + 1) * 22].reshape(-1, 22).copy(), y=y[:n].copy())
 
 
 class _Cfg(C.Structure):
@@ -131,6 +134,8 @@ def tts_lib():
     L.skw_tts_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]
     L.skw_tts_debug_get.restype = C.c_long; L.skw_tts_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
     L.skw_tts_last_ms.restype = C.c_float; L.skw_tts_last_ms.argtypes = [C.c_void_p]
+    L.skw_tts_generate_ids.restype = C.POINTER(_Audio); L.skw_tts_generate_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+    L.skw_tts_debug_enable.argtypes = [C.c_void_p, C.c_int]
     return L
 
 
@@ -151,13 +156,20 @@ class Tts:
         n = self.L.skw_tts_tokenize(self.h, text.encode(), ids.ctypes.data, ids.size)
         return ids[:n].copy()
 
-    def generate(self, text, sid=0, speed=1.0):
-        a = self.L.skw_tts_generate(self.h, text.encode(), sid, speed)
+    def generate(self, text, sid=0, speed=1.0, ids=None):
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int32)
+            a = self.L.skw_tts_generate_ids(self.h, ids.ctypes.data, ids.size, sid, speed)
+        else:
+            a = self.L.skw_tts_generate(self.h, text.encode(), sid, speed)
         if not a:
             raise RuntimeError(self.L.skw_tts_last_error(self.h).decode())
         y = np.ctypeslib.as_array(a.contents.samples, shape=(a.contents.n,)).copy(); rate = a.contents.sample_rate
         self.L.skw_tts_destroy_audio(a)
         return y, rate
+
+    def taps(self, on=True):
+        self.L.skw_tts_debug_enable(self.h, 1 if on else 0)
 
     def tap(self, what):
         n = self.L.skw_tts_debug_get(self.h, what, None, 0)

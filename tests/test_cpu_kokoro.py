@@ -146,8 +146,10 @@ def test_oracle_synthesiser_is_sane_and_deterministic(built):
     ids = kokoro_lib.tokenize(text, d)
     assert ids[0] == 0 and ids[-1] == 0 and ids[1:5] == [20, 17, 24, 27]                      # "hello" through the lexicon: h e l o
     F = int(r["dur"].sum())
-    assert (r["dur"] >= 1).all() and r["y"].size == 5 * (120 * F - 1) and np.isfinite(r["y"]).all()
-    assert 60.0 <= r["f0"].min() and r["f0"].max() <= 400.0
+    assert (r["dur"] >= 1).all() and F == r["F"] and len(set(r["dur"].tolist())) >= 2 and r["y"].size == 600 * F and np.isfinite(r["y"]).all()      # 600 samples per frame: 2 x 10 x 6 x hop 5
+    assert r["f0"].size == 2 * F and r["dec"].shape[0] == 2 * F and r["post"].shape == (120 * F + 1, 22) and r["bert"].shape[0] == len(ids)
+    voiced = float((r["f0"] > 10.0).mean())
+    assert 0.5 < voiced < 1.0 and r["f0"].max() <= 500.0                                        # Hz; values under 10 Hz are the unvoiced stretches
     assert 1e-3 < float(np.sqrt((r["y"] ** 2).mean())) < 0.5 and float(np.abs(r["y"]).max()) < 4.0
     # speed divides the durations; another speaker changes the voice
     fast = o.synth(text, sid=50, speed=2.0)

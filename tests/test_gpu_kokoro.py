@@ -1,5 +1,5 @@
 """GPU tests of the Kokoro TTS path (BASELINE.json configs[4]): the synthesiser behind include/skw_tts.h against
-oracle/skw_kokoro_oracle.c, the node libkokoro.so through the plugin C ABI, and the voice-agent chain
+oracle/skw_kokoro_oracle.cpp (the same network, include/skw_kokoro_net.h, every operator a CPU loop), the node libkokoro.so through the plugin C ABI, and the voice-agent chain
 30 s clip -> libwhisper.so (Whisper-small) -> Transcription -> Text -> libkokoro.so -> 24 kHz frames.
 PARITY UNPINNED for the synthesiser's arithmetic (include/skw_tts.h): the checker is this repository's own restatement, not the reference's
 (Kokoro-82M inside onnxruntime, absent offline); the node's text front end IS pinned, by the reference's own vectors (tests/test_cpu_kokoro.py)."""
@@ -18,15 +18,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KOKORO = os.path.join(ROOT, "streamkit_amd", "libkokoro.so")
 
-# tolerances of the float path, relative to the tensor's RMS: every contraction is f64-accumulated on both sides, so what differs is sinf / sin / cos
-# between libm and the device's (a few ulps) and the order of f64 partial sums (1e-16)
-TOL_STAGE = 1e-4
-TOL_WAVE = 1e-3
+# Every contraction is the same k-ascending f32 chain on both sides (MFMA 16x16x4 f32 on the GPU, fmaf on the CPU), exp is skw_expf on both and the f64 statistics are summed in
+# the contract's order (include/skw_kokoro_net.h), so everything up to the decoder's output — ALBERT, durations, F0 / energy curves, text encoder, decoder — must be BIT-IDENTICAL.
+# From the generator on, Snake's sinf and the source's sin / the STFT's atan2 / the inverse STFT's sin, cos are the platform's, a few ulps apart: tolerances relative to the RMS.
+# One discontinuity is the architecture's own: the source's STFT PHASE is a network input, and a near-empty bin whose phase sits at +-pi can wrap the other way on an ulp (measured
+# once, round 4, when the F0 curves still differed by 1e-6: three wraps in 650 000 bins, each disturbing ~600 spectrum rows).  Rows downstream of such a wrap are left out.
+TOL_GEN = 2e-5
+TOL_WAVE = 5e-5
+
+
+def _wrap_mask(har_gpu, har_cpu, span=1500):
+    """rows of the spectrum that no +-pi wrap of the source's phase can have reached (the generator's receptive field is under `span` rows either side)"""
+    dp = np.abs(har_gpu[:, 11:] - har_cpu[:, 11:])
+    rows = np.unique(np.nonzero(dp > 3.0)[0])
+    keep = np.ones(har_cpu.shape[0], bool)
+    for r in rows:
+        keep[max(0, r - span):r + span] = False
+    return keep, rows.size
 
 
 def _rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b * b)) + 1e-30))
+
+
+def _wave_ok(y, ref):
+    """the node-level check: same length, and at least 80 % of the 0.1 s blocks within TOL_WAVE of the checker's (a phase wrap, see above, disturbs at most a few blocks)"""
+    if y.size != ref.size:
+        return False
+    n = (y.size // 2400) * 2400
+    if n == 0:
+        return _rel(y, ref) < 2e-3
+    rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2)) + 1e-30
+    eb = np.sqrt(np.mean((y[:n].astype(np.float64) - ref[:n]).reshape(-1, 2400) ** 2, axis=1)) / rms
+    return float(np.mean(eb < TOL_WAVE)) >= 0.8
 
 
 TEXTS = ["Hello world. This is a test of the synthesiser, 1 2 3!", "Short one.", "你好。 Mixed: café, naïve?",
@@ -38,6 +63,7 @@ def test_synthesiser_matches_oracle_stage_by_stage(size):
     d = kokoro_lib.synth_kokoro_dir(size)
     tts = kokoro_lib.Tts(d); orc = kokoro_lib.OracleTts(d)
     assert tts.L.skw_tts_sample_rate(tts.h) == 24000 and tts.L.skw_tts_num_speakers(tts.h) == 103
+    tts.taps(True)
     for k, text in enumerate(TEXTS):
         sid, speed = (50, 1.0) if k % 2 == 0 else (7, 1.25)
         assert tts.tokenize(text).tolist() == kokoro_lib.tokenize(text, d)                       # the product's tokeniser == the Python restatement
@@ -46,10 +72,16 @@ def test_synthesiser_matches_oracle_stage_by_stage(size):
         assert rate == 24000
         assert np.array_equal(tts.tap(0).astype(np.int32), r["dur"]), (size, k)                  # durations: integers, exact
         F = int(r["dur"].sum())
-        assert y.size == 600 * F - 5 == r["y"].size                                              # 600 samples per frame, centre-trimmed
-        e = {"f0": _rel(tts.tap(1), r["f0"]), "energy": _rel(tts.tap(2), r["en"]), "decoder": _rel(tts.tap(3), r["z"].ravel()), "spec": _rel(tts.tap(4), r["o"].ravel()), "wave": _rel(y, r["y"])}
-        print("kokoro %s text %d: %d tokens, %d frames, %.2f s of audio in %.2f ms on the GPU; rel rms err %s" % (size, k, r["ids"].size, F, y.size / 24000.0, tts.last_ms(), {a: "%.2g" % b for a, b in e.items()}))
-        assert all(v < TOL_STAGE for n, v in e.items() if n != "wave") and e["wave"] < TOL_WAVE, e
+        assert y.size == 600 * F == r["y"].size                                                  # 600 samples per predicted frame (2 x 10 x 6 x hop 5)
+        for what, name in ((5, "bert"), (6, "d_en"), (7, "t_en"), (1, "f0"), (2, "en"), (3, "dec")):
+            assert np.array_equal(tts.tap(what).view(np.uint32), r[name].ravel().view(np.uint32)), (size, k, name, _rel(tts.tap(what), r[name].ravel()))
+        keep, wraps = _wrap_mask(tts.tap(8).reshape(-1, 22), r["har"])
+        assert wraps <= 3 and keep.mean() > 0.5, (wraps, keep.mean())
+        keep_y = np.repeat(keep[:-1], 5)                                                          # spectrum row p covers samples 5 p .. 5 p + 4
+        e = {"source": _rel(tts.tap(8).reshape(-1, 22)[keep, :11], r["har"][keep, :11]), "spec": _rel(tts.tap(4).reshape(-1, 22)[keep], r["post"][keep]), "wave": _rel(y[keep_y], r["y"][keep_y])}
+        print("kokoro %s text %d: %d tokens, %d frames, %.2f s of audio in %.2f ms on the GPU; bit-identical through the decoder; %d phase wrap(s); rel rms err %s"
+              % (size, k, r["ids"].size, F, y.size / 24000.0, tts.last_ms(), wraps, {a: "%.2g" % b for a, b in e.items()}))
+        assert e["source"] < TOL_GEN and e["spec"] < TOL_GEN and e["wave"] < TOL_WAVE, e
         assert np.isfinite(y).all() and 1e-3 < float(np.sqrt((y ** 2).mean())) < 0.5
     with pytest.raises(RuntimeError, match="speaker id"):
         tts.generate("Hello.", 1000, 1.0)
@@ -57,6 +89,31 @@ def test_synthesiser_matches_oracle_stage_by_stage(size):
         tts.generate("Hello.", 0, 0.0)
     with pytest.raises(RuntimeError, match="no symbol of the text"):
         tts.generate("☃☃", 0, 1.0)
+    tts.taps(False)
+    y2, _ = tts.generate(TEXTS[1], 7, 1.25)                                                      # taps off: the same audio, and the previous taps stay readable
+    assert np.array_equal(y2.view(np.uint32), tts.generate(TEXTS[1], 7, 1.25)[0].view(np.uint32))      # deterministic call to call
+    tts.close()
+
+
+def test_kokoro_82m_geometry_speed():
+    """The synthesiser at Kokoro-82M's real widths (tools/make_synth_kokoro.py --size kokoro82m: 12 ALBERT passes at 768, 512-wide predictor / text encoder, 1024-wide decoder,
+    512 -> 256 -> 128 generator; seeded weights): ~30 s of speech in one call, timed with GPU events.  Too large for the CPU checker within a test run — the arithmetic is the
+    same code the micro / small sizes check against it; here the output is only checked for shape, finiteness and determinism."""
+    d = kokoro_lib.synth_kokoro_dir("kokoro82m")
+    tts = kokoro_lib.Tts(d)
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([[0], rng.integers(1, 60, 300), [0]]).astype(np.int32)
+    y, _ = tts.generate(None, 50, 1.0, ids=ids)
+    frames = y.size // 600
+    speed = float(np.clip(frames / 1200.0, 0.3, 3.0))                                          # aim at ~1200 frames = 30 s
+    best = 1e9
+    for _ in range(3):
+        y, rate = tts.generate(None, 50, speed, ids=ids); best = min(best, tts.last_ms())
+    secs = y.size / 24000.0
+    y2, _ = tts.generate(None, 50, speed, ids=ids)
+    assert np.isfinite(y).all() and y.size % 600 == 0 and 10.0 < secs <= 75.0 and np.array_equal(y.view(np.uint32), y2.view(np.uint32))
+    print("kokoro82m geometry: %d tokens -> %d frames, %.1f s of 24 kHz audio in %.1f ms on the GPU (best of 3): %.0fx real time" % (ids.size, y.size // 600, secs, best, secs * 1000.0 / best))
+    assert secs * 1000.0 / best > 20.0
     tts.close()
 
 
@@ -80,7 +137,7 @@ def test_kokoro_node_through_the_plugin_abi():
         rate, ch = C.c_uint32(), C.c_uint16(); L.mh_output_audio_format(node.h, i, C.byref(rate), C.byref(ch))
         assert o[0] == "out" and o[1] == 0 and (rate.value, ch.value) == (24000, 1)            # RawAudio{24000, 1, F32} on pin "out"
         y = np.frombuffer(o[2], np.float32); r = orc.synth(sent, 9, 1.0)
-        assert y.size == r["y"].size and _rel(y, r["y"]) < TOL_WAVE, (i, sent)
+        assert _wave_ok(y, r["y"]), (i, sent)
     tel = node.telemetry()
     assert [t[0] for t in tel] == ["tts.start", "tts.done"] * 3
     s0, d0 = tel[0][1], tel[1][1]
@@ -97,7 +154,7 @@ def test_kokoro_node_through_the_plugin_abi():
     outs = node.outputs()
     assert len(outs) == 4
     r = orc.synth("x.", 3, 1.5); y = np.frombuffer(outs[3][2], np.float32)
-    assert y.size == r["y"].size and _rel(y, r["y"]) < TOL_WAVE
+    assert _wave_ok(y, r["y"])
     assert node.telemetry()[-1][1]["speaker_id"] == 3 and node.telemetry()[-1][1]["speed"] == 1.5
     assert node.flush() == 0 and len(node.outputs()) == 4                                       # nothing left
     # errors (kokoro_node.rs:447-455)
@@ -144,7 +201,7 @@ def test_config5_whisper_small_to_kokoro_voice_agent_chain(small_model_path):
         assert o[1] == 0 and np.isfinite(y).all()
         if len(sent) <= 400:                                                                    # (the oracle's direct convolutions take a few seconds per long sentence)
             r = orc.synth(sent, 50, 1.0)
-            assert y.size == r["y"].size and _rel(y, r["y"]) < TOL_WAVE, sent[:40]
+            assert _wave_ok(y, r["y"]), sent[:40]
     done = [t[1] for t in tts.telemetry() if t[0] == "tts.done"]
     assert len(done) == len(frames) and sum(x["audio_samples"] for x in done) == total
     print("configs[4]: 30 s clip -> Whisper-small (f16_mfma) -> %d sentence(s), %d chars -> Kokoro-shaped synthesiser -> %.1f s of 24 kHz audio; chain wall time %.2f s (packet feeding included), TTS latency %s ms"

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Writes a Kokoro-shaped model directory with seeded weights (there is no kokoro-multi-lang-v1_1 offline).
+"""Writes a Kokoro model directory with seeded weights of the PUBLISHED architecture (there is no kokoro-multi-lang-v1_1 offline).
 
 The directory has the three files the reference's node insists on (kokoro_node.rs:741-758): model.onnx, voices.bin, tokens.txt — plus a small
-lexicon-us-en.txt.  model.onnx holds the initializers of the REDUCED network streamkit_amd/csrc/skw_tts.hip evaluates, by
-name, raw little-endian f32, as a protobuf encoded by hand (no `onnx` package in this image); it is not an export of Kokoro-82M.
+lexicon-us-en.txt.  model.onnx holds, as ONNX initializers (raw little-endian f32, protobuf encoded by hand: no `onnx` package in this image), every tensor
+of the network include/skw_kokoro_net.h wires up, under the PyTorch module names listed there (weight-norm pairs folded into `.weight`):
+ALBERT text encoder (one shared layer), bert_encoder, the prosody predictor's BiLSTMs / AdaLayerNorms / AdainResBlk1d stacks, the acoustic text encoder,
+the AdaIN decoder and the ISTFTNet generator.  Sizes: "kokoro82m" is Kokoro-82M's geometry (81.8 M parameters — for timing on the GPU box only);
+"micro" and "small" are the same network at reduced widths for the tests.  It is not an export of the trained model.
 voices.bin is f32 [n_speakers][510][256] like Kokoro's (one 256-float style row per token count: 128 acoustic + 128 prosody).
-Weights are scaled so that speech-like numbers come out: ~2.6 frames (65 ms) per symbol, F0 inside 60..400 Hz, waveform amplitude ~0.1.
+Weights are scaled so that speech-like numbers come out: ~2 frames per symbol, F0 around 100 - 250 Hz with unvoiced stretches, waveform amplitude ~0.1.
 
-usage: make_synth_kokoro.py OUT_DIR [--seed N] [--size micro|small] [--speakers N]
+usage: make_synth_kokoro.py OUT_DIR [--seed N] [--size micro|small|kokoro82m] [--speakers N]
 """
 import os
 import sys
@@ -17,8 +20,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_synth_silero import ld, tensor  # noqa: E402  (the hand protobuf encoder)
 
-SIZES = {"micro": dict(d=64, n_te=2, K=50, C=48, n_dec=2, G=32), "small": dict(d=256, n_te=3, K=50, C=128, n_dec=3, G=64)}
-N_SYM, U, H, STYLE = 178, 120, 8, 128
+SIZES = {
+    "micro": dict(emb=32, hid=64, ffn=128, layers=2, d=64, max_dur=50, te_depth=2, dec_c=96, asr_c=16, gen=(64, 32, 16), n_decode=2),
+    "small": dict(emb=64, hid=128, ffn=256, layers=3, d=128, max_dur=50, te_depth=3, dec_c=192, asr_c=32, gen=(128, 64, 32), n_decode=3),
+    "kokoro82m": dict(emb=128, hid=768, ffn=2048, layers=12, d=512, max_dur=50, te_depth=3, dec_c=1024, asr_c=64, gen=(512, 256, 128), n_decode=4),
+}
+N_SYM, STYLE, MAX_POS = 178, 128, 512
 SYMBOLS = "$;:,.!?-'\"() " + "abcdefghijklmnopqrstuvwxyz" + "ABCDEFGHIJKLMNOPQRSTUVWXYZ" + "0123456789" + "éèü。！？你好"
 
 
@@ -28,35 +35,109 @@ def uni(rng, shape, fan_in, gain=1.0):
 
 
 def build(seed, size):
-    g = SIZES[size]; d, C, G, K = g["d"], g["C"], g["G"], g["K"]
+    g = SIZES[size]
+    emb, hid, ffn, d, H = g["emb"], g["hid"], g["ffn"], g["d"], g["d"] // 2
+    c0, c1, c2 = g["gen"]
     rng = np.random.default_rng(seed)
     w = {}
+
+    def lin(name, n_out, n_in, gain=1.0, bias=True):
+        w[name + ".weight"] = uni(rng, (n_out, n_in), n_in, gain)
+        if bias:
+            w[name + ".bias"] = uni(rng, (n_out,), 64, 0.5)
+
+    def conv(name, c_out, c_in, k, gain=1.0, bias=True):
+        w[name + ".weight"] = uni(rng, (c_out, c_in, k), c_in * k, gain)
+        if bias:
+            w[name + ".bias"] = uni(rng, (c_out,), 64, 0.5)
+
+    def lstm(p, n_in):
+        for sfx in ("", "_reverse"):
+            w[p + "weight_ih_l0" + sfx] = uni(rng, (4 * H, n_in), n_in, 1.0)
+            w[p + "weight_hh_l0" + sfx] = uni(rng, (4 * H, H), H, 0.8)
+            w[p + "bias_ih_l0" + sfx] = uni(rng, (4 * H,), 64, 0.5)
+            w[p + "bias_hh_l0" + sfx] = uni(rng, (4 * H,), 64, 0.5)
+
+    def style_fc(name, c):
+        w[name + ".weight"] = uni(rng, (2 * c, STYLE), STYLE, 0.4)
+        w[name + ".bias"] = np.zeros(2 * c, np.float32)
+
+    def resblk(p, c_in, c_out, up):
+        style_fc(p + "norm1.fc", c_in); style_fc(p + "norm2.fc", c_out)
+        conv(p + "conv1", c_out, c_in, 3, 1.4); conv(p + "conv2", c_out, c_out, 3, 1.4)
+        if c_in != c_out:
+            conv(p + "conv1x1", c_out, c_in, 1, 1.0, bias=False)
+        if up:
+            w[p + "pool.weight"] = (np.array([0.5, 1.0, 0.5], np.float32)[None, None, :] * (1.0 + 0.1 * rng.standard_normal((c_in, 1, 1)))).astype(np.float32)
+            w[p + "pool.bias"] = np.zeros(c_in, np.float32)
+
+    def resblock1(p, c, k):
+        for j in range(3):
+            conv(p + "convs1.%d" % j, c, c, k, 0.9); conv(p + "convs2.%d" % j, c, c, k, 0.9)
+            style_fc(p + "adain1.%d.fc" % j, c); style_fc(p + "adain2.%d.fc" % j, c)
+            w[p + "alpha1.%d" % j] = (1.0 + 0.5 * rng.random(c)).astype(np.float32)
+            w[p + "alpha2.%d" % j] = (1.0 + 0.5 * rng.random(c)).astype(np.float32)
+
+    # ---- bert (ALBERT) ----
+    w["bert.embeddings.word_embeddings.weight"] = rng.standard_normal((N_SYM, emb)).astype(np.float32)
+    w["bert.embeddings.position_embeddings.weight"] = (0.3 * rng.standard_normal((MAX_POS, emb))).astype(np.float32)
+    w["bert.embeddings.token_type_embeddings.weight"] = (0.1 * rng.standard_normal((2, emb))).astype(np.float32)
+    w["bert.embeddings.LayerNorm.weight"] = (1.0 + 0.1 * rng.standard_normal(emb)).astype(np.float32)
+    w["bert.embeddings.LayerNorm.bias"] = (0.1 * rng.standard_normal(emb)).astype(np.float32)
+    lin("bert.encoder.embedding_hidden_mapping_in", hid, emb)
+    L = "bert.encoder.albert_layer_groups.0.albert_layers.0."
+    for p in ("attention.query", "attention.key", "attention.value", "attention.dense"):
+        lin(L + p, hid, hid, 1.2 if p != "attention.dense" else 0.7)
+    for p in ("attention.LayerNorm", "full_layer_layer_norm"):
+        w[L + p + ".weight"] = (1.0 + 0.1 * rng.standard_normal(hid)).astype(np.float32)
+        w[L + p + ".bias"] = (0.1 * rng.standard_normal(hid)).astype(np.float32)
+    w[L + "ffn.weight"] = uni(rng, (ffn, hid), hid, 1.0); w[L + "ffn.bias"] = uni(rng, (ffn,), 64, 0.5)
+    w[L + "ffn_output.weight"] = uni(rng, (hid, ffn), ffn, 0.7); w[L + "ffn_output.bias"] = uni(rng, (hid,), 64, 0.5)
+    w["bert.config.num_hidden_layers"] = np.array([g["layers"]], np.float32)
+    lin("bert_encoder", d, hid)
+    # ---- predictor ----
+    for i in range(3):
+        lstm("predictor.text_encoder.lstms.%d." % (2 * i), d + STYLE)
+        style_fc("predictor.text_encoder.lstms.%d.fc" % (2 * i + 1), d)
+    lstm("predictor.lstm.", d + STYLE)
+    lstm("predictor.shared.", d + STYLE)
+    # the 50 duration bins share a direction, so that a token's bins move together and durations spread over ~1 - 6 frames
+    w["predictor.duration_proj.linear_layer.weight"] = (uni(rng, (1, d), d, 4.0) + uni(rng, (g["max_dur"], d), d, 1.0)).astype(np.float32)
+    w["predictor.duration_proj.linear_layer.bias"] = np.full(g["max_dur"], -3.3, np.float32)
+    for br in ("predictor.F0.", "predictor.N."):
+        resblk(br + "0.", d, d, False); resblk(br + "1.", d, d // 2, True); resblk(br + "2.", d // 2, d // 2, False)
+    w["predictor.F0_proj.weight"] = uni(rng, (1, d // 2, 1), d // 2, 100.0); w["predictor.F0_proj.bias"] = np.array([110.0], np.float32)      # Hz; dips below 10 Hz read as unvoiced
+    w["predictor.N_proj.weight"] = uni(rng, (1, d // 2, 1), d // 2, 1.0); w["predictor.N_proj.bias"] = np.array([0.2], np.float32)
+    # ---- text encoder ----
     w["text_encoder.embedding.weight"] = rng.standard_normal((N_SYM, d)).astype(np.float32)
-    for i in range(g["n_te"]):
-        p = "text_encoder.cnn.%d." % i
-        w[p + "weight"] = uni(rng, (d, d, 5), 5 * d, 1.4); w[p + "bias"] = uni(rng, (d,), 16)
-        w[p + "norm.gamma"] = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32); w[p + "norm.beta"] = (0.1 * rng.standard_normal(d)).astype(np.float32)
-    w["predictor.text_encoder.fc.weight"] = uni(rng, (2 * d, STYLE), STYLE, 0.5); w["predictor.text_encoder.fc.bias"] = np.zeros(2 * d, np.float32)
-    w["predictor.duration_proj.weight"] = uni(rng, (K, d), d, 1.0); w["predictor.duration_proj.bias"] = np.full(K, -3.2, np.float32)
-    w["predictor.F0_proj.weight"] = uni(rng, (d,), d, 1.5); w["predictor.F0_proj.style"] = uni(rng, (STYLE,), STYLE, 1.0); w["predictor.F0_proj.bias"] = np.array([-0.6], np.float32)
-    w["predictor.N_proj.weight"] = uni(rng, (d,), d, 1.0); w["predictor.N_proj.bias"] = np.array([0.1], np.float32)
-    w["decoder.encode.weight"] = uni(rng, (C, d + 2, 3), 3 * (d + 2), 1.4); w["decoder.encode.bias"] = uni(rng, (C,), 16)
-    w["decoder.encode.fc.weight"] = uni(rng, (2 * C, STYLE), STYLE, 0.5); w["decoder.encode.fc.bias"] = np.zeros(2 * C, np.float32)
-    for i in range(g["n_dec"]):
-        p = "decoder.decode.%d." % i
-        w[p + "weight"] = uni(rng, (C, C, 3), 3 * C, 1.4); w[p + "bias"] = uni(rng, (C,), 16)
-        w[p + "fc.weight"] = uni(rng, (2 * C, STYLE), STYLE, 0.5); w[p + "fc.bias"] = np.zeros(2 * C, np.float32)
-    # generator: smooth up-sampling kernels (a raised cosine across the 120 sub-frames times a random channel mix) so the spectrum moves slowly inside a frame
-    mix = uni(rng, (C, G), C, 1.0)
-    ramp = (0.75 + 0.25 * np.cos(2 * np.pi * (np.arange(U) / U))).astype(np.float32)
-    w["decoder.generator.ups.weight"] = (mix[:, :, None] * ramp[None, None, :] + 0.02 * rng.standard_normal((C, G, U))).astype(np.float32)
-    w["decoder.generator.ups.bias"] = uni(rng, (G,), 16)
-    w["decoder.generator.source.weight"] = (uni(rng, (H, G), H, 1.0) / (1.0 + np.arange(H))[:, None]).astype(np.float32)
-    w["decoder.generator.resblock.alpha"] = (1.0 + 0.5 * rng.random(G)).astype(np.float32)
-    w["decoder.generator.resblock.weight"] = uni(rng, (G, G, 3), 3 * G, 1.0); w["decoder.generator.resblock.bias"] = np.zeros(G, np.float32)
-    post = uni(rng, (22, G, 7), 7 * G, 0.6)
-    w["decoder.generator.conv_post.weight"] = post
-    pb = np.zeros(22, np.float32); pb[:11] = -0.8 - 0.25 * np.arange(11)      # log-magnitudes falling with frequency
+    for i in range(g["te_depth"]):
+        conv("text_encoder.cnn.%d.0" % i, d, d, 5, 1.4)
+        w["text_encoder.cnn.%d.1.gamma" % i] = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+        w["text_encoder.cnn.%d.1.beta" % i] = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    lstm("text_encoder.lstm.", d)
+    # ---- decoder ----
+    conv("decoder.asr_res.0", g["asr_c"], d, 1)
+    w["decoder.F0_conv.weight"] = np.array([[[0.25, 0.5, 0.25]]], np.float32) / 200.0; w["decoder.F0_conv.bias"] = np.array([-0.6], np.float32)
+    w["decoder.N_conv.weight"] = np.array([[[0.25, 0.5, 0.25]]], np.float32); w["decoder.N_conv.bias"] = np.array([0.0], np.float32)
+    resblk("decoder.encode.", d + 2, g["dec_c"], False)
+    cat = g["dec_c"] + 2 + g["asr_c"]
+    for i in range(g["n_decode"]):
+        last = i + 1 == g["n_decode"]
+        resblk("decoder.decode.%d." % i, cat, c0 if last else g["dec_c"], last)
+    # ---- generator ----
+    for i, (ci, co, up) in enumerate(((c0, c1, 10), (c1, c2, 6))):
+        ramp = (0.5 - 0.5 * np.cos(2 * np.pi * (np.arange(2 * up) + 0.5) / (2 * up))).astype(np.float32)      # overlapping Hann ramps: smooth up-sampling
+        w["decoder.generator.ups.%d.weight" % i] = (uni(rng, (ci, co, 1), ci, 1.2) * ramp[None, None, :] + 0.02 * rng.standard_normal((ci, co, 2 * up))).astype(np.float32)
+        w["decoder.generator.ups.%d.bias" % i] = uni(rng, (co,), 64, 0.5)
+    w["decoder.generator.m_source.l_linear.weight"] = (uni(rng, (1, 9), 9, 6.0) / (1.0 + np.arange(9))[None, :]).astype(np.float32)
+    w["decoder.generator.m_source.l_linear.bias"] = np.array([0.0], np.float32)
+    conv("decoder.generator.noise_convs.0", c1, 22, 12, 0.6); conv("decoder.generator.noise_convs.1", c2, 22, 1, 0.6)
+    resblock1("decoder.generator.noise_res.0.", c1, 7); resblock1("decoder.generator.noise_res.1.", c2, 11)
+    for i in range(2):
+        for j, k in enumerate((3, 7, 11)):
+            resblock1("decoder.generator.resblocks.%d." % (3 * i + j), c2 if i else c1, k)
+    w["decoder.generator.conv_post.weight"] = uni(rng, (22, c2, 7), 7 * c2, 0.5)
+    pb = np.zeros(22, np.float32); pb[:11] = -2.2 - 0.25 * np.arange(11)      # log-magnitudes falling with frequency
     w["decoder.generator.conv_post.bias"] = pb
     return w
 
@@ -67,15 +148,16 @@ def write_dir(out, seed=1234, size="micro", speakers=103):
     graph = b"".join(ld(5, tensor(k, v)) for k, v in w.items()) + ld(2, b"skw_kokoro_synth")
     open(os.path.join(out, "model.onnx"), "wb").write(ld(7, graph))
     rng = np.random.default_rng(seed + 1)
-    base = rng.standard_normal((speakers, 1, 2 * STYLE)).astype(np.float32)
+    base = (0.3 * rng.standard_normal((speakers, 1, 2 * STYLE))).astype(np.float32)      # (Kokoro's style rows are small numbers too)
     rows = np.arange(510, dtype=np.float32)[None, :, None] / 510.0
-    drift = rng.standard_normal((speakers, 1, 2 * STYLE)).astype(np.float32) * 0.2
+    drift = rng.standard_normal((speakers, 1, 2 * STYLE)).astype(np.float32) * 0.06
     (base + drift * rows).astype("<f4").tofile(os.path.join(out, "voices.bin"))
     with open(os.path.join(out, "tokens.txt"), "w", encoding="utf-8") as f:
         for i, ch in enumerate(SYMBOLS):
             f.write("%s %d\n" % (ch, i))
     with open(os.path.join(out, "lexicon-us-en.txt"), "w", encoding="utf-8") as f:
         f.write("hello h e l o\nworld w r l d\nthe d a\nthe t h e\n")
+    return sum(v.size for v in w.values())
 
 
 if __name__ == "__main__":
@@ -85,4 +167,5 @@ if __name__ == "__main__":
     seed = int(a[a.index("--seed") + 1]) if "--seed" in a else 1234
     size = a[a.index("--size") + 1] if "--size" in a else "micro"
     spk = int(a[a.index("--speakers") + 1]) if "--speakers" in a else 103
-    write_dir(a[0], seed, size, spk)
+    n = write_dir(a[0], seed, size, spk)
+    print("%s: %.1f M parameters" % (size, n / 1e6))
