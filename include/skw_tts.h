@@ -65,6 +65,8 @@ void skw_tts_debug_enable(skw_tts*, int on);
  * 6 bert_encoder output [T][d], 7 acoustic text encoder output [T][d], 8 the source's STFT magnitude + phase [120 F + 1][22];
  * returns the element count of the last call with taps on, copies min(count, cap) */
 long skw_tts_debug_get(skw_tts*, int what, float* out, long cap);
+/* which convolution kernel the next calls use: 0 automatic, 1 untiled, 2 LDS-tiled (the same f32 chain: results are bit-identical, which a test asserts) */
+void skw_tts_debug_conv_mode(int mode);
 /* timing of the last generate (GPU events): milliseconds */
 float skw_tts_last_ms(const skw_tts*);
 

@@ -72,6 +72,89 @@ __global__ __launch_bounds__(256) void k_tts_conv(const float* x, int T, int Ci,
         for (int r = 0; r < 4; ++r) if (co + r < Co) out[(long)t * Co + co + r] = bias ? acc[n][r] + bias[co + r] : acc[n][r];
     }
 }
+// The same contraction, tiled for the long launches (the generator's 120 F rows, the decoder's 1090-wide inputs): a workgroup is 128 time steps x 64 MT output channels
+// (wave w = MT channel tiles x eight 16-step tiles).  The 128 x 32 slab of the implicit im2col matrix for k = 32 c .. 32 c + 31 is gathered ONCE per workgroup with coalesced loads
+// (lanes along k = along ci: 128-byte runs), double-buffered in LDS (row stride 36 floats: the MFMA operand read, 16 rows x 4 k per wave instruction, then touches all 64 banks
+// once), and shared by the four waves; weights go from the packed image straight to the first operand as in k_tts_conv.  Same k order, same chain: bit-identical to k_tts_conv.
+#define TTS_CT_ROWS 128
+#define TTS_CT_LDW 36
+template <int MT> __global__ __launch_bounds__(256, 2)
+void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out) {
+    __shared__ float tile[2][TTS_CT_ROWS * TTS_CT_LDW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kq = lane >> 4;
+    const int co0 = blockIdx.y * (64 * MT) + wave * (16 * MT), t0 = blockIdx.x * TTS_CT_ROWS;
+    const int Ktot = K * Ci, nk4 = (Ktot + 3) >> 2, nchunk = (nk4 + 7) >> 3;
+    const int s_kk = threadIdx.x & 31, s_r0 = threadIdx.x >> 5;
+    f32x4 acc[MT][8];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st[16];
+    auto gather = [&](int c) {      // this thread's column k = 32 c + s_kk of the slab: 16 rows
+        const int k = 32 * c + s_kk; const bool kv = k < Ktot; const int tap = kv ? k / Ci : 0, ci = k - tap * Ci; const int tb = (t0 + s_r0) * stride + tap * dil - pad;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int tt = tb + 8 * j * stride; st[j] = (kv && tt >= 0 && tt < T) ? x[(long)tt * Ci + ci] : 0.0f; }
+    };
+    auto put = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[b][(s_r0 + 8 * j) * TTS_CT_LDW + s_kk] = st[j];
+    };
+    bool mv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mv[m] = co0 + 16 * m < Co16;
+    const float* wrow = wp + ((long)co0 + i16) * 4 + kq;
+    float an[8][MT], ac[8][MT];
+    auto loadw = [&](int c) {      // chunk c's 8 x MT first operands; steps past the end of k multiply zeros (their slab columns are zero too)
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) an[k4][m] = (mv[m] && 8 * c + k4 < nk4) ? wrow[((long)(8 * c + k4) * Co16 + 16 * m) * 4] : 0.0f;
+    };
+    gather(0); loadw(0); put(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int b = c & 1;
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ac[k4][m] = an[k4][m];
+        if (c + 1 < nchunk) { gather(c + 1); loadw(c + 1); }      // the next chunk's slab column and weights are in flight under this chunk's MFMAs
+        const float* tb = &tile[b][i16 * TTS_CT_LDW + kq];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            float bb[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) bb[n] = tb[16 * n * TTS_CT_LDW + 4 * k4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k4][m], bb[n], acc[m][n], 0, 0, 0);
+        }
+        if (c + 1 < nchunk) put(b ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = co0 + 16 * m + 4 * kq;
+        if (co >= Co) continue;
+        const bool vec = co + 3 < Co && (Co & 3) == 0;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (bias && co + r < Co) ? bias[co + r] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int t = t0 + 16 * n + i16;
+            if (t >= To) continue;
+            float* o = out + (long)t * Co + co;
+            if (vec) { *(f32x4*)o = bias ? (f32x4){acc[m][n][0] + bv[0], acc[m][n][1] + bv[1], acc[m][n][2] + bv[2], acc[m][n][3] + bv[3]} : acc[m][n]; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (co + r < Co) o[r] = bias ? acc[m][n][r] + bv[r] : acc[m][n][r];
+            }
+        }
+    }
+}
 // ConvTranspose1d: out[u][co] = bias[co] + chain_{tap asc (u + pad - tap = t * stride), ci asc} w[ci][co][tap] * x[t][ci]; weights pre-transposed to [tap][ci][co]
 __global__ __launch_bounds__(256) void k_tts_convtr(const float* x, int T, int Ci, const float* wt, int Co, const float* bias, int K, int stride, int pad, int To, float* out) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x; if (idx >= (long)To * Co) return;
@@ -108,17 +191,32 @@ __global__ __launch_bounds__(256) void k_tts_ln(float* x, int C, const float* ga
     for (int c = threadIdx.x; c < C; c += 256) { const float n = (xr[c] - mu) * rstd; xr[c] = mode == 0 ? n * gamma[c] + beta[c] : n * (1.0f + gb[c]) + gb[C + c]; }
 }
 // instance norm over time, per channel: partial f64 sums of x (mean == nullptr) or of (x - mean)^2 over row chunks of 512; thread = channel (coalesced rows)
-__global__ __launch_bounds__(256) void k_tts_in_partial(const float* x, int T, int C, const double* mean, double* part) {
-    const int c = blockIdx.y * 256 + threadIdx.x; if (c >= C) return;
-    const int t0 = blockIdx.x * 512, t1 = min(T, t0 + 512); double s = 0.0;
-    if (mean) { const double m = mean[c]; for (int t = t0; t < t1; ++t) { const double u = (double)x[(long)t * C + c] - m; s += u * u; } }
-    else for (int t = t0; t < t1; ++t) s += (double)x[(long)t * C + c];
+__global__ __launch_bounds__(64) void k_tts_in_partial(const float* x, int T, int C, const double* mean, double* part) {
+    const int c = blockIdx.y * 64 + threadIdx.x; if (c >= C) return;
+    const int t0 = blockIdx.x * 512, t1 = min(T, t0 + 512); double s = 0.0; const double m = mean ? mean[c] : 0.0; const bool sq = mean != nullptr;
+    int t = t0;
+    for (; t + 16 <= t1; t += 16) {      // sixteen loads in flight, then their adds in row order (the chain of f64 adds is the contract; the loads are what it waited for)
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = x[(long)(t + j) * C + c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const double u = (double)v[j] - m; s += sq ? u * u : u; }
+    }
+    for (; t < t1; ++t) { const double u = (double)x[(long)t * C + c] - m; s += sq ? u * u : u; }
     part[(long)blockIdx.x * C + c] = s;
 }
 // chunk sums in ascending order -> mean (stage 0) or (mean as f32, rstd) (stage 1)
 __global__ void k_tts_in_final(const double* part, int nchunk, int T, int C, double* mean, float* stats, int stage) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x; if (c >= C) return;
-    double s = 0.0; for (int i = 0; i < nchunk; ++i) s += part[(long)i * C + c];
+    double s = 0.0; int i = 0;
+    for (; i + 8 <= nchunk; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(long)(i + j) * C + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; i < nchunk; ++i) s += part[(long)i * C + c];
     if (stage == 0) mean[c] = s / T; else { stats[c] = (float)mean[c]; stats[C + c] = (float)(1.0 / sqrt(s / T + (double)1e-5f)); }
 }
 __global__ void k_tts_in_apply(float* x, long n, int C, const float* stats, const float* gb) {
@@ -248,6 +346,8 @@ __global__ void k_tts_istft(const float* o, int P, float* y, long n_out) {
 }
 
 // ------------------------------------------------------------------ engine
+static int g_conv_mode = [] { const char* e = getenv("SKW_TTS_CONV"); return e ? atoi(e) : 0; }();
+extern "C" void skw_tts_debug_conv_mode(int mode) { g_conv_mode = mode; }
 struct skw_tts {
     int device = 0; hipStream_t stream = nullptr; std::mutex mu; char errbuf[512] = {0};
     Weights w; Dims g; std::vector<void*> allocs; float length_scale = 1.0f;
@@ -295,11 +395,21 @@ struct GpuBackend {
         return b;
     }
     const float* word_tab = nullptr;
+    // g_conv_mode (SKW_TTS_CONV / skw_tts_debug_conv_mode): 1 forces the untiled kernel, 2 the tiled one — both evaluate the same chain and the tests run one against the other;
+    // 0 = tiled when the launch is long enough to fill tiles
+    void launch_conv(const float* x, int T, int Ci, const float* wp, int Co, const float* bias, int K, int stride, int dil, int pad, int To, float* out) {
+        const int Co16 = (Co + 15) & ~15, mode = g_conv_mode;
+        const bool tiled = mode == 2 || (mode != 1 && To >= 256 && (long)K * Ci >= 32);
+        if (!tiled) hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+        else if (Co16 > 64)
+            hipLaunchKernelGGL(k_tts_conv_t<2>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, (Co16 + 127) / 128), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+        else
+            hipLaunchKernelGGL(k_tts_conv_t<1>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, 1), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+    }
     Buf conv(const Buf& x, const Tensor& w, const Tensor* bias, int K, int stride, int dil, int pad) {
-        const int Co = (int)w.dims[0], Ci = (int)w.dims[1], Co16 = (Co + 15) & ~15, To = (x.T + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+        const int Co = (int)w.dims[0], Ci = (int)w.dims[1], To = (x.T + 2 * pad - dil * (K - 1) - 1) / stride + 1;
         Buf o = make(To, Co);
-        if (o.p) hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x.p, x.T, Ci, (const float*)w.packed, Co, Co16,
-            bias ? dev(*bias) : nullptr, K, stride, dil, pad, To, o.p);
+        if (o.p) launch_conv(x.p, x.T, Ci, (const float*)w.packed, Co, bias ? dev(*bias) : nullptr, K, stride, dil, pad, To, o.p);
         return o;
     }
     Buf convtr(const Buf& x, const Tensor& w, const Tensor* bias, int K, int stride, int pad, int out_pad, bool depthwise) {
@@ -318,13 +428,13 @@ struct GpuBackend {
     }
     void ada_ln(Buf& x, const Buf& gb) { hipLaunchKernelGGL(k_tts_ln, dim3(x.T), dim3(256), 0, s, x.p, x.C, (const float*)nullptr, (const float*)nullptr, gb.p, 1, 1e-5f); }
     void ada_in(Buf& x, const Buf& gb) {
-        const int nchunk = (x.T + 511) / 512; const dim3 grid(nchunk, (x.C + 255) / 256);
+        const int nchunk = (x.T + 511) / 512; const dim3 grid(nchunk, (x.C + 63) / 64);
         double* part = (double*)arena_get(t, sizeof(double) * (size_t)nchunk * x.C);
         double* mean = (double*)arena_get(t, sizeof(double) * x.C); float* stats = (float*)arena_get(t, sizeof(float) * 2 * x.C);
         if (!part || !mean || !stats) return;
-        hipLaunchKernelGGL(k_tts_in_partial, grid, dim3(256), 0, s, x.p, x.T, x.C, (const double*)nullptr, part);
+        hipLaunchKernelGGL(k_tts_in_partial, grid, dim3(64), 0, s, x.p, x.T, x.C, (const double*)nullptr, part);
         hipLaunchKernelGGL(k_tts_in_final, dim3((x.C + 255) / 256), dim3(256), 0, s, part, nchunk, x.T, x.C, mean, stats, 0);
-        hipLaunchKernelGGL(k_tts_in_partial, grid, dim3(256), 0, s, x.p, x.T, x.C, (const double*)mean, part);
+        hipLaunchKernelGGL(k_tts_in_partial, grid, dim3(64), 0, s, x.p, x.T, x.C, (const double*)mean, part);
         hipLaunchKernelGGL(k_tts_in_final, dim3((x.C + 255) / 256), dim3(256), 0, s, part, nchunk, x.T, x.C, mean, stats, 1);
         const long n = (long)x.T * x.C;
         hipLaunchKernelGGL(k_tts_in_apply, dim3(blocks(n)), dim3(256), 0, s, x.p, n, x.C, stats, gb.p);
@@ -359,10 +469,9 @@ struct GpuBackend {
         // W_ih x + b_ih for every step at once, on the matrix cores (the [4H][In] weight viewed as a k = 1 convolution)
         Buf xp[2];
         for (int dir = 0; dir < 2; ++dir) {
-            const Tensor& wih = *ws[4 * dir]; const int G4 = (int)wih.dims[0], In = (int)wih.dims[1], Co16 = (G4 + 15) & ~15;
+            const Tensor& wih = *ws[4 * dir]; const int G4 = (int)wih.dims[0], In = (int)wih.dims[1];
             xp[dir] = make(x.T, G4);
-            if (xp[dir].p) hipLaunchKernelGGL(k_tts_conv, dim3((x.T + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x.p, x.T, In, (const float*)wih.packed, G4, Co16,
-                dev(*ws[4 * dir + 2]), 1, 1, 1, 0, x.T, xp[dir].p);
+            if (xp[dir].p) launch_conv(x.p, x.T, In, (const float*)wih.packed, G4, dev(*ws[4 * dir + 2]), 1, 1, 1, 0, x.T, xp[dir].p);
         }
         if (o.p && xp[0].p && xp[1].p)
             hipLaunchKernelGGL(k_tts_lstm, dim3(2), dim3(1024), sizeof(float) * 5 * H, s, xp[0].p, xp[1].p, (const float*)ws[1]->packed, (const float*)ws[5]->packed,
