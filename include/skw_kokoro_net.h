@@ -51,7 +51,7 @@ enum { STYLE_DIM = 128, N_FFT = 20, HOP = 5, N_BINS = 11, N_HARM = 9, SAMPLE_RAT
 enum Act { ACT_LEAKY02 = 0, ACT_LEAKY01 = 1, ACT_LEAKY001 = 2, ACT_GELU = 3, ACT_SNAKE = 4 };
 
 /* a weight as the backends see it: host copy of the file's tensor + whatever the backend attached (device pointer, packed image) */
-struct Tensor { std::vector<int64_t> dims; std::vector<float> host; void* dev = nullptr; void* packed = nullptr; long n() const { return (long)host.size(); } };
+struct Tensor { std::vector<int64_t> dims; std::vector<float> host; void* dev = nullptr; void* packed = nullptr; void* packed2 = nullptr; long n() const { return (long)host.size(); } };
 typedef std::map<std::string, Tensor> Weights;
 
 /* geometry, derived from tensor shapes (check() fills it and names the first missing / mis-shaped tensor) */

@@ -67,6 +67,8 @@ void skw_tts_debug_enable(skw_tts*, int on);
 long skw_tts_debug_get(skw_tts*, int what, float* out, long cap);
 /* which convolution kernel the next calls use: 0 automatic, 1 untiled, 2 LDS-tiled (the same f32 chain: results are bit-identical, which a test asserts) */
 void skw_tts_debug_conv_mode(int mode);
+/* which LSTM kernel: 0 automatic, 1 one workgroup per direction, 2 H / 32 workgroups per direction with the recurrent weights resident in LDS (bit-identical, asserted by a test) */
+void skw_tts_debug_lstm_mode(int mode);
 /* timing of the last generate (GPU events): milliseconds */
 float skw_tts_last_ms(const skw_tts*);
 

@@ -33,11 +33,13 @@ __device__ const double TWC[N_FFT] = SKW_KOKORO_TW_COS, TWS[N_FFT] = SKW_KOKORO_
 __device__ __forceinline__ float sigmoid_e(float v) { return 1.0f / (1.0f + skw_expf(-v)); }
 __device__ __forceinline__ float tanh_e(float v) { const float e = skw_expf(2.0f * v); return 1.0f - 2.0f / (e + 1.0f); }
 
-// conv / linear on the matrix cores.  out[t][co] = bias[co] + chain_{tap, ci} w[co][ci][tap] * x[t * stride + tap * dil - pad][ci].
+// conv / linear on the matrix cores.  out[t * os + oo][co] = bias[co] + chain_{tap, ci} w[co][ci][tap] * x[t * stride + tap * dil - pad][ci]   (os = 1, oo = 0 for a convolution; a
+// ConvTranspose1d is `stride` such launches, one per output phase, with dil = -1: see GpuBackend::convtr).
 // Weights arrive packed as [k / 4][Co padded to 16][4] with k = tap * Ci + ci (zero padded to a multiple of 4): lane (i = lane & 15, kq = lane >> 4) of the MFMA's first
 // operand is one coalesced float.  A workgroup is 64 output channels x 64 time steps, wave w = channel tile w x four 16-step tiles; a lane ends with 4 adjacent
 // channels of one step: one 16-byte store.  The gather of x is plain loads (activations are small and L2-resident; the network's weights stream once per launch).
-__global__ __launch_bounds__(256) void k_tts_conv(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out) {
+__global__ __launch_bounds__(256)
+void k_tts_conv(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out, int os, int oo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kq = lane >> 4;
     const int co0 = blockIdx.y * 64 + wave * 16, t0 = blockIdx.x * 64;
     if (co0 >= Co16) return;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_tts_conv(const float* x, int T, int Ci,
         const int t = t0 + 16 * n + i16;
         if (t >= To) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (co + r < Co) out[(long)t * Co + co + r] = bias ? acc[n][r] + bias[co + r] : acc[n][r];
+        for (int r = 0; r < 4; ++r) if (co + r < Co) out[((long)t * os + oo) * Co + co + r] = bias ? acc[n][r] + bias[co + r] : acc[n][r];
     }
 }
 // The same contraction, tiled for the long launches (the generator's 120 F rows, the decoder's 1090-wide inputs): a workgroup is 128 time steps x 64 MT output channels
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void k_tts_conv(const float* x, int T, int Ci,
 #define TTS_CT_ROWS 128
 #define TTS_CT_LDW 36
 template <int MT> __global__ __launch_bounds__(256, 2)
-void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out) {
+void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out, int os, int oo) {
     __shared__ float tile[2][TTS_CT_ROWS * TTS_CT_LDW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kq = lane >> 4;
     const int co0 = blockIdx.y * (64 * MT) + wave * (16 * MT), t0 = blockIdx.x * TTS_CT_ROWS;
@@ -146,7 +148,7 @@ void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co
         for (int n = 0; n < 8; ++n) {
             const int t = t0 + 16 * n + i16;
             if (t >= To) continue;
-            float* o = out + (long)t * Co + co;
+            float* o = out + ((long)t * os + oo) * Co + co;
             if (vec) { *(f32x4*)o = bias ? (f32x4){acc[m][n][0] + bv[0], acc[m][n][1] + bv[1], acc[m][n][2] + bv[2], acc[m][n][3] + bv[3]} : acc[m][n]; }
             else {
 #pragma unroll
@@ -295,6 +297,55 @@ __global__ __launch_bounds__(1024) void k_tts_lstm(const float* xp_f, const floa
         __syncthreads();
     }
 }
+// The same recurrence spread over H / 32 workgroups per direction, each on its own CU: workgroup j keeps the four gate rows of hidden units 32 j .. 32 j + 31 — its 128 x H slice of
+// the recurrent weight — in LDS for the whole sequence (128 KiB at H = 256), so a step reads no weight from L2 (k_tts_lstm re-reads the full 1 MiB per step through ONE CU's load path:
+// ~9 us per step).  A step's h slices meet through global memory: 32 stores, a release fence, one atomic add on the direction's counter; the others poll it, then read h with
+// device-scope loads into LDS.  h buffers alternate by step parity (a workgroup cannot run two steps ahead: it needs everyone's step s to start s + 1).  Thread = (gate, unit):
+// the same k-ascending chain over h as k_tts_lstm, so results are bit-identical.  Every wait is bounded: a poll that outlasts ~2 s raises `err` and the workgroup stops waiting.
+__global__ __launch_bounds__(128) void k_tts_lstm_mw(const float* xp_f, const float* xp_r, const float* whhT_f, const float* whhT_r, const float* bhh_f, const float* bhh_r, int T, int H, float* out,
+                                                     unsigned* hbuf, unsigned* cnt, int* err) {
+    extern __shared__ float ls[];      // w [H / 4][128][4] | h [H] | a [128]
+    float* w = ls; float* hs = ls + (size_t)H * 128; float* as = hs + H;
+    const int NW = H / 32, dir = blockIdx.x / NW, j = blockIdx.x % NW, tid = threadIdx.x, g = tid >> 5, u = tid & 31, G4 = 4 * H, gi = g * H + 32 * j + u;
+    const float* xp = dir ? xp_r : xp_f; const float* whhT = dir ? whhT_r : whhT_f; const float bh = (dir ? bhh_r : bhh_f)[gi];
+    for (int k = 0; k < H; ++k) w[((k >> 2) * 128 + tid) * 4 + (k & 3)] = whhT[(long)k * G4 + gi];
+    for (int k = tid; k < H; k += 128) hs[k] = 0.0f;
+    float c = 0.0f; bool dead = false;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        const float xv = xp[(long)t * G4 + gi];
+        float acc = 0.0f;
+        for (int k4 = 0; k4 < (H >> 2); ++k4) {
+            const f32x4 wv = *(const f32x4*)&w[(k4 * 128 + tid) * 4], hv = *(const f32x4*)&hs[4 * k4];
+            acc = __builtin_fmaf(wv[0], hv[0], acc); acc = __builtin_fmaf(wv[1], hv[1], acc); acc = __builtin_fmaf(wv[2], hv[2], acc); acc = __builtin_fmaf(wv[3], hv[3], acc);
+        }
+        as[tid] = (xv + acc) + bh;
+        __syncthreads();
+        if (tid < 32) {
+            const float ig = sigmoid_e(as[u]), fg = sigmoid_e(as[32 + u]), gg = tanh_e(as[64 + u]), og = sigmoid_e(as[96 + u]);
+            c = (fg * c) + (ig * gg); const float hv = og * tanh_e(c);
+            out[(long)t * 2 * H + dir * H + 32 * j + u] = hv;
+            if (s + 1 < T) {
+                __hip_atomic_store(&hbuf[((s & 1) * 2 + dir) * H + 32 * j + u], __float_as_uint(hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                if (tid == 0) __hip_atomic_fetch_add(&cnt[dir], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (s + 1 < T) {
+            if (tid == 0 && !dead) {
+                const unsigned target = (unsigned)NW * (unsigned)(s + 1); long spins = 0;
+                while (__hip_atomic_load(&cnt[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (++spins > (1L << 25)) { *err = 1; dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < H; k += 128) hs[k] = __uint_as_float(__hip_atomic_load(&hbuf[((s & 1) * 2 + dir) * H + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __syncthreads();
+        }
+    }
+}
 __global__ void k_tts_durations(const float* lg, int T, int K, float scale, int* dur) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= T) return;
     double s = 0.0; for (int k = 0; k < K; ++k) s += (double)sigmoid_e(lg[(long)t * K + k]);
@@ -347,7 +398,9 @@ __global__ void k_tts_istft(const float* o, int P, float* y, long n_out) {
 
 // ------------------------------------------------------------------ engine
 static int g_conv_mode = [] { const char* e = getenv("SKW_TTS_CONV"); return e ? atoi(e) : 0; }();
+static int g_lstm_mode = [] { const char* e = getenv("SKW_TTS_LSTM"); return e ? atoi(e) : 0; }();      // 0 automatic, 1 one workgroup per direction, 2 H / 32 workgroups per direction
 extern "C" void skw_tts_debug_conv_mode(int mode) { g_conv_mode = mode; }
+extern "C" void skw_tts_debug_lstm_mode(int mode) { g_lstm_mode = mode; }
 struct skw_tts {
     int device = 0; hipStream_t stream = nullptr; std::mutex mu; char errbuf[512] = {0};
     Weights w; Dims g; std::vector<void*> allocs; float length_scale = 1.0f;
@@ -355,6 +408,7 @@ struct skw_tts {
     TtsText text;
     // scratch arena: chunks kept for the engine's life, bump-allocated per call (a call's buffers are all live until it ends)
     struct Chunk { char* p; size_t cap; }; std::vector<Chunk> chunks; size_t cur_chunk = 0, cur_off = 0; bool arena_failed = false;
+    unsigned* lstm_sync = nullptr;      // [4 H] h exchange (two step parities x two directions) | [2] arrival counters | [1] error flag
     bool taps_on = false; std::vector<float> dbg[9]; float last_ms = 0.0f;
 };
 static void* dev_upload(skw_tts* t, const void* h, size_t bytes) {
@@ -397,14 +451,14 @@ struct GpuBackend {
     const float* word_tab = nullptr;
     // g_conv_mode (SKW_TTS_CONV / skw_tts_debug_conv_mode): 1 forces the untiled kernel, 2 the tiled one — both evaluate the same chain and the tests run one against the other;
     // 0 = tiled when the launch is long enough to fill tiles
-    void launch_conv(const float* x, int T, int Ci, const float* wp, int Co, const float* bias, int K, int stride, int dil, int pad, int To, float* out) {
+    void launch_conv(const float* x, int T, int Ci, const float* wp, int Co, const float* bias, int K, int stride, int dil, int pad, int To, float* out, int os = 1, int oo = 0) {
         const int Co16 = (Co + 15) & ~15, mode = g_conv_mode;
         const bool tiled = mode == 2 || (mode != 1 && To >= 256 && (long)K * Ci >= 32);
-        if (!tiled) hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+        if (!tiled) hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
         else if (Co16 > 64)
-            hipLaunchKernelGGL(k_tts_conv_t<2>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, (Co16 + 127) / 128), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+            hipLaunchKernelGGL(k_tts_conv_t<2>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, (Co16 + 127) / 128), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
         else
-            hipLaunchKernelGGL(k_tts_conv_t<1>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, 1), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out);
+            hipLaunchKernelGGL(k_tts_conv_t<1>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, 1), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
     }
     Buf conv(const Buf& x, const Tensor& w, const Tensor* bias, int K, int stride, int dil, int pad) {
         const int Co = (int)w.dims[0], Ci = (int)w.dims[1], To = (x.T + 2 * pad - dil * (K - 1) - 1) / stride + 1;
@@ -412,12 +466,26 @@ struct GpuBackend {
         if (o.p) launch_conv(x.p, x.T, Ci, (const float*)w.packed, Co, bias ? dev(*bias) : nullptr, K, stride, dil, pad, To, o.p);
         return o;
     }
+    // ConvTranspose1d.  Output u takes the taps with (u + pad - tap) % stride == 0, ascending — for phase f = (u + pad) % stride that is tap = f + m stride with x row q - m,
+    // q = (u + pad) / stride: a convolution over q with K / stride taps walking BACKWARDS (dil = -1), writing every stride-th output row.  So the matrix cores run it as `stride`
+    // launches of the convolution kernel on per-phase weight images (upload_weights: [m * Ci + ci] from w[ci][co][f + m stride]); the chain order (tap, then ci) is unchanged.
     Buf convtr(const Buf& x, const Tensor& w, const Tensor* bias, int K, int stride, int pad, int out_pad, bool depthwise) {
         const int Ci = (int)w.dims[0], Co = depthwise ? Ci : (int)w.dims[1], To = (x.T - 1) * stride - 2 * pad + K + out_pad;
         Buf o = make(To, Co);
         if (!o.p) return o;
-        if (depthwise) hipLaunchKernelGGL(k_tts_convtr_dw, dim3(blocks((long)To * Co)), dim3(256), 0, s, x.p, x.T, Ci, dev(w), bias ? dev(*bias) : nullptr, K, stride, pad, To, o.p);
-        else hipLaunchKernelGGL(k_tts_convtr, dim3(blocks((long)To * Co)), dim3(256), 0, s, x.p, x.T, Ci, (const float*)w.packed, Co, bias ? dev(*bias) : nullptr, K, stride, pad, To, o.p);
+        const float* bp = bias ? dev(*bias) : nullptr;
+        if (depthwise) { hipLaunchKernelGGL(k_tts_convtr_dw, dim3(blocks((long)To * Co)), dim3(256), 0, s, x.p, x.T, Ci, dev(w), bp, K, stride, pad, To, o.p); return o; }
+        if (g_conv_mode == 1 || !w.packed2 || K != 2 * stride) {
+            hipLaunchKernelGGL(k_tts_convtr, dim3(blocks((long)To * Co)), dim3(256), 0, s, x.p, x.T, Ci, (const float*)w.packed, Co, bp, K, stride, pad, To, o.p);
+            return o;
+        }
+        const int Co16 = (Co + 15) & ~15, taps = K / stride; const size_t img = (size_t)((taps * Ci + 3) / 4) * Co16 * 4;
+        for (int f = 0; f < stride; ++f) {
+            const int q0 = (pad - f + stride - 1) / stride > 0 ? (pad - f + stride - 1) / stride : 0;      // first q with u = q stride + f - pad >= 0
+            const int u0 = q0 * stride + f - pad; if (u0 >= To) continue;
+            const int rows = (To - 1 - u0) / stride + 1;
+            launch_conv(x.p, x.T, Ci, (const float*)w.packed2 + (size_t)f * img, Co, bp, taps, 1, -1, -q0, rows, o.p, stride, u0);
+        }
         return o;
     }
     void layernorm(Buf& x, const Tensor& g, const Tensor& b, float eps) { hipLaunchKernelGGL(k_tts_ln, dim3(x.T), dim3(256), 0, s, x.p, x.C, dev(g), dev(b), (const float*)nullptr, 0, eps); }
@@ -473,9 +541,17 @@ struct GpuBackend {
             xp[dir] = make(x.T, G4);
             if (xp[dir].p) launch_conv(x.p, x.T, In, (const float*)wih.packed, G4, dev(*ws[4 * dir + 2]), 1, 1, 1, 0, x.T, xp[dir].p);
         }
-        if (o.p && xp[0].p && xp[1].p)
+        if (!o.p || !xp[0].p || !xp[1].p) return o;
+        const bool multi = g_lstm_mode == 2 || (g_lstm_mode != 1 && H % 32 == 0 && x.T >= 8);
+        if (!multi)
             hipLaunchKernelGGL(k_tts_lstm, dim3(2), dim3(1024), sizeof(float) * 5 * H, s, xp[0].p, xp[1].p, (const float*)ws[1]->packed, (const float*)ws[5]->packed,
                 dev(*ws[3]), dev(*ws[7]), x.T, H, o.p);
+        else {
+            unsigned* cnt = t->lstm_sync + 4 * t->g.H;
+            hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), s);
+            hipLaunchKernelGGL(k_tts_lstm_mw, dim3(2 * (H / 32)), dim3(128), sizeof(float) * ((size_t)H * 128 + H + 128), s, xp[0].p, xp[1].p, (const float*)ws[1]->packed,
+                (const float*)ws[5]->packed, dev(*ws[3]), dev(*ws[7]), x.T, H, o.p, t->lstm_sync, cnt, (int*)(cnt + 2));
+        }
         return o;
     }
     Buf gather_rows(const Buf& x, const std::vector<int>& rows) {
@@ -516,6 +592,14 @@ static bool upload_weights(skw_tts* t, std::string* err) {
         const bool is_hh = n.find("weight_hh_l0") != std::string::npos;
         const bool is_pool = n.find("pool.weight") != std::string::npos;
         std::vector<float> img;
+        if (is_tr && w.dims[2] % 2 == 0) {      // the matrix-core form: one image per output phase, stride = K / 2 (Kokoro's up-sampling layers: k = 2 x stride)
+            const int64_t Ci = w.dims[0], Co = w.dims[1], K = w.dims[2], st = K / 2, Co16 = (Co + 15) & ~15, nk4 = (2 * Ci + 3) / 4;
+            std::vector<float> ph((size_t)(st * nk4 * Co16 * 4), 0.0f);
+            for (int64_t f = 0; f < st; ++f) for (int64_t m = 0; m < 2; ++m) for (int64_t ci = 0; ci < Ci; ++ci) for (int64_t co = 0; co < Co; ++co) {
+                const int64_t kk = m * Ci + ci; ph[(size_t)(((f * nk4 + (kk >> 2)) * Co16 + co) * 4 + (kk & 3))] = w.host[(size_t)((ci * Co + co) * K + f + m * st)]; }
+            w.packed2 = dev_upload(t, ph.data(), ph.size() * sizeof(float));
+            if (!w.packed2) { *err = "device allocation failed for '" + n + "'"; return false; }
+        }
         if (is_tr) {
             const int64_t Ci = w.dims[0], Co = w.dims[1], K = w.dims[2]; img.resize(w.host.size());
             for (int64_t ci = 0; ci < Ci; ++ci) for (int64_t co = 0; co < Co; ++co) for (int64_t k = 0; k < K; ++k) img[(size_t)((k * Ci + ci) * Co + co)] = w.host[(size_t)((ci * Co + co) * K + k)];
@@ -554,6 +638,13 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
     if (t->g.H > 256) return fail("model file: LSTM width above 256 per direction is not supported (one workgroup holds a direction's gates)");
     for (auto& kv : t->text.sym2id) if (kv.second < 0 || kv.second >= t->g.n_sym) return fail("tokens file names an id outside the embedding table");
     if (!upload_weights(t, &e)) return fail(e);
+    {   // the multi-workgroup LSTM's exchange buffers, and its LDS size (a 128 x H weight slice: over the 64 KiB default)
+        std::vector<unsigned> z((size_t)4 * t->g.H + 3, 0u);
+        t->lstm_sync = (unsigned*)dev_upload(t, z.data(), z.size() * sizeof(unsigned));
+        if (!t->lstm_sync) return fail("device allocation failed for the LSTM exchange buffers");
+        if (hipFuncSetAttribute((const void*)k_tts_lstm_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ((size_t)t->g.H * 128 + t->g.H + 128))) != hipSuccess)
+            return fail("hipFuncSetAttribute failed for the LSTM kernel");
+    }
     {   // voices.bin: f32 [n_spk][rows][256]; rows = 510 in Kokoro's files
         std::vector<uint8_t> vb; if (!read_file(cfg->voices, &vb, (size_t)1024 << 20)) return fail(std::string("cannot read voices file ") + cfg->voices);
         const size_t row = 2 * STYLE_DIM * 4; if (vb.size() < row || vb.size() % row) return fail("voices file: size is not a multiple of 256 floats");
@@ -618,6 +709,8 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
         || hipGetLastError() != hipSuccess) {
         free(host); return fail("synthesis kernels failed"); }
     hipEventElapsedTime(&t->last_ms, ev.a, ev.b);
+    {   int lstm_err = 0; hipMemcpy(&lstm_err, t->lstm_sync + 4 * t->g.H + 2, sizeof(int), hipMemcpyDeviceToHost);
+        if (lstm_err) { hipMemset(t->lstm_sync + 4 * t->g.H + 2, 0, sizeof(int)); free(host); return fail("LSTM workgroups timed out waiting for each other (GPU oversubscribed?)"); } }
     if (t->taps_on) {      // stage taps for the parity tests (skw_tts_debug_enable): 0 durations, 1 F0, 2 N, 3 decoder output, 4 spectrum + phase, 5 bert, 6 d_en, 7 t_en, 8 source STFT
         auto grab = [&](int k, const GpuBackend::Buf& b) { t->dbg[k].resize((size_t)b.T * b.C); hipMemcpy(t->dbg[k].data(), b.p, sizeof(float) * t->dbg[k].size(), hipMemcpyDeviceToHost); };
         t->dbg[0].assign(out.dur.begin(), out.dur.end());

@@ -135,7 +135,7 @@ def tts_lib():
     L.skw_tts_debug_get.restype = C.c_long; L.skw_tts_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
     L.skw_tts_last_ms.restype = C.c_float; L.skw_tts_last_ms.argtypes = [C.c_void_p]
     L.skw_tts_generate_ids.restype = C.POINTER(_Audio); L.skw_tts_generate_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float]
-    L.skw_tts_debug_enable.argtypes = [C.c_void_p, C.c_int]; L.skw_tts_debug_conv_mode.argtypes = [C.c_int]
+    L.skw_tts_debug_enable.argtypes = [C.c_void_p, C.c_int]; L.skw_tts_debug_conv_mode.argtypes = [C.c_int]; L.skw_tts_debug_lstm_mode.argtypes = [C.c_int]
     return L
 
 

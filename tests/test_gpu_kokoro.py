@@ -96,19 +96,20 @@ def test_synthesiser_matches_oracle_stage_by_stage(size):
 
 
 @pytest.mark.parametrize("size", ["micro", "small"])
-def test_tiled_and_untiled_convolutions_are_bit_identical(size):
-    """k_tts_conv (one gather per lane) and k_tts_conv_t (128-step slabs through LDS) evaluate the same k-ascending chain: forced one way and the other, every tap and the waveform
-    must agree bit for bit (the automatic choice mixes them by launch size, so the checker comparison above covers the mix)."""
+def test_kernel_variants_are_bit_identical(size):
+    """k_tts_conv (one gather per lane) and k_tts_conv_t (128-step slabs through LDS), k_tts_lstm (one workgroup per direction) and k_tts_lstm_mw (H / 32 workgroups per direction,
+    weights resident in LDS, h exchanged through memory) evaluate the same k-ascending chains: forced one way and the other, every tap and the waveform must agree bit for bit
+    (the automatic choice mixes them by launch size, so the checker comparison above covers the mix)."""
     d = kokoro_lib.synth_kokoro_dir(size)
     tts = kokoro_lib.Tts(d); tts.taps(True)
     got = {}
     try:
         for mode in (1, 2):
-            tts.L.skw_tts_debug_conv_mode(mode)
+            tts.L.skw_tts_debug_conv_mode(mode); tts.L.skw_tts_debug_lstm_mode(mode)
             y, _ = tts.generate(TEXTS[3], 7, 1.25)
             got[mode] = [y] + [tts.tap(k) for k in range(9)]
     finally:
-        tts.L.skw_tts_debug_conv_mode(0)
+        tts.L.skw_tts_debug_conv_mode(0); tts.L.skw_tts_debug_lstm_mode(0)
     for a, b in zip(got[1], got[2]):
         assert a.size == b.size and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     tts.close()
