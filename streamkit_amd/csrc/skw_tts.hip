@@ -74,33 +74,34 @@ void k_tts_conv(const float* x, int T, int Ci, const float* wp, int Co, int Co16
         for (int r = 0; r < 4; ++r) if (co + r < Co) out[((long)t * os + oo) * Co + co + r] = bias ? acc[n][r] + bias[co + r] : acc[n][r];
     }
 }
-// The same contraction, tiled for the long launches (the generator's 120 F rows, the decoder's 1090-wide inputs): a workgroup is 128 time steps x 64 MT output channels
-// (wave w = MT channel tiles x eight 16-step tiles).  The 128 x 32 slab of the implicit im2col matrix for k = 32 c .. 32 c + 31 is gathered ONCE per workgroup with coalesced loads
+// The same contraction, tiled for the long launches (the generator's 120 F rows, the decoder's 1090-wide inputs): a workgroup is 16 NT time steps x 64 MT output channels
+// (wave w = MT channel tiles x NT 16-step tiles; NT = 8, MT = 2 for the long launches, smaller tiles when the launch would otherwise leave CUs idle).  The 16 NT x 32 slab of the
+//  implicit im2col matrix for k = 32 c .. 32 c + 31 is gathered ONCE per workgroup with coalesced loads
 // (lanes along k = along ci: 128-byte runs), double-buffered in LDS (row stride 36 floats: the MFMA operand read, 16 rows x 4 k per wave instruction, then touches all 64 banks
 // once), and shared by the four waves; weights go from the packed image straight to the first operand as in k_tts_conv.  Same k order, same chain: bit-identical to k_tts_conv.
-#define TTS_CT_ROWS 128
 #define TTS_CT_LDW 36
-template <int MT> __global__ __launch_bounds__(256, 2)
+template <int MT, int NT> __global__ __launch_bounds__(256, 2)
 void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil, int pad, int To, float* out, int os, int oo) {
-    __shared__ float tile[2][TTS_CT_ROWS * TTS_CT_LDW];
+    constexpr int ROWS = 16 * NT, NG = 2 * NT;      // rows of the slab; rows each staging thread gathers
+    __shared__ float tile[2][ROWS * TTS_CT_LDW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kq = lane >> 4;
-    const int co0 = blockIdx.y * (64 * MT) + wave * (16 * MT), t0 = blockIdx.x * TTS_CT_ROWS;
+    const int co0 = blockIdx.y * (64 * MT) + wave * (16 * MT), t0 = blockIdx.x * ROWS;
     const int Ktot = K * Ci, nk4 = (Ktot + 3) >> 2, nchunk = (nk4 + 7) >> 3;
     const int s_kk = threadIdx.x & 31, s_r0 = threadIdx.x >> 5;
-    f32x4 acc[MT][8];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float st[16];
-    auto gather = [&](int c) {      // this thread's column k = 32 c + s_kk of the slab: 16 rows
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st[NG];
+    auto gather = [&](int c) {      // this thread's column k = 32 c + s_kk of the slab: NG rows
         const int k = 32 * c + s_kk; const bool kv = k < Ktot; const int tap = kv ? k / Ci : 0, ci = k - tap * Ci; const int tb = (t0 + s_r0) * stride + tap * dil - pad;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const int tt = tb + 8 * j * stride; st[j] = (kv && tt >= 0 && tt < T) ? x[(long)tt * Ci + ci] : 0.0f; }
+        for (int j = 0; j < NG; ++j) { const int tt = tb + 8 * j * stride; st[j] = (kv && tt >= 0 && tt < T) ? x[(long)tt * Ci + ci] : 0.0f; }
     };
     auto put = [&](int b) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tile[b][(s_r0 + 8 * j) * TTS_CT_LDW + s_kk] = st[j];
+        for (int j = 0; j < NG; ++j) tile[b][(s_r0 + 8 * j) * TTS_CT_LDW + s_kk] = st[j];
     };
     bool mv[MT];
 #pragma unroll
@@ -125,13 +126,13 @@ void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co
         const float* tb = &tile[b][i16 * TTS_CT_LDW + kq];
 #pragma unroll
         for (int k4 = 0; k4 < 8; ++k4) {
-            float bb[8];
+            float bb[NT];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) bb[n] = tb[16 * n * TTS_CT_LDW + 4 * k4];
+            for (int n = 0; n < NT; ++n) bb[n] = tb[16 * n * TTS_CT_LDW + 4 * k4];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 8; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k4][m], bb[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k4][m], bb[n], acc[m][n], 0, 0, 0);
         }
         if (c + 1 < nchunk) put(b ^ 1);
         __syncthreads();
@@ -145,7 +146,7 @@ void k_tts_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = (bias && co + r < Co) ? bias[co + r] : 0.0f;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const int t = t0 + 16 * n + i16;
             if (t >= To) continue;
             float* o = out + ((long)t * os + oo) * Co + co;
@@ -299,11 +300,12 @@ __global__ __launch_bounds__(1024) void k_tts_lstm(const float* xp_f, const floa
 }
 // The same recurrence spread over H / 32 workgroups per direction, each on its own CU: workgroup j keeps the four gate rows of hidden units 32 j .. 32 j + 31 — its 128 x H slice of
 // the recurrent weight — in LDS for the whole sequence (128 KiB at H = 256), so a step reads no weight from L2 (k_tts_lstm re-reads the full 1 MiB per step through ONE CU's load path:
-// ~9 us per step).  A step's h slices meet through global memory: 32 stores, a release fence, one atomic add on the direction's counter; the others poll it, then read h with
-// device-scope loads into LDS.  h buffers alternate by step parity (a workgroup cannot run two steps ahead: it needs everyone's step s to start s + 1).  Thread = (gate, unit):
-// the same k-ascending chain over h as k_tts_lstm, so results are bit-identical.  Every wait is bounded: a poll that outlasts ~2 s raises `err` and the workgroup stops waiting.
+// ~9 us per step).  A step's h slices meet through global memory with ONE round trip each way: a unit's h is stored as a 64-bit word {launch epoch : step + 1, h} (single-copy atomic),
+// and the consumers poll the words they need until the tag is this step's — no counter, no fence.  Buffers alternate by step parity (a workgroup cannot run two steps ahead: it needs
+// everyone's step s to start s + 1).  Thread = (gate, unit): the same k-ascending chain over h as k_tts_lstm, so results are bit-identical.  Every wait is bounded: a poll that
+// outlasts ~1 s raises `err`, and every later wait of every workgroup gives up as soon as it sees the flag.
 __global__ __launch_bounds__(128) void k_tts_lstm_mw(const float* xp_f, const float* xp_r, const float* whhT_f, const float* whhT_r, const float* bhh_f, const float* bhh_r, int T, int H, float* out,
-                                                     unsigned* hbuf, unsigned* cnt, int* err) {
+                                                     unsigned long long* hbuf, unsigned epoch, int* err) {
     extern __shared__ float ls[];      // w [H / 4][128][4] | h [H] | a [128]
     float* w = ls; float* hs = ls + (size_t)H * 128; float* as = hs + H;
     const int NW = H / 32, dir = blockIdx.x / NW, j = blockIdx.x % NW, tid = threadIdx.x, g = tid >> 5, u = tid & 31, G4 = 4 * H, gi = g * H + 32 * j + u;
@@ -315,33 +317,47 @@ __global__ __launch_bounds__(128) void k_tts_lstm_mw(const float* xp_f, const fl
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
         const float xv = xp[(long)t * G4 + gi];
+        // the chain over h, eight 4-k groups at a time with the NEXT eight's LDS reads already in flight (one wave per SIMD has nobody else to hide an LDS round trip behind).
+        // Measured: this is not what bounds a step — 4.1 us with or without the prefetch; ~3 us of it are the two device-scope trips of the h exchange (workgroups sit on different XCDs,
+        // so the store and the poll both go past the XCD's L2 to the memory side)
         float acc = 0.0f;
-        for (int k4 = 0; k4 < (H >> 2); ++k4) {
-            const f32x4 wv = *(const f32x4*)&w[(k4 * 128 + tid) * 4], hv = *(const f32x4*)&hs[4 * k4];
-            acc = __builtin_fmaf(wv[0], hv[0], acc); acc = __builtin_fmaf(wv[1], hv[1], acc); acc = __builtin_fmaf(wv[2], hv[2], acc); acc = __builtin_fmaf(wv[3], hv[3], acc);
+        f32x4 wc[8], hc[8], wn[8], hn[8];
+        const f32x4* wq = (const f32x4*)w + tid; const f32x4* hq = (const f32x4*)hs;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wc[i] = wq[i * 128]; hc[i] = hq[i]; }
+        for (int kb = 0; kb < (H >> 5); ++kb) {
+            const int nb = min(kb + 1, (H >> 5) - 1) * 8;      // (the last block re-reads itself: no branch in the loop)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wn[i] = wq[(nb + i) * 128]; hn[i] = hq[nb + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc = __builtin_fmaf(wc[i][0], hc[i][0], acc); acc = __builtin_fmaf(wc[i][1], hc[i][1], acc);
+                acc = __builtin_fmaf(wc[i][2], hc[i][2], acc); acc = __builtin_fmaf(wc[i][3], hc[i][3], acc);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wc[i] = wn[i]; hc[i] = hn[i]; }
         }
         as[tid] = (xv + acc) + bh;
         __syncthreads();
+        const unsigned tag = (epoch << 12) | (unsigned)(s + 1);
+        unsigned long long* hb = hbuf + (size_t)((s & 1) * 2 + dir) * H;
         if (tid < 32) {
             const float ig = sigmoid_e(as[u]), fg = sigmoid_e(as[32 + u]), gg = tanh_e(as[64 + u]), og = sigmoid_e(as[96 + u]);
             c = (fg * c) + (ig * gg); const float hv = og * tanh_e(c);
+            if (s + 1 < T) __hip_atomic_store(&hb[32 * j + u], ((unsigned long long)tag << 32) | __float_as_uint(hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out[(long)t * 2 * H + dir * H + 32 * j + u] = hv;
-            if (s + 1 < T) {
-                __hip_atomic_store(&hbuf[((s & 1) * 2 + dir) * H + 32 * j + u], __float_as_uint(hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
-                if (tid == 0) __hip_atomic_fetch_add(&cnt[dir], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
         if (s + 1 < T) {
-            if (tid == 0 && !dead) {
-                const unsigned target = (unsigned)NW * (unsigned)(s + 1); long spins = 0;
-                while (__hip_atomic_load(&cnt[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (++spins > (1L << 25)) { *err = 1; dead = true; break; }
+            __syncthreads();      // a[] is free again; h[] below is not read by anyone until the next barrier
+            for (int k = tid; k < H; k += 128) {
+                unsigned long long v = __hip_atomic_load(&hb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); long spins = 0;
+                while ((unsigned)(v >> 32) != tag && !dead) {
+                    if ((++spins & 1023) == 0 && (spins > (1L << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { *err = 1; dead = true; break; }
                     __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(&hb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                hs[k] = __uint_as_float((unsigned)v);
             }
-            __syncthreads();
-            for (int k = tid; k < H; k += 128) hs[k] = __uint_as_float(__hip_atomic_load(&hbuf[((s & 1) * 2 + dir) * H + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __syncthreads();
         }
     }
@@ -408,7 +424,7 @@ struct skw_tts {
     TtsText text;
     // scratch arena: chunks kept for the engine's life, bump-allocated per call (a call's buffers are all live until it ends)
     struct Chunk { char* p; size_t cap; }; std::vector<Chunk> chunks; size_t cur_chunk = 0, cur_off = 0; bool arena_failed = false;
-    unsigned* lstm_sync = nullptr;      // [4 H] h exchange (two step parities x two directions) | [2] arrival counters | [1] error flag
+    unsigned long long* lstm_sync = nullptr; unsigned lstm_epoch = 0;      // [4 H] tagged h exchange words (two step parities x two directions) | [1] error flag (low half of a word)
     bool taps_on = false; std::vector<float> dbg[9]; float last_ms = 0.0f;
 };
 static void* dev_upload(skw_tts* t, const void* h, size_t bytes) {
@@ -451,14 +467,21 @@ struct GpuBackend {
     const float* word_tab = nullptr;
     // g_conv_mode (SKW_TTS_CONV / skw_tts_debug_conv_mode): 1 forces the untiled kernel, 2 the tiled one — both evaluate the same chain and the tests run one against the other;
     // 0 = tiled when the launch is long enough to fill tiles
+    template <int MT, int NT> void launch_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil,
+        int pad, int To, float* out, int os, int oo) {
+        hipLaunchKernelGGL((k_tts_conv_t<MT, NT>), dim3((To + 16 * NT - 1) / (16 * NT), (Co16 + 64 * MT - 1) / (64 * MT)), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias,
+            K, stride, dil, pad, To, out, os, oo);
+    }
     void launch_conv(const float* x, int T, int Ci, const float* wp, int Co, const float* bias, int K, int stride, int dil, int pad, int To, float* out, int os = 1, int oo = 0) {
         const int Co16 = (Co + 15) & ~15, mode = g_conv_mode;
-        const bool tiled = mode == 2 || (mode != 1 && To >= 256 && (long)K * Ci >= 32);
-        if (!tiled) hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
-        else if (Co16 > 64)
-            hipLaunchKernelGGL(k_tts_conv_t<2>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, (Co16 + 127) / 128), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
-        else
-            hipLaunchKernelGGL(k_tts_conv_t<1>, dim3((To + TTS_CT_ROWS - 1) / TTS_CT_ROWS, 1), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
+        const bool tiled = mode == 2 || (mode != 1 && To >= 32 && (long)K * Ci >= 32);
+        if (!tiled) { hipLaunchKernelGGL(k_tts_conv, dim3((To + 63) / 64, (Co16 + 63) / 64), dim3(256), 0, s, x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo); return; }
+        // the largest tile that still gives the 256 CUs a workgroup each (the chain does not allow splitting k, so a short launch can only spread by smaller tiles)
+        auto wgs = [&](int mt, int nt) { return (long)((To + 16 * nt - 1) / (16 * nt)) * ((Co16 + 64 * mt - 1) / (64 * mt)); };
+        if (Co16 > 64 && wgs(2, 8) >= 256) launch_conv_t<2, 8>(x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
+        else if (wgs(1, 8) >= 256) launch_conv_t<1, 8>(x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
+        else if (wgs(1, 4) >= 256) launch_conv_t<1, 4>(x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
+        else launch_conv_t<1, 2>(x, T, Ci, wp, Co, Co16, bias, K, stride, dil, pad, To, out, os, oo);
     }
     Buf conv(const Buf& x, const Tensor& w, const Tensor* bias, int K, int stride, int dil, int pad) {
         const int Co = (int)w.dims[0], Ci = (int)w.dims[1], To = (x.T + 2 * pad - dil * (K - 1) - 1) / stride + 1;
@@ -542,15 +565,15 @@ struct GpuBackend {
             if (xp[dir].p) launch_conv(x.p, x.T, In, (const float*)wih.packed, G4, dev(*ws[4 * dir + 2]), 1, 1, 1, 0, x.T, xp[dir].p);
         }
         if (!o.p || !xp[0].p || !xp[1].p) return o;
-        const bool multi = g_lstm_mode == 2 || (g_lstm_mode != 1 && H % 32 == 0 && x.T >= 8);
+        const bool multi = H % 32 == 0 && x.T < 4096 && (g_lstm_mode == 2 || (g_lstm_mode != 1 && x.T >= 8));
         if (!multi)
             hipLaunchKernelGGL(k_tts_lstm, dim3(2), dim3(1024), sizeof(float) * 5 * H, s, xp[0].p, xp[1].p, (const float*)ws[1]->packed, (const float*)ws[5]->packed,
                 dev(*ws[3]), dev(*ws[7]), x.T, H, o.p);
         else {
-            unsigned* cnt = t->lstm_sync + 4 * t->g.H;
-            hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), s);
+            t->lstm_epoch = (t->lstm_epoch + 1) & 0xFFFFFu;      // 20 bits of launch epoch + 12 bits of step in a word's tag (T <= TTS_MAX_FRAMES < 4096)
+            if (t->lstm_epoch == 0) { hipMemsetAsync(t->lstm_sync, 0, sizeof(unsigned long long) * 4 * t->g.H, s); t->lstm_epoch = 1; }
             hipLaunchKernelGGL(k_tts_lstm_mw, dim3(2 * (H / 32)), dim3(128), sizeof(float) * ((size_t)H * 128 + H + 128), s, xp[0].p, xp[1].p, (const float*)ws[1]->packed,
-                (const float*)ws[5]->packed, dev(*ws[3]), dev(*ws[7]), x.T, H, o.p, t->lstm_sync, cnt, (int*)(cnt + 2));
+                (const float*)ws[5]->packed, dev(*ws[3]), dev(*ws[7]), x.T, H, o.p, t->lstm_sync, t->lstm_epoch, (int*)(t->lstm_sync + 4 * t->g.H));
         }
         return o;
     }
@@ -639,8 +662,8 @@ static skw_tts* create_impl(const skw_tts_config* cfg, char* err, size_t errlen)
     for (auto& kv : t->text.sym2id) if (kv.second < 0 || kv.second >= t->g.n_sym) return fail("tokens file names an id outside the embedding table");
     if (!upload_weights(t, &e)) return fail(e);
     {   // the multi-workgroup LSTM's exchange buffers, and its LDS size (a 128 x H weight slice: over the 64 KiB default)
-        std::vector<unsigned> z((size_t)4 * t->g.H + 3, 0u);
-        t->lstm_sync = (unsigned*)dev_upload(t, z.data(), z.size() * sizeof(unsigned));
+        std::vector<unsigned long long> z((size_t)4 * t->g.H + 1, 0ull);
+        t->lstm_sync = (unsigned long long*)dev_upload(t, z.data(), z.size() * sizeof(unsigned long long));
         if (!t->lstm_sync) return fail("device allocation failed for the LSTM exchange buffers");
         if (hipFuncSetAttribute((const void*)k_tts_lstm_mw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ((size_t)t->g.H * 128 + t->g.H + 128))) != hipSuccess)
             return fail("hipFuncSetAttribute failed for the LSTM kernel");
@@ -709,8 +732,8 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
         || hipGetLastError() != hipSuccess) {
         free(host); return fail("synthesis kernels failed"); }
     hipEventElapsedTime(&t->last_ms, ev.a, ev.b);
-    {   int lstm_err = 0; hipMemcpy(&lstm_err, t->lstm_sync + 4 * t->g.H + 2, sizeof(int), hipMemcpyDeviceToHost);
-        if (lstm_err) { hipMemset(t->lstm_sync + 4 * t->g.H + 2, 0, sizeof(int)); free(host); return fail("LSTM workgroups timed out waiting for each other (GPU oversubscribed?)"); } }
+    {   int lstm_err = 0; hipMemcpy(&lstm_err, t->lstm_sync + 4 * t->g.H, sizeof(int), hipMemcpyDeviceToHost);
+        if (lstm_err) { hipMemset(t->lstm_sync + 4 * t->g.H, 0, sizeof(int)); free(host); return fail("LSTM workgroups timed out waiting for each other (GPU oversubscribed?)"); } }
     if (t->taps_on) {      // stage taps for the parity tests (skw_tts_debug_enable): 0 durations, 1 F0, 2 N, 3 decoder output, 4 spectrum + phase, 5 bert, 6 d_en, 7 t_en, 8 source STFT
         auto grab = [&](int k, const GpuBackend::Buf& b) { t->dbg[k].resize((size_t)b.T * b.C); hipMemcpy(t->dbg[k].data(), b.p, sizeof(float) * t->dbg[k].size(), hipMemcpyDeviceToHost); };
         t->dbg[0].assign(out.dur.begin(), out.dur.end());
