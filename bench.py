@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tts", action="store_true", help="skip the config-5 row: libskw_tts.so at Kokoro-82M's geometry (seeded weights), ~30 s of speech per call")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the SURVEY 8(d) config-2 leg through libwhisper.so (N plugin instances fed 960-sample packets)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -113,6 +114,27 @@ def plugin_path_leg(args, model_path, host_pcm, B, reps=3):
                                     "first packet in -> last Transcription JSON out; best of %d rounds" % (B, reps),
                             "wall_ms": round(best, 2), "instances": B, "packet_samples": 960, "batch_window_ms": 40, "vad_mode": "always", "precision": args.precision,
                             "segments": n_seg, "model_loads_in_process": loads.value, "context_cache_hits": hits.value, "first_create_log": log0}}
+
+
+def tts_leg(reps=5):
+    """BASELINE.json configs[4]'s second half, reported beside the headline (never part of `value`): libskw_tts.so — the published Kokoro-82M architecture in fp32 HIP
+    (seeded weights, PARITY UNPINNED) — speaking ~30 s in one call; GPU-event time of the call, best of `reps`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import kokoro_lib
+    tts = kokoro_lib.Tts(kokoro_lib.synth_kokoro_dir("kokoro82m"))
+    try:
+        ids = np.concatenate([[0], np.random.default_rng(5).integers(1, 60, 300), [0]]).astype(np.int32)
+        y, _ = tts.generate(None, 50, 1.0, ids=ids)
+        speed = float(np.clip((y.size // 600) / 1200.0, 0.3, 3.0))
+        ms = []
+        for _ in range(reps):
+            y, rate = tts.generate(None, 50, speed, ids=ids); ms.append(tts.last_ms())
+        secs = y.size / float(rate)
+        return {"tts": {"what": "libskw_tts.so, Kokoro-82M geometry (81.1 M seeded parameters, fp32 on v_mfma_f32_16x16x4_f32), %d tokens -> %d frames in one call; GPU-event time, best of %d"
+                                % (ids.size, y.size // 600, reps), "audio_s": round(secs, 2), "gpu_ms": round(min(ms), 2), "x_real_time": round(secs * 1000.0 / min(ms), 1), "parity": "unpinned"}}
+    finally:
+        tts.close()
 
 
 def main():
@@ -376,6 +398,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_plugin_path:
         out.update(plugin_path_leg(args, path, host, B))
+
+    if rank == 0 and world == 1 and not args.no_tts:
+        try:
+            out.update(tts_leg())
+        except Exception as e:      # a side row must not cost the headline line
+            out["tts"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (a port) on the host cores, bounded sample of the same workload

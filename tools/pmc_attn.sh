@@ -1,7 +1,7 @@
 export TMPDIR=/tmp; cd /tmp
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_IFETCH SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_HITS"; do
   tag=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_attn_$tag -o a -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --clips 16 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_attn_$tag.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_attn_$tag -o a -- python3 $GRAFT_REPO_ROOT/bench.py --no-tts --steps 1 --warmup 0 --clips 16 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_attn_$tag.log 2>&1
   python3 - <<PY
 import csv, collections, glob
 for f in glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_attn_$tag/*counter_collection.csv"):

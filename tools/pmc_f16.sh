@@ -6,7 +6,7 @@ TAG=${1:-rXX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; export TMPDIR=/tmp; cd /tmp
 : > $O/${TAG}_pmc_sq_f16.txt
 for C in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_INSTS_SALU"; do
   tag=$(echo $C | tr ' ' '_' | cut -c1-48)
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc16_$tag -o a -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-mode > $O/${TAG}_pmc16_$tag.log 2>&1 || { echo "pass $C failed" >> $O/${TAG}_pmc_sq_f16.txt; continue; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc16_$tag -o a -- python3 $R/bench.py --no-tts --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-other-mode > $O/${TAG}_pmc16_$tag.log 2>&1 || { echo "pass $C failed" >> $O/${TAG}_pmc_sq_f16.txt; continue; }
   python3 - "$tag" >> $O/${TAG}_pmc_sq_f16.txt <<'PY'
 import csv, collections, glob, sys
 tag = sys.argv[1]
