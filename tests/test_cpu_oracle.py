@@ -77,6 +77,28 @@ def test_mel_against_float64_restatement(oracle_micro, micro_model_path, n_sampl
     assert np.abs(mel - ref).max() < 1e-4          # north_star tolerance for mel frames
 
 
+def test_mel_matches_transformers_feature_extractor(oracle_micro, micro_model_path):
+    """K1 against an INDEPENDENT implementation: transformers' WhisperFeatureExtractor (numpy: periodic Hann(400), centred reflect padding, hop 160, power spectrum, Slaney mel
+    filterbank, log10 floor 1e-10, max - 8 clamp, (x + 4) / 4).  (i) The 80 x 201 filterbank this repository computes for its model files (tools/make_synth_model.c) is HF's
+    `mel_filter_bank(norm="slaney", mel_scale="slaney")`; (ii) the oracle's log-mel of a 30 s clip equals HF's on every frame both define the same way.  They differ by design at
+    the clip's end only: whisper.cpp appends zeros after the audio (restated in oracle/skw_frontend.c), HF reflects the padded buffer's end and drops its last frame — frames >= 2998."""
+    tr = pytest.importorskip("transformers")
+    fe = tr.WhisperFeatureExtractor(feature_size=80, sampling_rate=16000, hop_length=160, chunk_length=30, n_fft=400)
+    _, filters, _, _ = read_ggml(micro_model_path)
+    hf_filters = np.asarray(fe.mel_filters, np.float64).T                      # [80][201]
+    assert filters.shape == hf_filters.shape == (80, 201)
+    assert np.abs(filters.astype(np.float64) - hf_filters).max() < 2e-7 * hf_filters.max()
+    for seed, n in ((5, 480000), (9, 480000), (3, 16000 * 7 + 123)):
+        pcm = synth.clip(seed, n)
+        mel, _ = oracle_micro.log_mel(pcm)
+        hf = fe(pcm, sampling_rate=16000, return_tensors="np").input_features[0]      # [80][3000], the clip zero-padded to 30 s
+        last = min(2998, (n - 200) // 160)                                       # frames whose 400-sample window ends inside the audio see the same samples in both
+        # the clamp is max - 8 over all frames: both maxima sit in the audio (the padding is silence), so the floor is shared
+        err = float(np.abs(mel[:, :last] - hf[:, :last]).max())
+        print("log-mel vs transformers, seed %d, %d samples: max abs difference %.2e over %d frames" % (seed, n, err, last))
+        assert err < 2e-4, (seed, n, err)      # measured 5.5e-5 .. 9.0e-5: the oracle follows whisper.cpp in an fp32 FFT, HF computes in float64
+
+
 def test_mel_frame_counts(oracle_micro):
     # 30 s -> 6000 frames / n_len_org 2999; the plugin's forced cut hands over 30.048 s -> 6004 / 3004 (SURVEY K12)
     for n, n_len, n_org in [(480000, 6000, 2999), (480768, 6004, 3004), (16000, 3100, 99)]:
