@@ -160,6 +160,20 @@ def test_oracle_synthesiser_is_sane_and_deterministic(built):
     assert np.array_equal(again["y"].view(np.uint32), r["y"].view(np.uint32))
 
 
+def test_oracle_synthesiser_refuses_what_the_product_refuses(built):
+    d = kokoro_lib.synth_kokoro_dir()
+    o = kokoro_lib.OracleTts(d)
+    ids = np.concatenate([[0], np.random.default_rng(11).integers(1, 70, 508), [0]]).astype(np.int32)
+    with pytest.raises(RuntimeError, match=r"Generated audio too long \(\d+ frames; at most 3000\)"):
+        o.synth(None, 3, 0.05, ids=ids)
+    with pytest.raises(RuntimeError, match="token id outside the embedding table"):
+        o.synth(None, 3, 1.0, ids=np.array([0, 5000, 0], np.int32))
+    with pytest.raises(RuntimeError, match="token count outside the model's position table"):
+        o.synth(None, 3, 1.0, ids=np.zeros(600, np.int32))
+    r = o.synth(None, 3, 1.0, ids=np.array([0, 20, 0], np.int32))
+    assert r["F"] == int(r["dur"].sum()) >= 3 and r["y"].size == 600 * r["F"]
+
+
 def test_text_front_end_equals_an_independent_restatement_on_random_strings(built):
     """skw_kokoro_text.h (C++) against tests/kokoro_lib.py (Python, written separately from the same Rust source) on seeded random strings drawn
     from an alphabet that exercises every class of the sanitiser and every boundary of the splitter."""

@@ -115,6 +115,36 @@ def test_kernel_variants_are_bit_identical(size):
     tts.close()
 
 
+def test_synthesiser_edges_shortest_longest_and_too_long():
+    """The ends of the input range, against the checker: the shortest utterance the tokeniser lets through (one symbol between the pads: 3 tokens, every launch a fraction of a
+    tile), the longest (510 tokens incl. pads: the position table's and voices.bin's last row), and a call whose predicted frame count passes the engine's cap — refused with the
+    same message by both, before any waveform work."""
+    d = kokoro_lib.synth_kokoro_dir("micro")
+    tts = kokoro_lib.Tts(d); orc = kokoro_lib.OracleTts(d); tts.taps(True)
+    rng = np.random.default_rng(11)
+    for ids, speed in (([0, 20, 0], 1.0), (np.concatenate([[0], rng.integers(1, 70, 508), [0]]), 2.0)):
+        ids = np.asarray(ids, np.int32)
+        y, _ = tts.generate(None, 3, speed, ids=ids)
+        r = orc.synth(None, 3, speed, ids=ids)
+        assert np.array_equal(tts.tap(0).astype(np.int32), r["dur"]) and y.size == r["y"].size == 600 * int(r["dur"].sum())
+        for what, name in ((5, "bert"), (1, "f0"), (3, "dec")):
+            assert np.array_equal(tts.tap(what).view(np.uint32), r[name].ravel().view(np.uint32)), (ids.size, name)
+        keep, wraps = _wrap_mask(tts.tap(8).reshape(-1, 22), r["har"])
+        keep_y = np.repeat(keep[:-1], 5)
+        assert wraps <= 3 and _rel(y[keep_y], r["y"][keep_y]) < TOL_WAVE, (ids.size, wraps)
+        print("kokoro micro edge: %d tokens -> %d frames, %.2f s of audio in %.2f ms" % (ids.size, y.size // 600, y.size / 24000.0, tts.last_ms()))
+    long_ids = np.concatenate([[0], rng.integers(1, 70, 508), [0]]).astype(np.int32)
+    with pytest.raises(RuntimeError, match=r"Generated audio too long \(\d+ frames; at most 3000\)"):
+        tts.generate(None, 3, 0.05, ids=long_ids)                                                    # durations are divided by the speed: 20 x as many frames
+    with pytest.raises(RuntimeError, match=r"Generated audio too long \(\d+ frames; at most 3000\)"):
+        orc.synth(None, 3, 0.05, ids=long_ids)
+    with pytest.raises(RuntimeError, match="token id outside the embedding table"):
+        tts.generate(None, 3, 1.0, ids=np.array([0, 5000, 0], np.int32))
+    y, _ = tts.generate(None, 3, 1.0, ids=np.array([0, 20, 0], np.int32))                             # the engine is usable after a refused call
+    assert y.size > 0 and np.isfinite(y).all()
+    tts.close()
+
+
 def test_kokoro_82m_geometry_speed():
     """The synthesiser at Kokoro-82M's real widths (tools/make_synth_kokoro.py --size kokoro82m: 12 ALBERT passes at 768, 512-wide predictor / text encoder, 1024-wide decoder,
     512 -> 256 -> 128 generator; seeded weights): ~30 s of speech in one call, timed with GPU events.  Too large for the CPU checker within a test run — the arithmetic is the
