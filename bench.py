@@ -370,7 +370,13 @@ def main():
                 full_bytes = 4.0 * B * hp.n_audio_ctx * hp.n_text_state
                 roof["full_launch"] = {"rows": B, "bytes": full_bytes, "us": round(us.value, 2), "achieved": round(full_bytes / us.value / 1e3, 1), "unit": "GB/s",
                                        "frac": round(full_bytes / us.value / 1e3 / HBM_PEAK_GBS, 4)}
-            roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * 4.0 * B * hp.n_audio_ctx * hp.n_text_state), 4)
+            groups = int(os.environ.get("SKW_DECODE_GROUPS", "0") or 0) or (2 if fast and B >= 64 else 1)
+            roof["row_groups"] = groups
+            if groups > 1:
+                roof["row_groups_note"] = ("the decode step runs as %d row groups on %d streams (the engine's default for this precision and batch: +1.3 %% on the whole step, profiles/r04g): "
+                                           "a launch covers %d rows and shares HBM with the other group's kernels, so `frac` is per launch under that sharing; "
+                                           "`full_launch` is one %d-row launch alone" % (groups, groups, B // groups, B))
+            roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * 4.0 * (B // groups) * hp.n_audio_ctx * hp.n_text_state), 4)
             roof["booking"] = "algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state per launch (K and V^T, f16), live rows counted per step on the host"
             roof["timing"] = "per launch, HIP events stamped at the kernel's own begin and end (hipExtLaunchKernelGGL) on the engine's stream: the duration rocprofv3 reports for the same kernel"
         # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times

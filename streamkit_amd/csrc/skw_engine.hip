@@ -1248,7 +1248,11 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
-        const int n_groups = c->n_groups > 0 ? c->n_groups : 1;   // one row group in both precisions (exact: 194 ms against 213 with two, since the segmented decode GEMMs; f16_mfma: 178 against 204)
+        // Default: f16_mfma with 64 rows or more runs TWO row groups, one step graph each on its own stream (the groups' launch-bound stretches overlap a little: same-box A/B, three
+        // alternations, 167.96 -> 165.82 ms per 64-clip step, profiles/r04g; VERDICT r3: ship the faster configuration and describe its roofline) — each cross-attention launch
+        // is then 32 rows and shares HBM with the other group's kernels, which is what bench.py's per-launch roofline line then reports.  The exact precision keeps one group
+        // (two: -3 %), and so do smaller batches (16-row launches).  SKW_DECODE_GROUPS=n overrides.
+        const int n_groups = c->n_groups > 0 ? c->n_groups : (c->precision == SKW_PRECISION_F16_MFMA && Bw >= 64 ? 2 : 1);
         // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
         const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;
         // Groups are cut at multiples of 16 rows: the f16_mfma step keeps its attention / FC1 outputs as fragment-order images (skw_afrag_off), which
