@@ -68,6 +68,7 @@ struct SkwGemmArgs {
     int c_frag, a_frag;             // the f16 decode kernels (skw_gemm16_small / _lnA): c_frag — an EPI_GELU_F16_KPERM product writes C as the fragment-order A image of the product that follows
                                     // (per 16-row tile and 32-k block one KiB [lane r16 + 16 g][8 halves], skw_afrag_off); a_frag — A is such an image.  The decode step's fc1 -> fc2 pair.
     int frag;                       // skw_gemm16, EPI_F16_PLAIN / EPI_VT_F16 with n_ctx, H, Tpad set: C is the fragment-order cross K / V^T image (skw_kfrag_off / skw_vtfrag_off) instead of rows
+    int wgroups;                    // k_gemm16w only, set by its launcher: the XCDs split the features into this many n-tile groups (1: the contiguous walk)
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
     const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
     half_t* ln_out; unsigned* ln_cnt;                          // skw_gemm16_small, EPI_F32 with N = ldc: the workgroup that completes a 16-row block of C also writes

@@ -374,7 +374,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
     const int nk = a.K >> 6, nk32 = a.K >> 5, nstrip = a.N >> 4;
     const half_t* gA[A_PIECES];
     unsigned woff[TNT];                                                                     // byte offset of this lane's 16 bytes in k-block 0 of each of the wave's strips
+    // Tile -> (m, n).  Workgroups are dealt to the 8 XCDs round-robin, so tile t runs on XCD t & 7.  Default walk: an XCD takes a contiguous run of tiles, n fastest — the n-tiles
+    // of a token panel run together on one XCD.  That keeps A's re-reads local, but an XCD then streams the WHOLE weight through its 4 MiB L2 for every few panels: fine while W
+    // fits (768 x 768: 1.2 MB), pathological for FC1's 4.7 MB (PMC, profiles/r04i: 1 556 MB fetched per launch against 152 algorithmic — every W strip comes from the
+    // Infinity Cache, at its latency, into a loop whose weight loads have a quarter step of slack).  ng > 1 (a.wgroups): the XCDs split the FEATURES — XCD x owns n-tile group
+    // x % ng (its W slice stays in L2) for token-panel range x / ng; a panel is then fetched by ng XCDs instead of one.  Walk length is padded; tiles past the end do nothing.
+    const int ng = a.wgroups > 1 ? a.wgroups : 1, ngn = nbn / ng, mparts = 8 / ng, mp = (nbm + mparts - 1) / mparts;
+    const int nwalk = ng > 1 ? 8 * mp * ngn : nblk;
     auto tile_origin = [&](int tile, int& m0, int& n0) {
+        if (ng > 1) {
+            const int x = tile & 7, y = tile >> 3, gsel = x % ng, part = x / ng;
+            const int m = part * mp + y / ngn;
+            m0 = m < min(nbm, (part + 1) * mp) ? m * BM : -1; n0 = (gsel * ngn + y % ngn) * BN;
+            return;
+        }
         int q = nblk >> 3, r = nblk & 7, x = tile & 7, y = tile >> 3;
         const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
         m0 = (bid / nbn) * BM; n0 = (bid % nbn) * BN;
@@ -419,8 +432,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
         for (int p = tid; p < a.N; p += 256) { const int f = (PERM && !X_IS_M) ? ((p & ~31) | inv_kperm32(p & 31)) : p; bl[p] = a.bias ? a.bias[f] : 0.0f; }
         SKW_LDS_BARRIER();
     }
-    for (int tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
-        int m0, n0; tile_origin(tile, m0, n0); tile_sources(m0, n0);
+    for (int tile = blockIdx.x; tile < nwalk; tile += gridDim.x) {
+        int m0, n0; tile_origin(tile, m0, n0);
+        if (m0 < 0) continue;                                                                // (padding of the feature-split walk; uniform per workgroup)
+        tile_sources(m0, n0);
         f16x8 w0[TNT], w1[TNT];
         // The K loop is software-pipelined at QUARTER-step granularity with no extra registers: a 32-k half step is two groups of 16 MFMAs — token tiles 0-3 (fragments
         // `lo`) and 4-7 (`hi`) against the wave's four weight strips — and while a group's MFMAs issue, the LDS reads of the NEXT group's fragments are in flight:
@@ -609,9 +624,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm16w(SkwGemmArgs a) {
         }
     }
 }
-template <int EPI> static void launch_gemm16w(const SkwGemmArgs& a, hipStream_t s) {
+template <int EPI> static void launch_gemm16w(const SkwGemmArgs& a_in, hipStream_t s) {
+    SkwGemmArgs a = a_in;
     const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
-    const int nblk = ((Mv + 127) / 128) * ((a.N + 255) / 256);
+    const int nbn_ = (a.N + 255) / 256, nbm_ = (Mv + 127) / 128;
+    // feature-split walk (k_gemm16w's tile_origin): when the weight does not fit beside the token panels in an XCD's 4 MiB L2.  SKW_GEMM16W_NGROUPS: 0 automatic, 1 off, 2 / 4 / 8 forced
+    static const int ng_env = getenv("SKW_GEMM16W_NGROUPS") ? atoi(getenv("SKW_GEMM16W_NGROUPS")) : 0;
+    int ng = 1;
+    if (ng_env > 1) ng = ng_env;
+    else if (ng_env == 0 && !Epi16<EPI>::X_IS_M) { const double wb = 2.0 * a.N * a.K; while (ng < 8 && wb / ng > 2.6e6 && nbn_ % (2 * ng) == 0) ng *= 2; }
+    if (ng > 1 && (nbn_ % ng || 8 % ng || Epi16<EPI>::X_IS_M)) ng = 1;
+    a.wgroups = ng;
+    const int nblk = ng > 1 ? 8 * ((nbm_ + 8 / ng - 1) / (8 / ng)) * (nbn_ / ng) : nbm_ * nbn_;
     const int slots = ((a.probe & 2048) ? 1 : 2) * (skw_cu_count() & ~7);      // (probe bit 11: one workgroup per CU)
     if (a.probe) hipLaunchKernelGGL((k_gemm16w<EPI, true>), dim3(std::min(nblk, slots)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gemm16w<EPI>), dim3(std::min(nblk, slots)), dim3(256), 0, s, a);
