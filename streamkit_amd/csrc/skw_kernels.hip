@@ -343,22 +343,34 @@ __device__ __forceinline__ void att_store_m(half_t* out, int m, long ldo, int co
 }
 // ------------------------------------------------------------------ LayerNorm
 __device__ __forceinline__ double wave_sum_f64(double v) { return skw_wave_sum_f64(v); }   // DPP + readlane, no LDS crossbar (skw_dev_common.h)
-// one wave per row; d <= 64 NC (NC = 12 for every width up to Whisper-small's, 24 up to 1536); FULL: d == 64 NC (Whisper-small: straight-line code, no tail predicates)
-template <int NC, bool FULL>
+// one wave per R rows; d <= 64 NC (NC = 12 for every width up to Whisper-small's, 24 up to 1536); FULL: d == 64 NC (Whisper-small: straight-line code, no tail predicates).
+// R = 2 for the encoder's 96 000-row launches: the kernel is a stream (442 MB per launch) and a wave with one 3 KiB row in flight leaves the CU short of bytes in flight;
+// the rows' arithmetic is skw_ln_rows' either way (same bits).  SKW_LN_ROWS=1 restores one row per wave.
+template <int NC, bool FULL, int R = 1>
 __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (long)row * d;
-    float v[1][NC], wv[NC], bv[NC];
-    // the gain / bias loads go out together with the row (a 64-row decode launch is three dependent round trips otherwise)
+    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    float v[R][NC], wv[NC], bv[NC];
+    bool live[R]; half_t* o16[R]; float* o32[R];
+    // the gain / bias loads go out together with the rows (a 64-row decode launch is three dependent round trips otherwise)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { int i = lane + 64 * c; const bool in = FULL || i < d; v[0][c] = in ? xr[i] : 0.0f; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
-    const bool live[1] = {true}; half_t* const o16[1] = {out16 ? out16 + (long)row * d : nullptr}; float* const o32[1] = {out32 ? out32 + (long)row * d : nullptr};
-    skw_ln_rows<1, NC, FULL>(v, wv, bv, d, lane, live, o16, o32);
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r; live[r] = row < rows;
+        const float* xr = x + (long)(live[r] ? row : row0) * d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const int i = lane + 64 * c; v[r][c] = (FULL || i < d) ? xr[i] : 0.0f; }
+        o16[r] = out16 ? out16 + (long)(live[r] ? row : row0) * d : nullptr; o32[r] = out32 ? out32 + (long)(live[r] ? row : row0) * d : nullptr;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int i = lane + 64 * c; const bool in = FULL || i < d; wv[c] = in ? w[i] : 0.0f; bv[c] = in ? b[i] : 0.0f; }
+    skw_ln_rows<R, NC, FULL>(v, wv, bv, d, lane, live, o16, o32);
 }
 void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s) {
-    const dim3 g((rows + 3) / 4);
-    if (d == 768) hipLaunchKernelGGL((k_layernorm<12, true>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+    static const int r_env = getenv("SKW_LN_ROWS") ? atoi(getenv("SKW_LN_ROWS")) : 0;
+    const bool two = (r_env ? r_env == 2 : rows >= 8192) && d == 768;
+    const dim3 g(two ? (rows + 7) / 8 : (rows + 3) / 4);
+    if (two) hipLaunchKernelGGL((k_layernorm<12, true, 2>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
+    else if (d == 768) hipLaunchKernelGGL((k_layernorm<12, true>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
     else if (d <= 768) hipLaunchKernelGGL((k_layernorm<12, false>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
     else hipLaunchKernelGGL((k_layernorm<24, false>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
 }
