@@ -313,10 +313,12 @@ __global__ __launch_bounds__(128) void k_tts_lstm_mw(const float* xp_f, const fl
     for (int k = 0; k < H; ++k) w[((k >> 2) * 128 + tid) * 4 + (k & 3)] = whhT[(long)k * G4 + gi];
     for (int k = tid; k < H; k += 128) hs[k] = 0.0f;
     float c = 0.0f; bool dead = false;
+    float xv_next = xp[(long)(dir ? T - 1 : 0) * G4 + gi];      // W_ih x + b_ih of the step after this one is requested a step ahead: its round trip is not on the chain
     __syncthreads();
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
-        const float xv = xp[(long)t * G4 + gi];
+        const float xv = xv_next;
+        if (s + 1 < T) xv_next = xp[(long)(dir ? t - 1 : t + 1) * G4 + gi];
         // the chain over h, eight 4-k groups at a time with the NEXT eight's LDS reads already in flight (one wave per SIMD has nobody else to hide an LDS round trip behind).
         // Measured: this is not what bounds a step — 4.1 us with or without the prefetch; ~3 us of it are the two device-scope trips of the h exchange (workgroups sit on different XCDs,
         // so the store and the poll both go past the XCD's L2 to the memory side)
