@@ -1492,7 +1492,12 @@ void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt,
         static const int x16rd = getenv("SKW_XATTN16_RD") ? atoi(getenv("SKW_XATTN16_RD")) : 3;
         // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
         static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;
-        if (pv16 == 2 && x16hpw == 1) {
+        if (pv16 == 2 && x16nt && (x16hpw == 1 || x16hpw == 2)) {      // fewer heads per workgroup WITH the non-temporal policy (measurement: more, smaller workgroups for 32-row groups)
+            if (x16hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true, 2>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo,
+                seq, ofrag ? d : 0);
+            else hipLaunchKernelGGL((k_dec_cross_attn16<2, 3, true, 2>), dim3((H + 1) / 2, B), dim3(512), 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo,
+                seq, ofrag ? d : 0);
+        } else if (pv16 == 2 && x16hpw == 1) {
             const dim3 grid1(H, B), blk1(256);
             if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
                 Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
