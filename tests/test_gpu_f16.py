@@ -130,7 +130,7 @@ def test_tokens_identical_to_oracle_ragged_batch(tiny16, suppress_nst):
                 lp = max(abs(a[3] - b[3]) for a, b in zip(rg["tokens"], ro["tokens"]))
                 assert lp < 5e-2, (c, n, lp)                                      # token log-probs
     print("f16_mfma ragged batch (suppress_nst %d): %d of %d clips identical to the oracle" % (suppress_nst, n_same, len(CLIPS)))
-    assert n_same >= len(CLIPS) - 2, n_same
+    assert n_same >= len(CLIPS) - 1, n_same      # measured 9 of 10 in both settings (round 4; the tenth parts at a near-tie that same_or_near_tie prints); one more is a regression
 
 
 def test_quantised_file_in_f16_mfma_runs_its_f16_twin(eng):
