@@ -145,6 +145,9 @@ static bool up_ln(skw_model* m, std::vector<RawT>& ts, const std::string& wname,
 }
 
 extern "C" int skw_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" void* skw_host_alloc(size_t bytes) { void* p = nullptr;
+if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+extern "C" void skw_host_free(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int skw_model_lang_id(const char* lang) {
     if (!lang) return -1;
     for (int i = 0; i < g_n_lang; ++i) if (!strcmp(g_lang[i], lang)) return i;

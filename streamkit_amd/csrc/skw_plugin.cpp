@@ -121,8 +121,35 @@ bool parse_config(const char* json, WhisperConfig* cfg, std::string* err) {
 // ------------------------------------------------------------------ shared engine: model cache + batch scheduler
 // One per (model_path, use_gpu, gpu_device) — the key of the reference's WHISPER_CONTEXT_CACHE (lib.rs:175-180, 330).
 // Instances submit finished speech segments; a worker thread forms batches and runs skw_full_batch.
+// A segment's samples in page-locked memory, so that the engine's H2D copy of the batch is asynchronous DMA (64 x 30 s: ~2.3 ms) and not the driver's staged copy out of pageable
+// memory (~6 ms, all of it in front of the first kernel).  Buffers are recycled through a process-wide pool (page-locking is not free: one allocation per first use of a slot).
+struct PinnedPool {
+    struct Buf { float* p; size_t cap; };
+    std::mutex mu; std::vector<Buf> free_; size_t pooled_bytes = 0;
+    static PinnedPool& get() { static PinnedPool* pool = new PinnedPool(); return *pool; }      // (leaked on purpose: instances may outlive static destruction order)
+    Buf acquire(size_t n) {
+        {   std::lock_guard<std::mutex> l(mu); int best = -1;
+            for (int i = 0; i < (int)free_.size(); ++i) if (free_[i].cap >= n && (best < 0 || free_[i].cap < free_[best].cap)) best = i;
+            if (best >= 0) { Buf b = free_[best]; free_.erase(free_.begin() + best); pooled_bytes -= b.cap * sizeof(float); return b; } }
+        const size_t cap = std::max<size_t>((n + 65535) & ~(size_t)65535, 491520);      // at least a 30.72 s segment: the common size comes back from the pool
+        return Buf{(float*)skw_host_alloc(cap * sizeof(float)), cap};
+    }
+    void release(Buf b) {
+        if (!b.p) return;
+        {   std::lock_guard<std::mutex> l(mu);
+            if (pooled_bytes + b.cap * sizeof(float) <= ((size_t)512 << 20)) { free_.push_back(b); pooled_bytes += b.cap * sizeof(float); return; } }
+        skw_host_free(b.p);
+    }
+};
 struct Job {
-    std::vector<float> pcm; skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
+    std::vector<float> pcm_pageable; PinnedPool::Buf pinned{nullptr, 0}; size_t n = 0;
+    skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
+    void set_samples(const std::vector<float>& v) {
+        n = v.size(); pinned = PinnedPool::get().acquire(n);
+        if (pinned.p) memcpy(pinned.p, v.data(), n * sizeof(float)); else pcm_pageable = v;      // (no page-locked memory to be had: the ordinary copy path)
+    }
+    const float* data() const { return pinned.p ? pinned.p : pcm_pageable.data(); }
+    ~Job() { PinnedPool::get().release(pinned); }
 };
 struct SharedEngine {
     skw_model* model = nullptr;
@@ -173,7 +200,7 @@ struct SharedEngine {
             int rc = -1; std::string why;
             try {
                 std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n); int need = 0;
-                for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->pcm.data(); ns[i] = (int32_t)batch[i]->pcm.size(); need = std::max(need, (int)ns[i]); }
+                for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->data(); ns[i] = (int32_t)batch[i]->n; need = std::max(need, (int)ns[i]); }
                 if (ensure_workspace(need, n, &why)) {
                     rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
                     if (rc == 0) for (int i = 0; i < n; ++i) batch[i]->result = res[i]; else why = skw_ctx_last_error(ctx);
@@ -327,14 +354,14 @@ bool transcribe_and_emit(WhisperPlugin* self, const Emit& em, const skw::Segment
         em.telemetry("vad.speech_end", j);
     }
     auto job = std::make_shared<Job>();
-    job->pcm = cut.samples;
+    job->set_samples(cut.samples);
     skw_full_default_params(&job->params);
     int lang = self->config.language == "auto" ? -1 : skw_model_lang_id(self->config.language.c_str());     // "auto": whisper.cpp detects it from the first window
     if (lang < 0 && self->config.language != "auto") { *err = "Whisper inference failed: unknown language '" + self->config.language + "'"; return false; }
     job->params.lang_id = lang; job->params.translate = 0;
     job->params.suppress_blank = self->config.suppress_blank ? 1 : 0; job->params.suppress_nst = self->config.suppress_non_speech_tokens ? 1 : 0;
     job->params.n_threads = (int32_t)self->config.n_threads;
-    if ((int)job->pcm.size() > SharedEngine::kMaxSamples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
+    if ((int)job->n > SharedEngine::kMaxSamples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
     std::future<int> fut = job->done.get_future();
     { std::lock_guard<std::mutex> l(self->engine->mu); self->engine->queue.push_back(job); }
     self->engine->cv.notify_all();
