@@ -197,7 +197,9 @@ template <class Buf> struct Outputs {
  *   Buf conv(Buf x, W w, W* bias, int K, int stride, int dil, int pad)      [out rows = (T + 2 pad - dil (K - 1) - 1) / stride + 1];
  *   Buf convtr(Buf x, W w, W* bias, int K, int stride, int pad, int out_pad, bool depthwise);
  *   void layernorm(Buf&, W gamma, W beta, float eps);  Buf style_fc(W w, W b, const float* style)      [a 1-row Buf];
- *   void ada_ln(Buf& x, Buf gb)      (LayerNorm over channels, y = n (1 + gb[c]) + gb[C + c]);  void ada_in(Buf& x, Buf gb)      (instance norm over time, same affine);
+ *   void ada_ln(Buf& x, Buf gb)      (LayerNorm over channels, y = n (1 + gb[c]) + gb[C + c]);  void ada_in_act(Buf& x, Buf gb, Act, W* alpha)      (instance norm over time, same affine, then
+ *   the activation: the normalised value is rounded to f32 before the activation takes it, exactly as two passes would; a backend may make it one);
+ *   void add_scale(Buf& a, Buf b, float f)      ((a + b) * f);
  *   void act(Buf&, Act, W* alpha);  Buf concat(std::vector<Buf>)      (channels);  Buf concat_style(Buf x, const float* style);  void add(Buf& a, Buf b);  void scale(Buf&, float);
  *   Buf upsample2(Buf);  Buf reflect_pad_left(Buf);  Buf attention(Buf q, Buf k, Buf v, int heads);  Buf lstm_bi(Buf x, W* [8] weights fwd / rev);
  *   Buf gather_rows(Buf x, const std::vector<int>& rows);  std::vector<int> durations(Buf logits, float scale);
@@ -223,15 +225,12 @@ template <class B> struct Net {
         Buf sc = up ? be.upsample2(x) : x;
         if (c1x1) sc = be.conv(sc, *c1x1, nullptr, 1, 1, 1, 0);
         Buf r = be.copy(x);
-        be.ada_in(r, be.style_fc(W(p + "norm1.fc.weight"), W(p + "norm1.fc.bias"), style));
-        be.act(r, ACT_LEAKY02, nullptr);
+        be.ada_in_act(r, be.style_fc(W(p + "norm1.fc.weight"), W(p + "norm1.fc.bias"), style), ACT_LEAKY02, nullptr);
         if (up) r = be.convtr(r, W(p + "pool.weight"), Wopt(p + "pool.bias"), 3, 2, 1, 1, true);
         r = be.conv(r, W(p + "conv1.weight"), Wopt(p + "conv1.bias"), 3, 1, 1, 1);
-        be.ada_in(r, be.style_fc(W(p + "norm2.fc.weight"), W(p + "norm2.fc.bias"), style));
-        be.act(r, ACT_LEAKY02, nullptr);
+        be.ada_in_act(r, be.style_fc(W(p + "norm2.fc.weight"), W(p + "norm2.fc.bias"), style), ACT_LEAKY02, nullptr);
         r = be.conv(r, W(p + "conv2.weight"), Wopt(p + "conv2.bias"), 3, 1, 1, 1);
-        be.add(r, sc);
-        be.scale(r, 0.70710678118654752440f);
+        be.add_scale(r, sc, 0.70710678118654752440f);
         return r;
     }
     /* AdaINResBlock1 (generator): three [AdaIN, Snake, dilated conv, AdaIN, Snake, conv] residual steps */
@@ -241,11 +240,9 @@ template <class B> struct Net {
         for (int j = 0; j < 3; ++j) {
             const std::string J = std::to_string(j);
             Buf t = be.copy(x);
-            be.ada_in(t, be.style_fc(W(p + "adain1." + J + ".fc.weight"), W(p + "adain1." + J + ".fc.bias"), style));
-            be.act(t, ACT_SNAKE, &W(p + "alpha1." + J));
+            be.ada_in_act(t, be.style_fc(W(p + "adain1." + J + ".fc.weight"), W(p + "adain1." + J + ".fc.bias"), style), ACT_SNAKE, &W(p + "alpha1." + J));
             t = be.conv(t, W(p + "convs1." + J + ".weight"), Wopt(p + "convs1." + J + ".bias"), k, 1, dil[j], dil[j] * (k - 1) / 2);
-            be.ada_in(t, be.style_fc(W(p + "adain2." + J + ".fc.weight"), W(p + "adain2." + J + ".fc.bias"), style));
-            be.act(t, ACT_SNAKE, &W(p + "alpha2." + J));
+            be.ada_in_act(t, be.style_fc(W(p + "adain2." + J + ".fc.weight"), W(p + "adain2." + J + ".fc.bias"), style), ACT_SNAKE, &W(p + "alpha2." + J));
             t = be.conv(t, W(p + "convs2." + J + ".weight"), Wopt(p + "convs2." + J + ".bias"), k, 1, 1, (k - 1) / 2);
             be.add(t, x);
             x = t;
@@ -342,8 +339,8 @@ template <class B> struct Net {
             if (i == 1) gx = be.reflect_pad_left(gx);
             be.add(gx, xs);
             Buf sum = adain_resblock1(gx, "decoder.generator.resblocks." + std::to_string(3 * i) + ".", s_ac, g.rk[0]);
-            for (int j = 1; j < 3; ++j) be.add(sum, adain_resblock1(gx, "decoder.generator.resblocks." + std::to_string(3 * i + j) + ".", s_ac, g.rk[j]));
-            be.scale(sum, 1.0f / 3.0f);
+            be.add(sum, adain_resblock1(gx, "decoder.generator.resblocks." + std::to_string(3 * i + 1) + ".", s_ac, g.rk[1]));
+            be.add_scale(sum, adain_resblock1(gx, "decoder.generator.resblocks." + std::to_string(3 * i + 2) + ".", s_ac, g.rk[2]), 1.0f / 3.0f);
             gx = sum;
         }
         be.act(gx, ACT_LEAKY001, nullptr);

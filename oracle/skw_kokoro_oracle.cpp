@@ -108,6 +108,8 @@ struct CpuBackend {
         for (int c = 0; c < x.C; ++c) { float mu, rs; row_stats(x.data() + c, x.T, x.C, &mu, &rs, 1e-5f);
             for (int t = 0; t < x.T; ++t) { float& v = x.data()[(size_t)t * x.C + c]; v = ((v - mu) * rs) * (1.0f + gb.data()[c]) + gb.data()[x.C + c]; } }
     }
+    void ada_in_act(Buf& x, const Buf& gb, Act a, const Tensor* alpha) { ada_in(x, gb); act(x, a, alpha); }
+    void add_scale(Buf& a, const Buf& b, float f) { add(a, b); scale(a, f); }
     void act(Buf& x, Act a, const Tensor* alpha) {
         const size_t n = (size_t)x.T * x.C;
 #pragma omp parallel for schedule(static)

@@ -222,25 +222,30 @@ __global__ void k_tts_in_final(const double* part, int nchunk, int T, int C, dou
     for (; i < nchunk; ++i) s += part[(long)i * C + c];
     if (stage == 0) mean[c] = s / T; else { stats[c] = (float)mean[c]; stats[C + c] = (float)(1.0 / sqrt(s / T + (double)1e-5f)); }
 }
-__global__ void k_tts_in_apply(float* x, long n, int C, const float* stats, const float* gb) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const int c = (int)(i % C);
-    x[i] = ((x[i] - stats[c]) * stats[C + c]) * (1.0f + gb[c]) + gb[C + c];
-}
 // y[r] = bias[r] + chain_j w[r][j] * s[j]   (style projections: 128 inputs)
 __global__ void k_tts_style_fc(const float* w, const float* bias, const float* s, int rows, float* y) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= rows) return;
     float acc = 0.0f; for (int j = 0; j < STYLE_DIM; ++j) acc = __builtin_fmaf(w[(long)r * STYLE_DIM + j], s[j], acc);
     y[r] = acc + bias[r];
 }
-__global__ void k_tts_act(float* x, long n, int C, int kind, const float* alpha) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; float v = x[i];
-    if (kind == ACT_LEAKY02) v = v > 0.0f ? v : v * 0.2f;
-    else if (kind == ACT_LEAKY01) v = v > 0.0f ? v : v * 0.1f;
-    else if (kind == ACT_LEAKY001) v = v > 0.0f ? v : v * 0.01f;
-    else if (kind == ACT_GELU) { const float u = 0.79788456080286535588f * (v + 0.044715f * ((v * v) * v)); v = (0.5f * v) * (1.0f + tanh_e(u)); }
-    else { const float al = alpha[i % C]; const float s = sinf(al * v); v = v + (s * s) / al; }
-    x[i] = v;
+__device__ __forceinline__ float tts_activate(float v, int kind, const float* alpha, int c) {
+    if (kind == ACT_LEAKY02) return v > 0.0f ? v : v * 0.2f;
+    if (kind == ACT_LEAKY01) return v > 0.0f ? v : v * 0.1f;
+    if (kind == ACT_LEAKY001) return v > 0.0f ? v : v * 0.01f;
+    if (kind == ACT_GELU) { const float u = 0.79788456080286535588f * (v + 0.044715f * ((v * v) * v)); return (0.5f * v) * (1.0f + tanh_e(u)); }
+    const float al = alpha[c]; const float s = sinf(al * v); return v + (s * s) / al;
 }
+__global__ void k_tts_act(float* x, long n, int C, int kind, const float* alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    x[i] = tts_activate(x[i], kind, alpha, (int)(i % C));
+}
+// instance-norm affine and the activation that always follows it, one pass over the rows instead of two (the same f32 value goes into the activation either way)
+__global__ void k_tts_in_apply_act(float* x, long n, int C, const float* stats, const float* gb, int kind, const float* alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const int c = (int)(i % C);
+    const float v = ((x[i] - stats[c]) * stats[C + c]) * (1.0f + gb[c]) + gb[C + c];
+    x[i] = tts_activate(v, kind, alpha, c);
+}
+__global__ void k_tts_add_scale(float* a, const float* b, float f, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = (a[i] + b[i]) * f; }
 __global__ void k_tts_add(float* a, const float* b, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i] + b[i]; }
 __global__ void k_tts_scale(float* a, float f, long n) { const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i] * f; }
 // dst[t][c0 + c] = src[row(t)][c]: concat pieces, nearest up-sampling (div = 2), row gathers (rows != nullptr), the reflection pad (shift = 1)
@@ -520,7 +525,7 @@ struct GpuBackend {
         return o;
     }
     void ada_ln(Buf& x, const Buf& gb) { hipLaunchKernelGGL(k_tts_ln, dim3(x.T), dim3(256), 0, s, x.p, x.C, (const float*)nullptr, (const float*)nullptr, gb.p, 1, 1e-5f); }
-    void ada_in(Buf& x, const Buf& gb) {
+    void ada_in_act(Buf& x, const Buf& gb, Act a, const Tensor* alpha) {
         const int nchunk = (x.T + 511) / 512; const dim3 grid(nchunk, (x.C + 63) / 64);
         double* part = (double*)arena_get(t, sizeof(double) * (size_t)nchunk * x.C);
         double* mean = (double*)arena_get(t, sizeof(double) * x.C); float* stats = (float*)arena_get(t, sizeof(float) * 2 * x.C);
@@ -530,7 +535,7 @@ struct GpuBackend {
         hipLaunchKernelGGL(k_tts_in_partial, grid, dim3(64), 0, s, x.p, x.T, x.C, (const double*)mean, part);
         hipLaunchKernelGGL(k_tts_in_final, dim3((x.C + 255) / 256), dim3(256), 0, s, part, nchunk, x.T, x.C, mean, stats, 1);
         const long n = (long)x.T * x.C;
-        hipLaunchKernelGGL(k_tts_in_apply, dim3(blocks(n)), dim3(256), 0, s, x.p, n, x.C, stats, gb.p);
+        hipLaunchKernelGGL(k_tts_in_apply_act, dim3(blocks(n)), dim3(256), 0, s, x.p, n, x.C, stats, gb.p, (int)a, alpha ? dev(*alpha) : nullptr);
     }
     void act(Buf& x, Act a, const Tensor* alpha) { const long n = (long)x.T * x.C;
     hipLaunchKernelGGL(k_tts_act, dim3(blocks(n)), dim3(256), 0, s, x.p, n, x.C, (int)a, alpha ? dev(*alpha) : nullptr); }
@@ -549,6 +554,7 @@ struct GpuBackend {
         return o;
     }
     void add(Buf& a, const Buf& b) { const long n = (long)a.T * a.C; hipLaunchKernelGGL(k_tts_add, dim3(blocks(n)), dim3(256), 0, s, a.p, b.p, n); }
+    void add_scale(Buf& a, const Buf& b, float f) { const long n = (long)a.T * a.C; hipLaunchKernelGGL(k_tts_add_scale, dim3(blocks(n)), dim3(256), 0, s, a.p, b.p, f, n); }
     void scale(Buf& a, float f) { const long n = (long)a.T * a.C; hipLaunchKernelGGL(k_tts_scale, dim3(blocks(n)), dim3(256), 0, s, a.p, f, n); }
     Buf upsample2(const Buf& x) { Buf o = make(2 * x.T, x.C); if (o.p) put_cols(x, o, 0, 2, nullptr, 0); return o; }
     Buf reflect_pad_left(const Buf& x) { Buf o = make(x.T + 1, x.C); if (o.p) put_cols(x, o, 0, 1, nullptr, 1); return o; }
