@@ -702,8 +702,8 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 // then agree on which k sits in which slot) and V^T (already this kernel's layout).  One read of a sequence's K / V^T serves up to 128 of its prompt tokens instead of one.
 // frag: K / V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off)      // per sequence of the pass: first row, rows, window slot
 struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };
-template <bool XP>
-__global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
+template <bool XP, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
                                                            int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp, int ksw_r3) {
     __shared__ __attribute__((aligned(1024))) char lds[2][2][64 * 128];   // [buffer][K | V^T][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -867,7 +867,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_encoder16(const half_t* Qh, con
 static int attn_ksw_r3() { static const int v = getenv("SKW_ATTN_KSW_R3") ? atoi(getenv("SKW_ATTN_KSW_R3")) : 0; return v; }
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s) {
     const int qblocks = (n_ctx + A16_QB - 1) / A16_QB;
-    hipLaunchKernelGGL(k_attn_encoder16<false>, dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{}, attn_ksw_r3());
+    // registers capped at 128 (13 dwords of scratch per lane) so that four workgroups share a CU instead of three: 9.44-9.50 against 9.64-9.77 ms per batch in a same-box A/B
+    // (profiles/r04i/r04t); the waves of different workgroups are what overlaps one's exponentials with another's MFMAs.  SKW_ATTN_OCC=2: 143 registers, three per CU
+    static const int occ4 = getenv("SKW_ATTN_OCC") ? atoi(getenv("SKW_ATTN_OCC")) == 4 : 1;
+    if (occ4) hipLaunchKernelGGL((k_attn_encoder16<false, 4>), dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{},
+        attn_ksw_r3());
+    else hipLaunchKernelGGL((k_attn_encoder16<false, 2>), dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{}, attn_ksw_r3());
 }
 // the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
