@@ -54,6 +54,12 @@ def launch_ranks(args):
     """--gpus N > 1 without a launcher: start N fresh ranks.  This process must not initialise the GPU (a later exec / fork of a
     GPU-initialised process is what the pool forbids), so it only counts devices and relays rank 0's line."""
     import torch
+    from streamkit_amd import dist as skd
+    if args.gpus > skd.self_started_rank_limit():
+        sys.stderr.write("bench.py: --gpus %d without a launcher would start %d rank processes itself; self-started jobs are limited to %d (streamkit_amd/dist.py, the GPU pool's process guard).\n"
+                         "Launch the ranks the way the driver does: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...\n"
+                         % (args.gpus, args.gpus, skd.self_started_rank_limit(), args.gpus, args.gpus))
+        return 2
     n_dev = torch.cuda.device_count()          # does not create a HIP context
     if n_dev < args.gpus and not args.share_gpu:
         sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, n_dev))
@@ -79,17 +85,19 @@ def launch_ranks(args):
     return 0
 
 
-def plugin_path_leg(args, model_path, host_pcm, B, reps=3):
+def plugin_path_leg(model_path, host_pcm, B, precision, key, reps=3):
     """SURVEY.md 8(d) config 2 as written: B concurrent plugin instances (libwhisper.so through the StreamKit native ABI v2, driven by the C++ mini-host that
     replays wrapper.rs's call sequence), each fed its 30 s clip from host memory in 960-sample RawAudio packets and flushed; wall clock from the first packet
     to the last Transcription packet.  Includes packet feeding, the 512-sample VAD framing (vad_mode: always), batch formation across instances, H2D copies,
-    JSON building.  Model load is excluded the way the reference excludes it: the process-global context cache (a throw-away first round warms it)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    JSON building.  Model load is excluded the way the reference excludes it: the process-global context cache (a throw-away first round warms it).
+    precision None = the `precision` parameter is NOT sent: what a host that only swaps libwhisper.so gets (the plugin's default, exact)."""
     import ctypes as C
-    import minihost
+    from streamkit_amd import minihost
     plug = minihost.Plugin()
     pcms = [host_pcm[i] for i in range(B)]
-    params = {"model_path": model_path, "vad_mode": "always", "flush_tail": True, "max_batch": B, "batch_window_ms": 40, "precision": args.precision, "suppress_non_speech_tokens": True}
+    params = {"model_path": model_path, "vad_mode": "always", "flush_tail": True, "max_batch": B, "batch_window_ms": 40, "suppress_non_speech_tokens": True}
+    if precision is not None:
+        params["precision"] = precision
     best, n_seg, log0 = None, 0, ""
     for rep in range(reps + 1):
         nodes = [plug.create_node(params) for _ in range(B)]
@@ -101,7 +109,7 @@ def plugin_path_leg(args, model_path, host_pcm, B, reps=3):
         for n in nodes:
             n.destroy()
         if not okp:
-            return {"value_plugin_path": None, "plugin_path": {"error": "an instance did not emit exactly one Transcription packet: %s" % [len(o) for o in outs]}}
+            return {"value_" + key: None, key: {"error": "an instance did not emit exactly one Transcription packet: %s" % [len(o) for o in outs]}}
         n_seg = sum(len(json.loads(o[0][2].decode())["segments"]) for o in outs)
         if rep > 0:
             best = ms if best is None else min(best, ms)
@@ -109,20 +117,49 @@ def plugin_path_leg(args, model_path, host_pcm, B, reps=3):
     loads, hits = C.c_int(), C.c_int()
     L.skw_whisper_plugin_cache_stats(C.byref(loads), C.byref(hits))
     audio_s = sum(p.size for p in pcms) / 16000.0
-    return {"value_plugin_path": round(audio_s / (best * 1e-3), 1),
-            "plugin_path": {"what": "%d libwhisper.so instances (native plugin ABI v2, mini-host), each fed one 30 s clip as 960-sample packets from host memory, then flushed: "
-                                    "first packet in -> last Transcription JSON out; best of %d rounds" % (B, reps),
-                            "wall_ms": round(best, 2), "instances": B, "packet_samples": 960, "batch_window_ms": 40, "vad_mode": "always", "precision": args.precision,
-                            "segments": n_seg, "model_loads_in_process": loads.value, "context_cache_hits": hits.value, "first_create_log": log0}}
+    return {"value_" + key: round(audio_s / (best * 1e-3), 1),
+            key: {"what": "%d libwhisper.so instances (native plugin ABI v2, mini-host), each fed one 30 s clip as 960-sample packets from host memory, then flushed: "
+                          "first packet in -> last Transcription JSON out; best of %d rounds" % (B, reps),
+                  "wall_ms": round(best, 2), "instances": B, "packet_samples": 960, "batch_window_ms": 40, "vad_mode": "always",
+                  "precision_param": precision if precision is not None else "(not sent: the plugin's default, exact)", "model_file": os.path.basename(model_path),
+                  "segments": n_seg, "model_loads_in_process": loads.value, "context_cache_hits": hits.value, "first_create_log": log0}}
+
+
+def quant_leg(f16_path, host_pcm, dev_ptrs, ns, B, device, kind="q5_1"):
+    """The reference's DEFAULT model is a q5_1 file (plugins/native/whisper/src/lib.rs:114-116).  The benchmark model re-encoded as whisper.cpp's quantize tool lays it out
+    (tools/quantize_ggml.py), run in the exact precision = ggml's own arithmetic for such files (q8 activation blocks, integer block dots, f32 scales): engine level
+    (`value_quant_<kind>`, PCM resident in HBM like `value`) and through the plugin with no `precision` parameter (`value_plugin_path_<kind>_default`)."""
+    from streamkit_amd import engine
+    qpath = f16_path.replace(".bin", "_%s.bin" % kind)
+    if not os.path.exists(qpath):
+        tmp = "%s.tmp%d" % (qpath, os.getpid())
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "quantize_ggml.py"), f16_path, tmp, kind])
+        os.replace(tmp, qpath)
+    m = engine.Model(qpath, device=device)
+    ctx = engine.Context(m, max_batch=B, max_samples=480000)
+    ctx.set_precision("exact")
+    p = ctx.default_params(); p.suppress_nst = 1
+    ctx.full_batch(None, p, device_ptrs=dev_ptrs, n_samples=ns)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter(); ctx.full_batch(None, p, device_ptrs=dev_ptrs, n_samples=ns); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    t = ctx.timing()
+    out = {"value_quant_" + kind: round(B * 30.0 / best, 1),
+           "quant_" + kind: {"what": "the benchmark model as a %s GGML file (the reference's default file type), exact precision = ggml's arithmetic for block-quantised weights, "
+                                     "same %d clips resident in HBM; best of 2" % (kind, B), "ms_per_step": round(best * 1e3, 2), "encode_ms": round(t["encode_ms"], 2),
+                             "decode_ms": round(t["decode_ms"], 2), "ggml_type_running": m.quant}}
+    ctx.close(); m.close()
+    out.update(plugin_path_leg(qpath, host_pcm, B, None, "plugin_path_%s_default" % kind, reps=2))
+    return out
 
 
 def tts_leg(reps=5):
     """BASELINE.json configs[4]'s second half, reported beside the headline (never part of `value`): libskw_tts.so — the published Kokoro-82M architecture in fp32 HIP
     (seeded weights, PARITY UNPINNED) — speaking ~30 s in one call; GPU-event time of the call, best of `reps`."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import kokoro_lib
-    tts = kokoro_lib.Tts(kokoro_lib.synth_kokoro_dir("kokoro82m"))
+    from streamkit_amd import tts as skt
+    tts = skt.Tts(skt.synth_kokoro_dir("kokoro82m"))
     try:
         ids = np.concatenate([[0], np.random.default_rng(5).integers(1, 60, 300), [0]]).astype(np.int32)
         y, _ = tts.generate(None, 50, 1.0, ids=ids)
@@ -319,7 +356,19 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        # per-kernel-class HIP-event timing on the engine's streams, one extra (untimed) step
+        # (1) the dominant kernel's launches in the TIMED configuration — step graphs, the engine's row groups on their streams, eight steps enqueued ahead — stamped by the
+        # kernel's own clock (include/skw_engine.h skw_ctx_kernel_clock: first wave in -> last wave out, live rows per launch); one graph-capturing step, then the measured one
+        kclk = None
+        if fast:
+            try:
+                ctx.kernel_clock(True)
+                ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
+                ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
+                kclk = ctx.kernel_clock_get(); kclk["step"] = ctx.timing()
+                ctx.kernel_clock(False)
+            except RuntimeError as e:
+                kclk = {"error": str(e), "launches": 0}
+        # (2) per-kernel-class HIP-event timing on the engine's streams, one extra (untimed, eager) step: the class table and which kernel dominates
         ctx.profile(True)
         ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
         prof = ctx.profile_get()
@@ -358,27 +407,55 @@ def main():
                      "avg_launch_ms": round(p["ms"] / max(1, p["count"]), 4), "launches": p["count"], "kernels": kern})
         if name == "k_dec_cross_attn":
             # the profile class covers the step's cross attention in either precision; the symbol rocprofv3 shows for it:
-            roof["symbol"] = ("k_dec_cross_attn16<3,3,true,2> (one streaming pass over fragment-order K / V^T, non-temporal loads)" if fast and os.environ.get("SKW_XATTN_FRAG", "1") != "0"
+            roof["symbol"] = ("k_dec_cross_attn16<3,3> (one streaming pass over fragment-order K / V^T, non-temporal loads)" if fast and engine.switches()["XATTN_FRAG"][1] != 0
                               else "k_dec_cross_attn<24,4,3,...> (two-phase kernel over the row layouts)")
             # `achieved` books the bytes of LIVE rows only (a finished sequence's workgroups return at once): sum over launches of 4 x live rows x n_ctx x d,
             # over the summed launch time.  Beside it: one full launch (all rows live) in isolation, back to back over 12 different K / V^T images.
             import ctypes as C
             Lb = engine.lib()
-            Lb.skw_debug_xattn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
-            us = C.c_float()
-            if Lb.skw_debug_xattn(ctx.h, B, hp.n_text_layer, 0, 240, C.byref(us)) == 0 and us.value > 0:
-                full_bytes = 4.0 * B * hp.n_audio_ctx * hp.n_text_state
-                roof["full_launch"] = {"rows": B, "bytes": full_bytes, "us": round(us.value, 2), "achieved": round(full_bytes / us.value / 1e3, 1), "unit": "GB/s",
-                                       "frac": round(full_bytes / us.value / 1e3 / HBM_PEAK_GBS, 4)}
-            groups = int(os.environ.get("SKW_DECODE_GROUPS", "0") or 0) or (2 if fast and B >= 64 else 1)
-            roof["row_groups"] = groups
+            groups, grows = timing["decode_groups"], timing["decode_group_rows"]      # what the timed run's decode step actually was (skw_timing)
+            row_bytes = 4.0 * hp.n_audio_ctx * hp.n_text_state                          # K and V^T of one row, f16
+            roof["row_groups"] = groups; roof["rows_per_launch"] = grows
+            roof["booking"] = "algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state per launch (K and V^T, f16); finished rows' workgroups return at once and are not booked"
+            def isolated(rows):      # the same kernel, `rows` rows all live, alone on the GPU, back to back over 12 different K / V^T images: HIP events AND the in-kernel clock on the same launches
+                ue, uc = C.c_float(), C.c_float()
+                if Lb.skw_debug_xattn(ctx.h, rows, hp.n_text_layer, 0, 240, C.byref(ue), C.byref(uc)) != 0 or ue.value <= 0:
+                    return None
+                by = row_bytes * rows
+                return {"rows": rows, "bytes": by, "us": round(ue.value, 2), "us_in_kernel_clock": round(uc.value, 2) if uc.value > 0 else None,
+                        "achieved": round(by / ue.value / 1e3, 1), "unit": "GB/s", "frac": round(by / ue.value / 1e3 / HBM_PEAK_GBS, 4)}
+            full = isolated(B)
+            if full:
+                roof["full_launch"] = full
+            if kclk and kclk.get("launches", 0) > 0:
+                # in-kernel spans of the timed configuration + the dispatch / completion edges an event-stamped (= rocprofv3) duration adds, measured on isolated launches
+                # of the SAME shape with both instruments
+                iso = isolated(grows) if grows != B else full
+                edge = (iso["us"] - iso["us_in_kernel_clock"]) if iso and iso["us_in_kernel_clock"] else 0.0
+                n_l = kclk["launches"]; span = kclk["sum_us"] / n_l; live = kclk["sum_live_rows"] / n_l
+                dur = span + edge
+                ach = row_bytes * live / dur / 1e3
+                roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(dur * 1e-3, 5), "launches": n_l,
+                             "avg_launch_in_kernel_us": round(span, 3), "dispatch_edges_us": round(edge, 3), "live_rows_per_launch": round(live, 3),
+                             "live_row_fraction": round(live / grows, 4), "min_launch_in_kernel_us": round(kclk["min_us"], 2), "max_launch_in_kernel_us": round(kclk["max_us"], 2),
+                             "achieved_in_kernel": round(row_bytes * live / span / 1e3, 2),
+                             "clocked_step_ms": {"decode": round(kclk["step"]["decode_ms"], 2), "total": round(kclk["step"]["total_ms"], 2),
+                                                 "note": "the step the launches were clocked in: graph-launched like the timed steps (compare modes.%s.decode_ms)" % args.precision},
+                             "isolated_same_shape": iso})
+                roof["timing"] = ("every launch of the graph-launched decode step (%d row group(s), %d rows per launch) stamped by the kernel itself on the device's %d kHz constant clock: "
+                                  "first wave in -> last wave out; avg_launch_ms = that span + dispatch_edges_us, the difference between HIP-event (hipExtLaunchKernelGGL begin / end = "
+                                  "rocprofv3's duration) and in-kernel timing of isolated launches of the same shape.  Compare profiles/: rocprofv3 --kernel-trace --stats of this command"
+                                  % (groups, grows, kclk["clock_khz"]))
+                roof["eager_profile_avg_launch_ms"] = round(p["ms"] / max(1, p["count"]), 4)
+            else:
+                roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * row_bytes * max(1, grows)), 4) if grows else None
+                roof["timing"] = "per launch, HIP events stamped at the kernel's own begin and end (hipExtLaunchKernelGGL) in an eager profiled step"
+                if kclk and kclk.get("error"):
+                    roof["kernel_clock_error"] = kclk["error"]
             if groups > 1:
                 roof["row_groups_note"] = ("the decode step runs as %d row groups on %d streams (the engine's default for this precision and batch: +1.3 %% on the whole step, profiles/r04g): "
                                            "a launch covers %d rows and shares HBM with the other group's kernels, so `frac` is per launch under that sharing; "
-                                           "`full_launch` is one %d-row launch alone" % (groups, groups, B // groups, B))
-            roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * 4.0 * (B // groups) * hp.n_audio_ctx * hp.n_text_state), 4)
-            roof["booking"] = "algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state per launch (K and V^T, f16), live rows counted per step on the host"
-            roof["timing"] = "per launch, HIP events stamped at the kernel's own begin and end (hipExtLaunchKernelGGL) on the engine's stream: the duration rocprofv3 reports for the same kernel"
+                                           "`full_launch` is one %d-row launch alone" % (groups, groups, grows, B))
         # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times
         nwin, nsteps, nrow = timing["n_windows"], timing["n_decode_steps"], timing["n_row_steps"]
         d, dt_, nc, L = hp.n_audio_state, hp.n_text_state, hp.n_audio_ctx, hp.n_text_layer
@@ -403,7 +480,17 @@ def main():
         out["roofline"] = roof
 
     if rank == 0 and world == 1 and not args.no_plugin_path:
-        out.update(plugin_path_leg(args, path, host, B))
+        # the drop-in boundary, driver-run: (i) the headline precision, (ii) what a host gets that only swaps the .so (no `precision` parameter -> exact, the precision
+        # that is bit-identical to the CPU oracle), (iii) the same on the reference's default file type (q5_1)
+        out.update(plugin_path_leg(path, host, B, args.precision, "plugin_path"))
+        out.update(plugin_path_leg(path, host, B, None, "plugin_path_default", reps=2))
+        try:
+            out.update(quant_leg(path, host, ptrs, ns, B, local_rank))
+        except Exception as e:      # a side row must not cost the headline line
+            out["quant_q5_1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["config"]["drop_in_defaults"] = ("a host that only replaces libwhisper.so sends no `precision` parameter and gets the exact precision (the one bit-identical to oracle/): "
+                                             "value_plugin_path_default on an f16 file, value_plugin_path_q5_1_default on the reference's default file type; "
+                                             "value / value_plugin_path opt into precision=f16_mfma (teacher-forced tolerance mode)")
 
     if rank == 0 and world == 1 and not args.no_tts:
         try:

@@ -152,12 +152,21 @@ typedef struct { float mel_ms, encode_ms, decode_ms, total_ms; int32_t n_windows
                  /* n_row_steps: sum over rows of the decode steps the row was live in (a finished row's attention kernels return at once:
                     the HBM bytes of a step scale with its live rows) */
                  int32_t n_row_steps;
+                 /* how the decode step of the call's last window pass ran: row groups (each a step graph on its own stream) and rows in the first group — what a per-launch
+                    roofline of the decode kernels has to be booked against (bench.py reads these instead of restating the engine's default) */
+                 int32_t decode_groups, decode_group_rows;
 } skw_timing;
 void skw_ctx_last_timing(const skw_ctx*, skw_timing* out);
 /* per-kernel-class event timing (adds an event pair around every launch; use for roofline accounting, not for the timed run).
  * classes: 0 k_gemm, 1 k_gemm_smallm, 2 k_attn_encoder, 3 k_layernorm, 4 k_mel, 5 k_dec_self_attn, 6 k_dec_sample, 7 other, 8 k_dec_cross_attn */
 void skw_ctx_profile(skw_ctx*, int on);
 int  skw_ctx_profile_get(skw_ctx*, int cls, char* name, size_t name_len, long* count, double* ms, double* algorithmic_flops, double* algorithmic_bytes);
+/* In-kernel launch clock of the decode step's dominant kernel (the f16_mfma cross attention).  HIP events cannot sit between the kernels of a captured step graph, and an eager,
+ * event-stamped step is not the timed configuration (two row groups interleave differently): armed, the kernel itself records first-wave-in and last-wave-out of every launch on the
+ * device's constant-rate clock while the step graphs run as in any other call.  skw_ctx_kernel_clock_get: the launches the last skw_full_batch recorded — count, summed microseconds,
+ * summed live rows (a launch's algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state), shortest / longest launch, the clock's rate in kHz.  Diagnostic; off by default. */
+int  skw_ctx_kernel_clock(skw_ctx*, int on);
+int  skw_ctx_kernel_clock_get(skw_ctx*, long* launches, double* sum_us, double* sum_live_rows, double* min_us, double* max_us, int* clock_khz);
 /* the HIP stream the engine launches on (opaque hipStream_t) */
 void* skw_ctx_stream(const skw_ctx*);
 

@@ -9,6 +9,8 @@
 #include "skw_kernels.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -249,7 +251,7 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     }
     fclose(f); f = nullptr;
     {   // ggml's q8 arithmetic needs every matmul weight in one block type (what whisper.cpp's quantize writes); anything else runs as the f16 twin
-        int qt = 0; bool uniform = quant_mode != 0 && !getenv("SKW_QUANT_TWIN");
+        int qt = 0; bool uniform = quant_mode != 0 && !skw_sw(SW_QUANT_TWIN);
         for (auto& t : ts) if (is_matmul_weight(t)) { if (t.qblk.empty()) uniform = false; else if (!qt) qt = t.qtype; else if (qt != t.qtype) uniform = false; }
         m->quant = (uniform && qt) ? qt : 0;
     }
@@ -278,7 +280,7 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     m->d_pe = dev_upload(m, as_f32(t, tmp), t->n);
     bool ok = true;
     // fragment-order images of the decoder projections (SkwGemmArgs::Wf); =0: the f16 decode kernels read weight rows
-    const bool wfrag_on = !(getenv("SKW_DEC_WFRAG") && atoi(getenv("SKW_DEC_WFRAG")) == 0);
+    const bool wfrag_on = skw_sw(SW_DEC_WFRAG) != 0;
     ok = ok && up_lin(m, ts, "encoder.conv1.weight", "encoder.conv1.bias", &m->conv1, err, errlen);
     ok = ok && up_lin(m, ts, "encoder.conv2.weight", "encoder.conv2.bias", &m->conv2, err, errlen);
     ok = ok && up_ln(m, ts, "encoder.ln_post.weight", "encoder.ln_post.bias", &m->ln_post, err, errlen);
@@ -364,7 +366,7 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     }
     // Encoder weights as fragment-order images too (k_gemm16w, the f16_mfma precision's big GEMM: weights go from these straight into MFMA operands).  Rows in the
     // order of the epilogue that consumes the product: the kperm'ed-output epilogues (Q / K heads, FC1 and conv1 GELU) want strip row p = logical feature kperm^-1(p).
-    if (ok && !(getenv("SKW_ENC_WFRAG") && atoi(getenv("SKW_ENC_WFRAG")) == 0)) {
+    if (ok) {
         auto mke = [&](DevLin& X, int perm) {
             if ((X.n_out & 15) || (X.k_pad & 63) || !X.w) return;
             half_t* img = nullptr;
@@ -386,8 +388,9 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
         if (hipDeviceSynchronize() != hipSuccess) ok = false;
     }
     if (!ok) return fail2();
-    if ((m->hp.n_audio_state / m->hp.n_audio_head) != 64 || (m->hp.n_text_state / m->hp.n_text_head) != 64 || m->hp.n_audio_state % 64 || m->hp.n_audio_state > 1536) {
-        set_err(err, errlen, "unsupported model geometry (head dim must be 64, state <= 1536)"); return fail2();
+    if ((m->hp.n_audio_state / m->hp.n_audio_head) != 64 || (m->hp.n_text_state / m->hp.n_text_head) != 64 || m->hp.n_audio_state % 128 || m->hp.n_text_state % 128 || m->hp.n_audio_state > 1536) {
+        // (a multiple of 128: the decoder's contractions are four contiguous K segments, D3'; every Whisper width — 384, 512, 768, 1024, 1280 — is one)
+        set_err(err, errlen, "unsupported model geometry (head dim must be 64, state a multiple of 128 and <= 1536)"); return fail2();
     }
     hipDeviceSynchronize();
     return m;
@@ -403,6 +406,44 @@ extern "C" void skw_full_default_params(skw_full_params* p) {
     p->temperature = 0.0f; p->temperature_inc = 0.2f;
 }
 
+// ------------------------------------------------------------------ the switchboard (SkwSw, skw_kernels.h)
+struct SwDef { const char* name; int def; const char* what; };
+static const SwDef g_sw_defs[SW_COUNT] = {
+    {"QUANT_TWIN", 0, "1: a block-quantised file runs as its dequantised f16 twin in both precisions (model load)"},
+    {"DEC_WFRAG", 1, "0: the decode GEMMs read their weights as rows, no fragment-order images are built (model load)"},
+    {"GEMM16W", 1, "0: the encoder / cross-K-V / prompt-pass GEMMs run k_gemm16 (both operands through LDS) instead of k_gemm16w (weights from fragment-order images)"},
+    {"GEMM16W_NGROUPS", 0, "k_gemm16w's feature-split tile walk: 0 automatic, 1 off, 2 / 4 / 8 forced"},
+    {"XATTN_FRAG", 1, "0: f16_mfma keeps cross K / V^T as rows and runs the two-phase cross attention (context creation)"},
+    {"DECODE_GRAPHS", -1, "0: the decode steps are launched eagerly instead of as captured step graphs (context creation)"},
+    {"DECODE_GROUPS", 0, "row groups of the decode step, each on its own stream: 0 automatic (2 for f16_mfma at >= 64 rows, else 1), n forced (context creation)"},
+    {"DEC_LN_STATS", 1, "0: f16_mfma launches the decode step's LayerNorms instead of normalising inside the consuming GEMM (context creation)"},
+    {"PROMPT_PASS", 1, "0: the prompt is fed one token per step instead of in one multi-row pass (context creation)"},
+    {"PROMPT_SMALL_GEMM", 0, "1: a prompt pass of >= 256 rows keeps the small-M decode GEMMs instead of the big-tile kernel (f16_mfma)"},
+    {"PROMPT_XATTN_MQ", 1, "0: the f16_mfma prompt pass streams cross K / V^T once per prompt token (single-query kernel) instead of once per 128 (multi-query)"},
+    {"DEC_AFRAG", 1, "0: the f16_mfma decode step hands attention / FC1 outputs to the next GEMM as rows instead of fragment-order images"},
+    {"DEC_ATTN_FASTV", 1, "0: the f16_mfma decode self-attention uses the exact form's per-channel P.V chain"},
+    {"Q8_LDS", 1, "0: ggml-arithmetic GEMMs of quantised files take their operands from global memory (the form tails and odd geometries always use)"},
+    {"RESAMPLE_SCAN", 0, "1: the linear resampler's index sequence comes from the single-lane sequential walk only"},
+    {"RESAMPLE_NO_HOST_WALK", 0, "1: long resampler calls step the chunk starts on the device instead of on the host"},
+};
+static int g_sw_val[SW_COUNT];
+static std::once_flag g_sw_once;
+static std::atomic<unsigned> g_sw_epoch{0};
+// the one place this library reads its environment: SKW_<NAME> for every row of the table, once
+static void sw_init() {
+    for (int i = 0; i < SW_COUNT; ++i) { const std::string k = std::string("SKW_") + g_sw_defs[i].name; const char* e = getenv(k.c_str()); g_sw_val[i] = e ? atoi(e) : g_sw_defs[i].def; }
+}
+int skw_sw(int id) { std::call_once(g_sw_once, sw_init); return g_sw_val[id]; }
+unsigned skw_sw_epoch() { return g_sw_epoch.load(); }
+extern "C" int skw_debug_switch_count(void) { return SW_COUNT; }
+extern "C" const char* skw_debug_switch_name(int i) { return i >= 0 && i < SW_COUNT ? g_sw_defs[i].name : nullptr; }
+extern "C" const char* skw_debug_switch_what(int i) { return i >= 0 && i < SW_COUNT ? g_sw_defs[i].what : nullptr; }
+extern "C" int skw_debug_switch_default(int i) { return i >= 0 && i < SW_COUNT ? g_sw_defs[i].def : 0; }
+static int sw_find(const char* name) { for (int i = 0; i < SW_COUNT; ++i) if (!strcmp(name, g_sw_defs[i].name)) return i; return -1; }
+extern "C" int skw_debug_switch_get(const char* name) { const int i = sw_find(name); return i < 0 ? -1 : skw_sw(i); }
+// tests flip a switch in-process (takes effect at the point the table says: the next launch, context creation or model load; cached step graphs are re-captured)
+extern "C" int skw_debug_switch_set(const char* name, int value) { const int i = sw_find(name); if (i < 0) return -1; (void)skw_sw(i); g_sw_val[i] = value; g_sw_epoch.fetch_add(1); return 0; }
+
 // ------------------------------------------------------------------ context / workspace
 struct ProfState;
 struct skw_ctx {
@@ -415,7 +456,7 @@ struct skw_ctx {
     hipStream_t stream = nullptr; hipEvent_t ev[6] = {};
     hipStream_t cur = nullptr;                       // stream the launch helpers enqueue on (== stream outside the decode groups)
     static const int MAX_GROUPS = 8; hipStream_t gstream[MAX_GROUPS] = {}; hipEvent_t gev[MAX_GROUPS] = {}; int n_groups = 1;
-    struct StepGraph { int g, r0, n, precision, ln_stats; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
+    struct StepGraph { int g, r0, n, precision, ln_stats, kclk; unsigned sw_epoch; SkwLogitParams lp; hipGraphExec_t exec; }; std::vector<StepGraph> step_graphs; int use_graphs = 1;
     char errbuf[512] = {0};
     std::vector<void*> allocs;
     // front end
@@ -431,8 +472,7 @@ struct skw_ctx {
     half_t *selfK = nullptr, *selfV = nullptr; float* logits = nullptr;
     float *y32 = nullptr, *h32 = nullptr, *encq32 = nullptr, *dy32 = nullptr, *datt32 = nullptr, *dh32 = nullptr;
     int8_t* q8_a = nullptr; float *q8_d = nullptr, *q8_s = nullptr; int q8_kmax = 0;
-    unsigned* ln_cnt = nullptr;
-    // allocated at the first temperature retry (move_retry_slots)   // ln_cnt: row-block arrival counters of the decode GEMMs' LayerNorm tail (zero between launches)
+    // allocated at the first temperature retry (move_retry_slots)
     half_t *stageK = nullptr, *stageV = nullptr; int* slot_map = nullptr;
     int* prompt_buf = nullptr;                       // [B][SKW_PROMPT_CAP] per-row prompts
     int* row_tok = nullptr;                          // per-row prompt token / detected language scratch
@@ -449,12 +489,17 @@ struct skw_ctx {
     int ln_stats_on = 1;                             // LayerNorm folded into the decode GEMMs (f16_mfma); SKW_DEC_LN_STATS=0 or skw_debug_set_ln_stats(ctx, 0): LayerNorm kernels
     // profiling: rows of the step about to be launched that are still decoding (finished rows return at once in the attention kernels: their bytes are not booked)
     int live_rows_hint = -1;
+    // the in-kernel launch clock of the decode step's cross attention (skw_ctx_kernel_clock): one SkwKClk per (row group, layer); cur_group: the group run_decoder_step is enqueuing
+    void* kclk = nullptr; int kclk_on = 0, kclk_khz = 0, cur_group = 0;
     int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
     skw_timing timing{};
     int last_enc_B = 0;
     struct WsEntry { const char* name; void** slot; size_t bytes; bool zero; };      // one workspace buffer: the field it fills and its size (skw_ctx_create)
     std::vector<WsEntry> ws_table;
 };
+struct SkwKClk;
+static SkwKClk* kclk_node(const skw_ctx* c, int g, int l);
+static int kclk_reset(skw_ctx* c);
 // name of the first workspace buffer whose pointer is null, or nullptr when every entry of the table is allocated
 static const char* ws_first_null(const skw_ctx* c) {
     if (c->ws_table.empty()) return "(empty workspace table)";
@@ -481,18 +526,18 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     c->n_len_max = (max_samples + WHISPER_SAMPLE_RATE * 30 + 2 * (WHISPER_N_FFT / 2) - WHISPER_N_FFT) / WHISPER_HOP + 1;
     const skw_hparams& hp = m->hp; const int B = max_batch, nc = hp.n_audio_ctx, T = 2 * nc, d = hp.n_audio_state, dt = hp.n_text_state;
     c->Tpad = (nc + 31) & ~31;
-    if (getenv("SKW_XATTN_FRAG")) c->kv_frag_on = atoi(getenv("SKW_XATTN_FRAG")) != 0;
+    c->kv_frag_on = skw_sw(SW_XATTN_FRAG) != 0;
     bool ok = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ok = false;
     c->cur = c->stream;
     // decode groups: the step kernels are latency-bound chains that leave most CUs idle, so independent row groups run concurrently
     // -1 = default (see skw_full_batch): one row group as a captured step graph in both precisions (dependent chains on two streams do
     // not overlap on this part: tools/probe/probe_stream_overlap.hip)
-    { const char* e = getenv("SKW_DECODE_GRAPHS"); c->use_graphs = e ? atoi(e) : -1; }
-    { const char* e = getenv("SKW_DEC_LN_STATS"); c->ln_stats_on = e ? (atoi(e) != 0) : 1; }
-    { const char* e = getenv("SKW_PROMPT_PASS"); c->prompt_pass_on = e ? (atoi(e) != 0) : 1; }
+    c->use_graphs = skw_sw(SW_DECODE_GRAPHS);
+    c->ln_stats_on = skw_sw(SW_DEC_LN_STATS) != 0;
+    c->prompt_pass_on = skw_sw(SW_PROMPT_PASS) != 0;
     c->rows_cap = std::max(max_batch, std::min(max_batch * (SKW_PROMPT_CAP - 1), 4096));
-    { const char* e = getenv("SKW_DECODE_GROUPS"); c->n_groups = e ? atoi(e) : -1; if (c->n_groups == 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS; }
+    c->n_groups = skw_sw(SW_DECODE_GROUPS); if (c->n_groups <= 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS;
     for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
@@ -543,7 +588,6 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     want("selfK", c->selfK, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     want("selfV", c->selfV, (size_t)hp.n_text_layer * B * hp.n_text_ctx * dt, true);
     want("logits", c->logits, (size_t)B * hp.n_vocab, false);
-    want("ln_cnt", c->ln_cnt, ((size_t)B + 16) * SKW_LN_CNT_STRIDE, true);
     want("st", c->st, B, true);
     want("toks", c->toks, (size_t)B * c->max_tok, true);
     want("probs", c->probs, (size_t)B * skw_probs_row_floats(hp.n_vocab), false);
@@ -592,7 +636,7 @@ extern "C" void skw_ctx_free(skw_ctx* c) {
     c->step_graphs.clear();
     for (int g = 0; g < skw_ctx::MAX_GROUPS; ++g) { if (c->gstream[g]) { hipStreamSynchronize(c->gstream[g]); hipStreamDestroy(c->gstream[g]); } if (c->gev[g]) hipEventDestroy(c->gev[g]); }
     for (void* p : c->allocs) hipFree(p);
-    hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); hipFree(c->forced_dev); hipFree(c->trace_dev);
+    hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); hipFree(c->forced_dev); hipFree(c->trace_dev); hipFree(c->kclk);
     if (c->h_st) hipHostFree(c->h_st); if (c->h_toks) hipHostFree(c->h_toks); if (c->h_row_live) hipHostFree(c->h_row_live);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -702,21 +746,10 @@ static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical) {
     skw_gemm_smallm(a, c->cur);
 }
 
-// decode GEMM fed by a LayerNorm of x: one fused kernel in the f16 precision, LayerNorm kernel + GEMM otherwise
+// decode GEMM fed by a LayerNorm of x, as two launches (the exact precision; f16_mfma where the normalising GEMM does not cover the geometry)
 static void GEMM_S(skw_ctx* c, const SkwGemmArgs& a, int k_logical);
 static void GEMM_LN(skw_ctx* c, SkwGemmArgs a, const float* x, const DevLN& ln, half_t* y16, hipStream_t s, bool normalised = false) {
-    if (normalised) { GEMM_S(c, a, a.K); return; }                     // y16 already holds LayerNorm(x): the GEMM that wrote x did it (ln_tail)
-    // measured (profiles/r02c): the fused kernel costs 17 - 18 us at N = 2304 / 3072 and 9.6 us at N = 768 where LayerNorm (5 us)
-    // + plain GEMM (5 - 8.6 us) cost 10 - 13.6: every column strip re-normalises its rows, which outweighs the saved launch.  Off unless asked for.
-    static const int fuse_n = getenv("SKW_DEC_LN_FUSE") ? atoi(getenv("SKW_DEC_LN_FUSE")) : 0;      // 1: every LayerNorm-fed decode GEMM; n > 1: those with N <= n
-    const bool fuse = fuse_n == 1 || (fuse_n > 1 && a.N <= fuse_n);
-    if (c->precision == SKW_PRECISION_F16_MFMA && fuse) {
-        a.ln_x = x; a.ln_w = ln.w; a.ln_b = ln.b;
-        double fl, by; fl = 2.0 * a.M * a.N * a.K; by = 4.0 * a.M * a.K + 2.0 * a.N * a.K + 2.0 * a.M * a.N;
-        ProfScope p(c, PC_GEMM_SMALL, fl, by);
-        if (skw_gemm16_small_ln(a, c->cur)) return;
-        a.ln_x = nullptr;
-    }
+    if (normalised) { GEMM_S(c, a, a.K); return; }                     // y16 already holds LayerNorm(x): the embedding kernel did it (layer 0)
     { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * a.M * a.K); skw_layernorm(x, a.M, a.K, ln.w, ln.b, y16, nullptr, s); }
     GEMM_S(c, a, a.K);
 }
@@ -911,22 +944,18 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         c->cur = c->stream;
         return;
     }
-    // The first layer's LayerNorm rides on the embedding kernel (same bits: skw_ln_rows).  The others could ride on the GEMM that completes x
-    // (SKW_DEC_LN_TAIL=1, f16_mfma: the last workgroup to arrive per 16-row block normalises it — 8 launches per layer instead of 11), but a
-    // launch boundary (3 us) is cheaper on this part than what the hand-over costs inside a kernel (write-through stores, two counter
-    // round trips and the read-back, each ~2 us across XCDs): 15.6 us for GEMM + tail against 5.1 + 5.0 for the two launches.  Off by default.
-    static const bool ln_tail_env = getenv("SKW_DEC_LN_TAIL") ? atoi(getenv("SKW_DEC_LN_TAIL")) != 0 : false;
-    const bool tail = ln_tail_env && !prefill && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && dt <= 1536;
+    // The first layer's LayerNorm rides on the embedding kernel (same bits: skw_ln_rows).  (The others riding on the GEMM that completes x — the last workgroup to arrive per
+    // 16-row block normalises it — measured 15.6 us for GEMM + tail against 5.1 + 5.0 for the two launches, profiles/r02c: a launch boundary is cheaper on this part than a
+    // hand-over inside a kernel.  Removed in round 5.)
     const bool embed_ln = dt <= 1536;
     // LayerNorm without a launch (f16_mfma): the GEMM that consumes LayerNorm(x) loads the f32 rows, takes their statistics from its own
     // registers and normalises on the way into the MFMA.  35 of the step's 136 launches go.  SKW_DEC_LN_STATS=0 restores the LayerNorm kernels.
-    const bool lnA = c->ln_stats_on && !tail && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat
+    const bool lnA = c->ln_stats_on && embed_ln && c->precision == SKW_PRECISION_F16_MFMA && (dt & 127) == 0 && m->dec[0].qkv.w_nat && m->dec[0].cq.w_nat
         && m->dec[0].fc1.w_nat && m->dec[0].cq.k_pad == dt;
-    auto with_ln = [&](SkwGemmArgs& a, const DevLN& ln) { if (tail) { a.ln_w = ln.w; a.ln_b = ln.b; a.ln_out = dy16; a.ln_cnt = c->ln_cnt + (size_t)r0 * SKW_LN_CNT_STRIDE; } };
     // the prompt pass of a long-form batch is thousands of rows: there the projections are the encoder's big-tile GEMM (f16_mfma; the small-M kernels stream the
     // weights once per 16 rows and reach ~50 TF/s at M = 4096, the big kernel 600).  The QKV product keeps the decode form: its epilogue appends to the K / V caches.
-    const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !getenv("SKW_PROMPT_SMALL_GEMM");
-    static const bool afrag_on = !(getenv("SKW_DEC_AFRAG") && atoi(getenv("SKW_DEC_AFRAG")) == 0);
+    const bool bigM = prefill && c->precision == SKW_PRECISION_F16_MFMA && Bw >= 256 && !skw_sw(SW_PROMPT_SMALL_GEMM);
+    const bool afrag_on = skw_sw(SW_DEC_AFRAG) != 0;
     // the attention kernels leave their rows as the fragment-order A image the out-projections read (f16_mfma, small-M kernels on both sides; the cross attention: the one-pass
     //  kernel / its multi-query prompt form)
     const bool sa_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0, xa_frag = sa_frag && c->kv_frag();
@@ -956,19 +985,14 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
         half_t* ck = c->crossK + ((size_t)l * c->max_batch + r0) * c->kclip(); half_t* cv = c->crossV + ((size_t)l * c->max_batch + r0) * H * 64 * c->Tpad;
         { SkwGemmArgs a = gemm_args(dy16, dt, L.qkv, Bw, dq16, dt, EPI_DEC_QKV); a.scale = KQscale; a.has_scale = 1; a.n_ctx = dt;
           a.C2 = sk; a.C3 = sv; a.ldc2 = kv_ld; a.pos_ptr = kvpos; a.pos_stride = (int)(sizeof(SkwSeqState) / sizeof(int));
-          gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, tail || (l == 0 && embed_ln)); }
+          gemm_ln(a, L.qkv, L.attn_ln, l > 0 ? 3 * (l - 1) + 2 : -1, l == 0 && embed_ln); }
         { ProfScope p_(c, PC_DEC_ATTN, 0, 4.0 * live * (pos + 1) * dt);
         skw_dec_self_attn(dq16, sk, sv, &st[0].cur_pos, Bw, H, dt, ntc, datt16, &st[0].active, s, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, seqp, c->precision == SKW_PRECISION_F16_MFMA, sa_frag);
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = sa_frag; with_ln(a, L.cross_ln); gemm_s(a); }
-        // LayerNorm, query projection and cross attention as one launch where the kernel's prologue covers the geometry (every Whisper size), else as three
-        bool fused_q = false;
-        if (!tail && !lnA && !prefill && !c->kv_frag() && L.cq.k_pad == dt && skw_dec_cross_attn_vt_q_ok(H, dt)) { ProfScope p_(c, PC_DEC_XATTN,
-            4.0 * Bw * (double)nc * dt + 2.0 * Bw * (double)dt * dt, 4.0 * Bw * (double)nc * dt);
-            fused_q = skw_dec_cross_attn_vt_q(dx, L.cross_ln.w, L.cross_ln.b, L.cq.w, L.cq.k_pad, L.cq.b, KQscale, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s); }
-        if (!fused_q) {
-            { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, tail); }
-            static const bool xp_mq = getenv("SKW_PROMPT_XATTN_MQ") ? atoi(getenv("SKW_PROMPT_XATTN_MQ")) != 0 : true;
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.o, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = sa_frag; gemm_s(a); }
+        {
+            { SkwGemmArgs a = gemm_args(dy16, dt, L.cq, Bw, dq16, dt, EPI_F16_PLAIN); a.scale = KQscale; a.has_scale = 1; gemm_ln(a, L.cq, L.cross_ln, 3 * l, false); }
+            const bool xp_mq = skw_sw(SW_PROMPT_XATTN_MQ) != 0;
             if (prefill && xp_mq && c->precision == SKW_PRECISION_F16_MFMA && c->pf_nseq > 0) {
                 // the prompt pass in the tolerance precision: one read of a sequence's cross K / V^T for up to 128 of its prompt tokens (the encoder attention kernel with the
                 // prompt tokens as queries) instead of one per token — 4.6 MB per row per layer otherwise.  The exact precision keeps the single-query kernel: bit-identical to stepping.
@@ -976,20 +1000,19 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
                 skw_xattn_prefill16(dq16, ck, cv, datt16, c->pf_nseq, c->pf_nq_max, c->pf_meta, c->pf_meta + c->max_batch, c->pf_meta + 2 * c->max_batch, H, dt, nc, c->Tpad, s, c->kv_frag(), xa_frag);
             } else
             { ProfScope p_(c, PC_DEC_XATTN, 4.0 * live * (double)nc * dt, 4.0 * live * (double)nc * dt, true);
-            skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b(), xa_frag);
+            skw_dec_cross_attn_vt(dq16, ck, cv, Bw, H, dt, nc, c->Tpad, datt16, &st[0].active, s, 0, c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA, seqp, p_.ev_a(), p_.ev_b(), xa_frag,
+                                  prefill ? nullptr : kclk_node(c, c->cur_group, l));
             }
         }
-        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = xa_frag && !fused_q; with_ln(a, L.mlp_ln); gemm_s(a); }
+        { SkwGemmArgs a = gemm_args(datt16, dt, L.co, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = xa_frag; gemm_s(a); }
         // f16_mfma, small-M kernels on both sides: fc1 leaves its output as the fragment-order A image fc2 reads (fc2 7.4 -> 6.5 us per launch); the prompt pass's big-tile GEMMs keep rows
         const bool h_frag = afrag_on && c->precision == SKW_PRECISION_F16_MFMA && !bigM && (dt & 127) == 0;
-        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; a.c_frag = h_frag; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, tail); }
-        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = h_frag;
-          if (l + 1 < hp.n_text_layer) with_ln(a, m->dec[l + 1].attn_ln); else if (want_logits) with_ln(a, m->d_ln);
-          gemm_s(a); }
+        { SkwGemmArgs a = gemm_args(dy16, dt, L.fc1, Bw, dh16, 4L * dt, EPI_GELU_F16_KPERM); a.gelu_tab = m->gelu_tab; a.c_frag = h_frag; gemm_ln(a, L.fc1, L.mlp_ln, 3 * l + 1, false); }
+        { SkwGemmArgs a = gemm_args(dh16, 4L * dt, L.fc2, Bw, dx, dt, EPI_F32); a.res = dx; a.ldres = dt; a.a_frag = h_frag; gemm_s(a); }
     }
     if (want_logits) {
         // (the vocabulary kernel's 256 workgroups would each normalise all 64 rows: measured +6.4 us against this 5.0 us launch)
-        if (!tail) { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
+        { ProfScope p_(c, PC_LAYERNORM, 0, 6.0 * Bw * dt); skw_layernorm(dx, Bw, dt, m->d_ln.w, m->d_ln.b, dy16, nullptr, s); }
         SkwGemmArgs a = gemm_args(dy16, dt, m->te, Bw, c->logits + (size_t)r0 * hp.n_vocab, hp.n_vocab, EPI_F32); GEMM_S(c, a, a.K);
     }
     c->cur = c->stream;
@@ -1000,14 +1023,17 @@ static void run_decoder_step(skw_ctx* c, int r0, int Bw, int pos, bool want_logi
 static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogitParams& lp) {
     for (size_t i = 0; i < c->step_graphs.size(); ++i) {
         auto& sg = c->step_graphs[i];
-        if (sg.g == g && sg.r0 == r0 && sg.n == n && sg.precision == c->precision && sg.ln_stats == c->ln_stats_on && memcmp(&sg.lp, &lp, sizeof lp) == 0) {
+        if (sg.g == g && sg.r0 == r0 && sg.n == n && sg.precision == c->precision && sg.ln_stats == c->ln_stats_on && sg.kclk == c->kclk_on && sg.sw_epoch == skw_sw_epoch() &&
+            memcmp(&sg.lp, &lp, sizeof lp) == 0) {
             if (i + 1 != c->step_graphs.size()) { auto hit = sg; c->step_graphs.erase(c->step_graphs.begin() + i); c->step_graphs.push_back(hit); }   // most recently used last
             return c->step_graphs.back().exec;
         }
     }
     const int NV = c->m->hp.n_vocab; hipStream_t s = c->gstream[g]; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    c->cur_group = g;
     run_decoder_step(c, r0, n, 0, true, s);
+    c->cur_group = 0;
     skw_dec_sample(c->logits + (size_t)r0 * NV, c->static_mask, lp, c->st + r0, c->toks + (size_t)r0 * c->max_tok, c->max_tok, n, c->d_row_live + r0,
         c->probs + (size_t)r0 * skw_probs_row_floats(NV), c->rng, c->clip_idx + r0, c->prompt_buf + (size_t)r0 * SKW_PROMPT_CAP, s);
     if (hipStreamEndCapture(s, &graph) != hipSuccess || !graph) return nullptr;
@@ -1016,7 +1042,8 @@ static hipGraphExec_t step_graph(skw_ctx* c, int g, int r0, int n, const SkwLogi
     if (exec) {
         // bounded: a long-lived server with ragged batches would otherwise keep one executable graph per (group, rows, params) forever
         if (c->step_graphs.size() >= 24) { hipGraphExecDestroy(c->step_graphs.front().exec); c->step_graphs.erase(c->step_graphs.begin()); }
-        skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.precision = c->precision; sg.ln_stats = c->ln_stats_on; sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg);
+        skw_ctx::StepGraph sg; sg.g = g; sg.r0 = r0; sg.n = n; sg.precision = c->precision; sg.ln_stats = c->ln_stats_on; sg.kclk = c->kclk_on;
+         sg.sw_epoch = skw_sw_epoch(); sg.lp = lp; sg.exec = exec; c->step_graphs.push_back(sg);
     }
     return exec;
 }
@@ -1128,12 +1155,13 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
     skw_model* m = c->m; const skw_hparams& hp = m->hp; const int NV = hp.n_vocab;
     for (int i = 0; i < n_clips; ++i) { memset(&results[i], 0, sizeof(skw_result)); results[i].min_margin = INFINITY; }
     std::vector<int> n_len, n_len_org;
+    if (c->kclk_on && kclk_reset(c)) return -1;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (load_clips(c, pcm, n_samples, n_clips, pcm_on_device, n_len, n_len_org)) return -1;
     build_static_mask(c, p);
     run_mel(c, n_clips);
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0; long tot_row_steps = 0;
+    float enc_ms = 0.f, dec_ms = 0.f; int tot_windows = 0, tot_steps = 0, tot_tokens = 0; long tot_row_steps = 0; int used_groups = 1, used_group_rows = 0;
 
     std::vector<int> seek(n_clips, 0); std::vector<SeqAcc> acc(n_clips);
     // temperature ladder (whisper_full_with_state): per clip, the index of the temperature its current window is decoded at
@@ -1270,6 +1298,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
                 if (cut > prev) { g_r0[G] = prev; g_n[G] = cut - prev; g_live[G] = true; ++G; prev = cut; }
             }
         }
+        used_groups = G; used_group_rows = g_n[0];
         for (int j = 0; j < Bw; ++j) c->h_row_live[j] = 1;      // (every kernel of the previous window has drained: c->stream was synchronised at its end)
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(c->gstream[g], c->ev[5], 0));
@@ -1292,8 +1321,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         // runs after the last row of its group has finished changes nothing (its attention and sampling kernels return at once for
         // finished rows; what the GEMMs write for them is scratch), it only costs its launches.
         const int step_cap = SKW_PROMPT_CAP + lp.n_max + 2;
-        static const int ahead_env = getenv("SKW_DECODE_AHEAD") ? atoi(getenv("SKW_DECODE_AHEAD")) : 0;
-        const int ahead = profiling ? 1 : std::max(1, ahead_env ? ahead_env : 8);
+        const int ahead = profiling ? 1 : 8;
         for (int i = 0; i < step_cap; i += ahead) {
             const int nstep = std::min(ahead, step_cap - i);
             for (int k = 0; k < nstep; ++k)
@@ -1302,7 +1330,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
                     else {
                         // (ahead == 1: the previous step has drained)
                         if (profiling) { int lv = 0; for (int j = g_r0[g]; j < g_r0[g] + g_n[g]; ++j) lv += ((volatile int*)c->h_row_live)[j] != 0; c->live_rows_hint = lv; }
-                        run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); c->live_rows_hint = -1; HIPCHK(sample(g));
+                        c->cur_group = g;
+                        run_decoder_step(c, g_r0[g], g_n[g], i + k, true, c->gstream[g]); c->live_rows_hint = -1; c->cur_group = 0; HIPCHK(sample(g));
                     }
                 }
             bool any = false;
@@ -1393,7 +1422,7 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
     { float a = 0, t = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&t, c->ev[0], c->ev[5]);
       c->timing.mel_ms = a; c->timing.encode_ms = enc_ms; c->timing.decode_ms = dec_ms;
       c->timing.total_ms = t; c->timing.n_windows = tot_windows; c->timing.n_decode_steps = tot_steps;
-      c->timing.n_tokens = tot_tokens; c->timing.n_row_steps = (int32_t)tot_row_steps; }
+      c->timing.n_tokens = tot_tokens; c->timing.n_row_steps = (int32_t)tot_row_steps; c->timing.decode_groups = used_groups; c->timing.decode_group_rows = used_group_rows; }
     return 0;
 }
 extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
@@ -1581,8 +1610,8 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
     half_t *A = nullptr, *W = nullptr; void* C = nullptr; float *bias = nullptr, *res = nullptr;
     const size_t cbytes = (size_t)M * N * 4 + (size_t)64 * c->Tpad * N;
-    // SKW_PROBE_WCYCLE=n: the launches walk n copies of W (n x N x K x 2 bytes > the 256 MB Infinity Cache: every launch finds its weights in HBM, as a decode step does)
-    const int wcycle = (M <= 64 && getenv("SKW_PROBE_WCYCLE")) ? std::max(1, atoi(getenv("SKW_PROBE_WCYCLE"))) : 1;
+    // probe bits 12-19 = n (decode shapes): the launches walk n copies of W (n x N x K x 2 bytes > the 256 MB Infinity Cache: every launch finds its weights in HBM, as a decode step does)
+    const int wcycle = M <= 64 ? std::max(1, (probe >> 12) & 255) : 1; probe &= 0xfff;
     HIPCHK(hipMalloc((void**)&A, (size_t)M * K * 2)); HIPCHK(hipMalloc((void**)&W, (size_t)N * K * 2 * wcycle));
     HIPCHK(hipMalloc(&C, cbytes)); HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)); HIPCHK(hipMalloc((void**)&res, (size_t)M * N * 4));
     { std::vector<uint16_t> h((size_t)std::max(M, N) * K); uint32_t x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16(((x >> 8) & 0xffff) / 65536.0f - 0.5f); }
@@ -1618,47 +1647,152 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     return 0;
 }
 
-// tools/xattn_probe.py: the decode step's cross attention alone, B rows, launched back to back over `layers` different K / V^T images (so no launch
-// re-reads what a previous one left in a cache), parts switched off by `probe` (see k_dec_cross_attn).  Average microseconds per launch.
-extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int iters, float* us_per_launch) {
+// tests (tests/test_gpu_gemm16w.py; the regression cover of the round-4 k_gemm16w fault): ONE product on seeded operands through k_gemm16w — the encoder's GEMM, weights from a
+// fragment-order image, two memory queues counted by hand — and through k_gemm16 (both operands through LDS), every output byte compared.  epi: EPI_* of skw_kernels.h;
+// frag: EPI_F16_PLAIN / EPI_VT_F16 write the fragment-order cross K / V^T image; n_ctx / Tpad: rows per clip of the per-clip layouts (M must be a multiple of n_ctx for them);
+// ngroups: GEMM16W_NGROUPS for the k_gemm16w launch; with_res: EPI_F32 adds a residual.  Returns the number of differing bytes (0 = bit-identical), -2 when skw_gemm16 would not
+// take k_gemm16w for this geometry (nothing compared), -1 on error.
+extern "C" long skw_debug_gemm16_compare(skw_ctx* c, int M, int N, int K, int epi, int frag, int n_ctx, int Tpad, int ngroups, int with_res) {
     char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (M < 1 || N < 16 || (N & 15) || (K & 63) || n_ctx < 1 || (Tpad & 31) || Tpad < n_ctx) { snprintf(errbuf, 512, "skw_debug_gemm16_compare: bad geometry"); return -1; }
+    const bool per_clip = epi == EPI_HEADS_F16 || epi == EPI_VT_F16 || epi == EPI_GELU_F16_KPERM_ROWPAD || epi == EPI_CONV2 || frag;
+    if (per_clip && M % n_ctx) { snprintf(errbuf, 512, "skw_debug_gemm16_compare: M must be whole clips for this epilogue"); return -1; }
+    if ((epi == EPI_HEADS_F16 || epi == EPI_VT_F16 || frag) && (N & 63)) { snprintf(errbuf, 512, "skw_debug_gemm16_compare: N must be whole heads for this epilogue"); return -1; }
+    const size_t cbytes = ((size_t)(M / n_ctx + 2) * (Tpad + 2) * N + (size_t)M * N) * 4 + 4096;
+    half_t *A = nullptr, *W = nullptr, *Wf = nullptr; char *C1 = nullptr, *C2 = nullptr; float *bias = nullptr, *res = nullptr, *pe = nullptr;
+    auto cleanup = [&]() { hipFree(A); hipFree(W); hipFree(Wf); hipFree(C1); hipFree(C2); hipFree(bias); hipFree(res); hipFree(pe); };
+    auto chk = [&](hipError_t e) { if (e != hipSuccess) { snprintf(errbuf, 512, "skw_debug_gemm16_compare: %s", hipGetErrorString(e)); cleanup(); return false; } return true; };
+    if (!chk(hipMalloc((void**)&A, (size_t)M * K * 2)) || !chk(hipMalloc((void**)&W, (size_t)N * K * 2)) || !chk(hipMalloc((void**)&Wf, (size_t)N * K * 2)) || !chk(hipMalloc((void**)&C1, cbytes)) ||
+        !chk(hipMalloc((void**)&C2, cbytes)) || !chk(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)) || !chk(hipMalloc((void**)&res, (size_t)M * N * 4)) ||
+        !chk(hipMalloc((void**)&pe, (size_t)n_ctx * N * 4))) return -1;
+    {   // seeded operands: values of order 1 / sqrt(K) so that sums stay well inside f16's range after the epilogue
+        uint32_t x = 0x9e3779b9u ^ (uint32_t)(M * 31 + N * 17 + K * 7 + epi);
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        const float sc = 2.0f / sqrtf((float)K);
+        std::vector<uint16_t> h((size_t)std::max(M, N) * K);
+        for (auto& v : h) v = skw_f32_to_f16(rnd() * sc);
+        if (!chk(hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice))) return -1;
+        for (auto& v : h) v = skw_f32_to_f16(rnd() * 2.0f);
+        if (!chk(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice))) return -1;
+        std::vector<float> f((size_t)std::max((size_t)M * N, (size_t)n_ctx * N));
+        for (auto& v : f) v = rnd();
+        if (!chk(hipMemcpy(res, f.data(), (size_t)M * N * 4, hipMemcpyHostToDevice)) || !chk(hipMemcpy(pe, f.data(), (size_t)n_ctx * N * 4, hipMemcpyHostToDevice)) ||
+            !chk(hipMemcpy(bias, f.data(), (size_t)std::max(M, N) * 4, hipMemcpyHostToDevice))) return -1;
+    }
+    const bool perm = epi == EPI_F16_KPERM || epi == EPI_GELU_F16_KPERM || epi == EPI_GELU_F16_KPERM_ROWPAD || epi == EPI_HEADS_F16;
+    skw_make_wfrag(W, K, N, K, perm ? 1 : 0, Wf, c->stream);
+    SkwGemmArgs a{}; a.A = A; a.lda = K; a.W = W; a.ldw = K; a.Wf = Wf; a.M = M; a.N = N; a.K = K; a.ldc = N; a.bias = bias; a.epi = epi; a.scale = 0.125f;
+    a.has_scale = (epi == EPI_F16_KPERM || epi == EPI_HEADS_F16 || epi == EPI_F16_PLAIN) ? 1 : 0;
+    a.gelu_tab = c->m->gelu_tab; a.pe = pe; a.n_ctx = per_clip ? n_ctx : 0; a.H = N / 64; a.Tpad = Tpad; a.frag = frag;
+    if (epi == EPI_F32 && with_res) { a.res = res; a.ldres = N; }
+    if (!skw_gemm16_takes_w(a)) { cleanup(); return -2; }
+    (void)skw_sw(0);
+    const int ng_was = g_sw_val[SW_GEMM16W_NGROUPS], w_was = g_sw_val[SW_GEMM16W];
+    if (!chk(hipMemsetAsync(C1, 0xAB, cbytes, c->stream)) || !chk(hipMemsetAsync(C2, 0xAB, cbytes, c->stream))) return -1;
+    g_sw_val[SW_GEMM16W] = 1; g_sw_val[SW_GEMM16W_NGROUPS] = ngroups; a.C = C1; skw_gemm16(a, c->stream);
+    g_sw_val[SW_GEMM16W] = 0; a.C = C2; skw_gemm16(a, c->stream);
+    g_sw_val[SW_GEMM16W] = w_was; g_sw_val[SW_GEMM16W_NGROUPS] = ng_was;
+    if (!chk(hipStreamSynchronize(c->stream)) || !chk(hipGetLastError())) return -1;
+    std::vector<char> h1(cbytes), h2(cbytes);
+    if (!chk(hipMemcpy(h1.data(), C1, cbytes, hipMemcpyDeviceToHost)) || !chk(hipMemcpy(h2.data(), C2, cbytes, hipMemcpyDeviceToHost))) return -1;
+    long diff = 0, written = 0;
+    for (size_t i = 0; i < cbytes; ++i) { diff += h1[i] != h2[i]; written += (unsigned char)h2[i] != 0xAB; }
+    cleanup();
+    if (written < (long)M * N) { snprintf(errbuf, 512, "skw_debug_gemm16_compare: only %ld bytes written for %d x %d outputs", written, M, N); return -1; }
+    return diff;
+}
+
+// the launch clock's records (SkwKClk, skw_kernels.h): one clock per (row group, decoder layer) graph node
+static const int KCLK_CAP = 1024;                                       // launches recorded per node and call (a 30 s window is <= 466 steps)
+static size_t kclk_node_bytes() { return sizeof(SkwKClk) + sizeof(SkwKClkRec) * (KCLK_CAP - 1); }
+static SkwKClk* kclk_node(const skw_ctx* c, int g, int l) {
+    return c->kclk_on ? (SkwKClk*)((char*)c->kclk + kclk_node_bytes() * ((size_t)g * c->m->hp.n_text_layer + l)) : nullptr;
+}
+static int kclk_reset(skw_ctx* c) {
+    char* errbuf = c->errbuf;
+    const size_t nb = kclk_node_bytes(), n_nodes = (size_t)skw_ctx::MAX_GROUPS * c->m->hp.n_text_layer;
+    HIPCHK(hipMemsetAsync(c->kclk, 0, nb * n_nodes, c->stream));
+    std::vector<SkwKClk> hdr(1); memset(&hdr[0], 0, sizeof(SkwKClk)); hdr[0].cap = KCLK_CAP;
+    for (size_t i = 0; i < n_nodes; ++i) HIPCHK(hipMemcpyAsync((char*)c->kclk + nb * i, &hdr[0], 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+// Arms / disarms the in-kernel launch clock of the decode step's cross attention (f16_mfma, fragment-order images).  Armed, the step graphs are captured with the clock's
+// pointers (their key carries the flag) and every skw_full_batch starts from zeroed records; skw_ctx_kernel_clock_get sums what the last call recorded.
+extern "C" int skw_ctx_kernel_clock(skw_ctx* c, int on) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (on && !c->kclk) {
+        HIPCHK(hipMalloc((void**)&c->kclk, kclk_node_bytes() * skw_ctx::MAX_GROUPS * c->m->hp.n_text_layer));
+        int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->m->device));
+        if (khz <= 0) { snprintf(errbuf, 512, "device reports no wall clock rate"); return -1; }
+        c->kclk_khz = khz;
+    }
+    c->kclk_on = on ? 1 : 0;
+    return on ? kclk_reset(c) : 0;
+}
+// launches recorded by the last skw_full_batch: count, summed first-wave-in -> last-wave-out microseconds, summed live rows (the launch's algorithmic bytes are
+// 4 B x live rows x n_audio_ctx x n_text_state), shortest and longest launch
+extern "C" int skw_ctx_kernel_clock_get(skw_ctx* c, long* launches, double* sum_us, double* sum_live_rows, double* min_us, double* max_us, int* clock_khz) {
+    char* errbuf = c->errbuf;
+    if (!c->kclk) { snprintf(errbuf, 512, "the kernel clock was never armed"); return -1; }
+    HIPCHK(hipSetDevice(c->m->device));
+    const size_t nb = kclk_node_bytes(), n_nodes = (size_t)skw_ctx::MAX_GROUPS * c->m->hp.n_text_layer;
+    std::vector<char> h(nb * n_nodes);
+    HIPCHK(hipMemcpy(h.data(), c->kclk, h.size(), hipMemcpyDeviceToHost));
+    long n = 0; double su = 0, sl = 0, mn = 1e30, mx = 0;
+    for (size_t i = 0; i < n_nodes; ++i) {
+        const SkwKClk* k = (const SkwKClk*)(h.data() + nb * i);
+        for (int j = 0; j < KCLK_CAP; ++j) {
+            const SkwKClkRec& r = k->rec[j];
+            if (!r.t1 || !r.t0_inv) continue;
+            const double us = (double)(r.t1 - ~r.t0_inv) * 1000.0 / c->kclk_khz;
+            ++n; su += us; sl += r.live_rows; mn = std::min(mn, us); mx = std::max(mx, us);
+        }
+    }
+    *launches = n; *sum_us = su; *sum_live_rows = sl; *min_us = n ? mn : 0; *max_us = mx; *clock_khz = c->kclk_khz;
+    return 0;
+}
+
+// The decode step's cross attention alone, B rows, launched back to back over `layers` different K / V^T images (so no launch re-reads what a previous one left in a cache).
+// Every launch is stamped twice: by HIP events at the kernel's own begin and end (hipExtLaunchKernelGGL: what rocprofv3 reports as the duration) and — the one-pass kernel — by its
+// in-kernel clock (first wave in to last wave out).  us_per_launch: the event average; us_per_launch_clock (may be null): the clock's average, 0 where the kernel has no clock.
+extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int iters, float* us_per_launch, float* us_per_launch_clock) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (probe) { snprintf(errbuf, 512, "skw_debug_xattn: the parts-off probe launches were removed with round 5's pruning (results: profiles/r02f, r03b)"); return -1; }
     const skw_hparams& hp = c->m->hp; const int d = hp.n_text_state, H = hp.n_text_head, nc = hp.n_audio_ctx, Tpad = c->Tpad;
     const size_t kn = (size_t)B * Tpad * d, vn = (size_t)B * H * 64 * Tpad;
-    half_t *K = nullptr, *V = nullptr, *q = nullptr, *out = nullptr;
+    half_t *K = nullptr, *V = nullptr, *q = nullptr, *out = nullptr; SkwKClk* clk = nullptr;
+    iters = std::max(1, std::min(iters, KCLK_CAP));
     HIPCHK(hipMalloc((void**)&K, kn * 2 * layers)); HIPCHK(hipMalloc((void**)&V, vn * 2 * layers));
     HIPCHK(hipMalloc((void**)&q, (size_t)B * d * 2)); HIPCHK(hipMalloc((void**)&out, (size_t)B * d * 4));
+    HIPCHK(hipMalloc((void**)&clk, kclk_node_bytes()));
     { std::vector<uint16_t> h(std::max(kn, vn)); uint32_t x = 777; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16((((x >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.25f); }
       for (int l = 0; l < layers; ++l) { HIPCHK(hipMemcpy(K + kn * l, h.data(), kn * 2, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(V + vn * l, h.data(), vn * 2, hipMemcpyHostToDevice)); }
       HIPCHK(hipMemcpy(q, h.data(), (size_t)B * d * 2, hipMemcpyHostToDevice)); }
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    const int pv16 = c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA;       // (timing only: the images are random bytes in either layout; Tpad * d elements per slot are allocated below)
-    for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
-    // every launch stamped at its own begin and end (hipExtLaunchKernelGGL): the kernel's duration as rocprofv3 reports it, without the dispatch gap between launches.
-    // SKW_XATTN_PROBE_WALL=1: one event pair around the whole run instead (launch-to-launch time, what round 2's figures were)
+    const int pv16 = c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA;       // (timing only: the images are random bytes in either layout; Tpad * d elements per slot are allocated above)
+    for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, 0, pv16);
+    HIPCHK(hipMemsetAsync(clk, 0, kclk_node_bytes(), c->stream));
+    { SkwKClk hdr; memset(&hdr, 0, sizeof hdr); hdr.cap = KCLK_CAP; HIPCHK(hipMemcpyAsync(clk, &hdr, 16, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     float ms = 0;
-    if (getenv("SKW_XATTN_PROBE_WALL")) {
-        HIPCHK(hipEventRecord(e0, c->stream));
-        for (int i = 0; i < iters; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16);
-        HIPCHK(hipEventRecord(e1, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
-        hipEventElapsedTime(&ms, e0, e1);
-    } else {
-        std::vector<hipEvent_t> ev(2 * (size_t)iters);
-        for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-        // SKW_XATTN_PROBE_TOUCH_K / _V = megabytes of the launch's K / V^T image read (and discarded) by k_touch in front of it, untimed: what the launch gains from bytes waiting
-        //  in the Infinity Cache
-        const size_t tk = getenv("SKW_XATTN_PROBE_TOUCH_K") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_K")) * 1000000 : 0,
-            tv = getenv("SKW_XATTN_PROBE_TOUCH_V") ? (size_t)atoi(getenv("SKW_XATTN_PROBE_TOUCH_V")) * 1000000 : 0;
-        for (int i = 0; i < iters; ++i) {
-            if (tk) skw_touch(K + kn * (i % layers), std::min(tk, kn * 2) & ~(size_t)15, 256, nullptr, c->stream);
-            if (tv) skw_touch(V + vn * (i % layers), std::min(tv, vn * 2) & ~(size_t)15, 256, nullptr, c->stream);
-            skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, probe << 8, pv16, nullptr, ev[2 * i], ev[2 * i + 1]);
-        }
-        HIPCHK(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < iters; ++i) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) ms += t; }
-        for (auto& e : ev) hipEventDestroy(e);
-    }
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    for (int i = 0; i < iters; ++i)
+        skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, 0, pv16, nullptr, ev[2 * i], ev[2 * i + 1], 0, pv16 == 2 ? clk : nullptr);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < iters; ++i) { float t = 0; if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) ms += t; }
+    for (auto& e : ev) hipEventDestroy(e);
     *us_per_launch = 1000.0f * ms / iters;
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(K); hipFree(V); hipFree(q); hipFree(out);
+    if (us_per_launch_clock) {
+        *us_per_launch_clock = 0.0f;
+        if (pv16 == 2) {
+            int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->m->device));
+            std::vector<char> h(kclk_node_bytes()); HIPCHK(hipMemcpy(h.data(), clk, h.size(), hipMemcpyDeviceToHost));
+            const SkwKClk* k = (const SkwKClk*)h.data(); double su = 0; int n = 0;
+            for (int j = 0; j < iters; ++j) if (k->rec[j].t1 && k->rec[j].t0_inv) { su += (double)(k->rec[j].t1 - ~k->rec[j].t0_inv) * 1000.0 / std::max(1, khz); ++n; }
+            if (n) *us_per_launch_clock = (float)(su / n);
+        }
+    }
+    hipFree(K); hipFree(V); hipFree(q); hipFree(out); hipFree(clk);
     return 0;
 }
 
@@ -1716,7 +1850,7 @@ extern "C" int skw_resample_linear(skw_dsp* d, skw_resampler_state* st, const fl
     // two) keep the device's own proposals.  Same IEEE additions either way: the result is rubato's, bit for bit.
     const double t_ratio = 1.0 / st->ratio;
     const bool t_exact = chunk <= 4096 && ldexp(t_ratio, 36) == floor(ldexp(t_ratio, 36));
-    const bool host_walk = !t_exact && n_chunks >= 8 && !getenv("SKW_RESAMPLE_NO_HOST_WALK");
+    const bool host_walk = !t_exact && n_chunks >= 8 && !skw_sw(SW_RESAMPLE_NO_HOST_WALK);
     if (host_walk) {
         std::vector<double> hs((size_t)n_chunks + 1); std::vector<int> hc((size_t)n_chunks + 1, 0), ho((size_t)n_chunks + 1);
         const double end_idx = (double)(chunk - 9) - ceil(t_ratio); double s = st->last_index; int off = 0;

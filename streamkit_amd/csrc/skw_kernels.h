@@ -32,6 +32,14 @@ __host__ __device__ __forceinline__ long skw_vtfrag_off(int slot, int H, int Tpa
     return (((long)slot * H + h) * (Tpad >> 5) + (pos >> 5)) * 2048 + (ch >> 4) * 512 + ((ch & 15) + 16 * ((pos >> 3) & 3)) * 8;
 }
 
+// ---- the switchboard: every alternative path a run can select is one row of ONE table (skw_engine.hip, g_sw_defs).  A switch is read from the environment (SKW_<NAME>) the first
+// time anything asks — the only getenv of this library — and tests flip it in-process (skw_debug_switch_set); tests/test_gpu_switches.py runs a parity case per row.
+// What the measured-and-lost alternatives of rounds 1-4 were, and their numbers, is in DESIGN.md section 3 and profiles/; their code is gone.
+enum SkwSw : int { SW_QUANT_TWIN = 0, SW_DEC_WFRAG, SW_GEMM16W, SW_GEMM16W_NGROUPS, SW_XATTN_FRAG, SW_DECODE_GRAPHS, SW_DECODE_GROUPS, SW_DEC_LN_STATS, SW_PROMPT_PASS,
+                   SW_PROMPT_SMALL_GEMM, SW_PROMPT_XATTN_MQ, SW_DEC_AFRAG, SW_DEC_ATTN_FASTV, SW_Q8_LDS, SW_RESAMPLE_SCAN, SW_RESAMPLE_NO_HOST_WALK, SW_COUNT };
+int skw_sw(int id);
+unsigned skw_sw_epoch();      // bumped by every skw_debug_switch_set: captured step graphs carry the epoch they were built under
+
 enum SkwEpi : int {
     EPI_F32 = 0,        // C f32 [m][n] = (acc + bias[n]) (+ res[m][n])
     EPI_F16_KPERM = 1,  // C f16 [m][kperm(n)] = f16((acc + bias[n]) * scale)
@@ -45,7 +53,6 @@ enum SkwEpi : int {
     EPI_GELU_F16_KPERM_ROWPAD = 7, // conv1: like 2 but row index remapped m -> (m / T) * (T + 2) + (m % T) + 1 (one zero row of padding per clip side)
 };
 
-#define SKW_LN_CNT_STRIDE 1024
 struct SkwGemmArgs {
     const half_t* A; long lda;      // [M][K] f16, K axis kperm'ed, lda in elements (multiple of 8)
     int a_rows_per_batch; long a_batch_stride; // when a_rows_per_batch > 0: row m lives at A + (m / rpb) * a_batch_stride + (m % rpb) * lda
@@ -70,20 +77,17 @@ struct SkwGemmArgs {
     int frag;                       // skw_gemm16, EPI_F16_PLAIN / EPI_VT_F16 with n_ctx, H, Tpad set: C is the fragment-order cross K / V^T image (skw_kfrag_off / skw_vtfrag_off) instead of rows
     int wgroups;                    // k_gemm16w only, set by its launcher: the XCDs split the features into this many n-tile groups (1: the contiguous walk)
     int probe;                      // measurement only (skw_debug_gemm16): bit 0 skip the K-loop DMA, bit 1 skip the MFMAs, bit 2 skip the epilogue
-    const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_ln: A = LayerNorm(ln_x [M][K] f32) computed inside the GEMM (A / lda unused)
-    half_t* ln_out; unsigned* ln_cnt;                          // skw_gemm16_small, EPI_F32 with N = ldc: the workgroup that completes a 16-row block of C also writes
-                                                               // ln_out [M][N] = f16 kperm LayerNorm(C rows; ln_w, ln_b); ln_cnt: SKW_LN_CNT_STRIDE zeroed words per row block (needs N <= 16 * 8 * 15)
+    const float* ln_x; const float* ln_w; const float* ln_b;   // skw_gemm16_small_lnA: A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b) computed inside the GEMM (A / lda unused)
 };
 
 // big-M GEMM (LDS-tiled 128x128 block, 4 waves)
 void skw_gemm(const SkwGemmArgs& a, hipStream_t s);
 // f16-MFMA form of skw_gemm (skw_kernels_f16.hip): same operands and epilogues, K % 64 == 0
 void skw_gemm16(const SkwGemmArgs& a, hipStream_t s);
+bool skw_gemm16_takes_w(const SkwGemmArgs& a);      // true: skw_gemm16 launches k_gemm16w (weights from the fragment-order image a.Wf) for these arguments, false: k_gemm16
 bool skw_gemm16_small(const SkwGemmArgs& a, hipStream_t s);
 // A = LayerNorm(ln_x [M][K] f32; ln_w, ln_b), statistics and normalisation inside the kernel from the rows it holds in registers; W in NATURAL k order
 bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s);
-// the same with the LayerNorm that produces A folded in (K = d <= 1536)   // decode GEMMs (M small); false = geometry not handled, use skw_gemm_smallm
-bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s);
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s);
 // cross attention of the prompt pass (f16_mfma): the encoder attention kernel with a sequence's prompt tokens as the queries — one read of the sequence's cross K / V^T per 128 of them.
 // q: [rows][d] f16 plain (scaled); sequence i: rows row0[i] .. + nq[i], cross K / V^T of window slot slot[i]; out: [rows][kperm(d)] f16
@@ -135,20 +139,21 @@ void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, cons
                        // ofrag: output as a fragment-order A image (skw_afrag_off); fastv: the tolerance precision's P.V (16-byte V pieces, per-lane key shares)   // seq
                        //  (stride of `active`): row b uses the K / V cache of sequence seq[b] (the prompt pass: several rows per sequence); null: sequence b
                        const int* seq = nullptr, int fastv = 0, int ofrag = 0);
-// cross attention: ck/cv f16 plain [b][n_ctx][d]
-void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s);
 // bandwidth form: cross V stored per head transposed, cvt: [(b*H+h)*64 + c][Tpad kperm]
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
+// pv16: 0 the exact precision (two-phase kernel, f32 P.V chains), 1 f16_mfma over the row layouts (two-phase kernel, f16 P.V), 2 f16_mfma over the fragment-order images (one streaming pass)
+// In-kernel launch clock of the one-pass kernel (bench.py's roofline line must time the launches of the TIMED configuration — step graphs, two row groups on two streams — where no
+// HIP event can sit between captured kernels).  One SkwKClk per graph node (row group, layer); launch n of the node is the n-th group of gridDim workgroups to arrive.  Thread 0 of
+// every live workgroup folds its entry time into t0 (stored inverted, so zeroed memory is the identity of both maxima) and its exit time into t1, on the device's constant-rate
+// counter (wall_clock64, hipDeviceAttributeWallClockRate); live_rows counts the rows that streamed.  t1 - t0 is first-wave-in to last-wave-out: what rocprofv3 calls the duration
+// minus the dispatch and completion-signal edges, which skw_debug_xattn measures (events and clock on the same isolated launches) so that the line can state both.
+struct SkwKClkRec { unsigned long long t0_inv, t1; unsigned live_rows, pad; };
+struct SkwKClk { unsigned arrive, cap, pad0, pad1; SkwKClkRec rec[1]; };      // rec[cap] follows
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
     int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
                            // ofrag (one-pass kernel only): the output rows as the fragment-order A image of the projection that follows; events: stamped at the kernel's
                            //  own begin / end (the engine's per-kernel profile)
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int ofrag = 0);
-// the same with the LayerNorm of x and the query projection (f16 weights, exact segmented chain) done by the kernel itself; false = not launched
-void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s);     // read and discard: warms the Infinity Cache
-bool skw_dec_cross_attn_vt_q_ok(int H, int d);
-bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
-                             const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s);
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int ofrag = 0, SkwKClk* clk = nullptr);
 
 // per-sequence decoding state kept on the device (whisper_decoder + the bits of whisper_full_with_state's loop that depend on it)
 struct SkwSeqState {

@@ -105,99 +105,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm(SkwGemmArgs a) {
             }
 }
 
-// ------------------------------------------------------------------ small-M GEMM (decode, M <= 64)
-// Weight-streaming form: one wave per (16-column strip, 16-row tile) with ONE accumulator, so the contraction chain
-// advances at the MFMA's dependent latency (40 cycles per 4 k) instead of being shared between row tiles, and a ring
-// of SM_DEPTH k-blocks of fragments (16 B per lane per operand per block) is kept in flight straight from global
-// memory to hide HBM latency.  The 4 waves of a block are the 4 row tiles of one strip (W lines shared through L1/L2).
-template <int EPI, int SM_DEPTH>
-__global__ __launch_bounds__(256) void k_gemm_smallm(SkwGemmArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 16, mt = blockIdx.y * 4 + wave;
-    if (mt * 16 >= a.M) return;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int gn = n0 + r16, gm = mt * 16 + r16;
-    // buffer descriptors with hardware range checking: rows past N / M and k-blocks past K read as zeros,
-    // and fma(0, 0, acc) == acc, so padding never perturbs a chain.  (The intrinsic also keeps the loads 128-bit wide.)
-    const unsigned wbytes = (unsigned)((long)a.N * a.ldw * 2), abytes = (unsigned)(((long)(a.M - 1) * a.lda + a.K) * 2);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, wbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, abytes, 0x00020000);
-    const unsigned oob = 0x7fffff00u;
-    const unsigned wo = (gn < a.N) ? (unsigned)(((long)gn * a.ldw + kq * 8) * 2) : oob;
-    const unsigned ao = (gm < a.M) ? (unsigned)(((long)gm * a.lda + kq * 8) * 2) : oob;
-    const int nk = a.K >> 5;
-    H8v fw[SM_DEPTH], fa[SM_DEPTH];
-#pragma unroll
-    for (int j = 0; j < SM_DEPTH; ++j) {
-        fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || j >= nk) ? oob : wo + j * 64, 0, 0);
-        fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || j >= nk) ? oob : ao + j * 64, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);    // issue in ring order (the scheduler would issue the first-needed block last)
-    }
-    // epilogue operands that do not depend on the chain are fetched now: a 10 us decode kernel cannot afford a dependent memory
-    // round trip (~2-3 us) after its last MFMA
-    const int en = n0 + r16; const bool en_ok = en < a.N;
-    float pre_bias = 0.0f, pre_res[4] = {0.f, 0.f, 0.f, 0.f}; long pre_po[4] = {0, 0, 0, 0};
-    if (EPI != EPI_VT_F16 && a.bias && en_ok) pre_bias = a.bias[en];
-    if (EPI == EPI_F32 && a.res && en_ok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_res[r] = a.res[(long)m * a.ldres + en]; }
-    }
-    if (EPI == EPI_DEC_QKV && a.pos_ptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int m = mt * 16 + kq * 4 + r; if (m < a.M) pre_po[r] = (long)a.pos_ptr[(long)m * a.pos_stride] * a.n_ctx; }
-    }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < nk; kb0 += SM_DEPTH) {      // branch-free body: the ring stays SM_DEPTH blocks ahead
-#pragma unroll
-        for (int j = 0; j < SM_DEPTH; ++j) {
-            // convert the block's 16 operands first, then issue its 8 MFMAs back to back: a dependent MFMA that directly follows its
-            // producer costs 32 cycles, one separated from it by VALU work ~52 (tools/probe/probe_mfma_chain.hip: 56 -> 42 cycles/MFMA)
-            float xa[8], xw[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { xa[e] = h2f(fa[j].h[e]); xw[e] = h2f(fw[j].h[e]); }
-            __builtin_amdgcn_sched_barrier(0);
-            // refill the slot only now that it has been read: a copy of the old fragment kept live across the reload makes the
-            // register allocator rotate the whole ring with ~100 v_mov at the loop's back edge behind an s_waitcnt vmcnt(0)
-            // (a full memory latency per trip: K = 3072 ran at 31 us instead of 21)
-            const int nb = kb0 + j + SM_DEPTH;
-            fw[j].v = __builtin_amdgcn_raw_buffer_load_b128(rw, (wo == oob || nb >= nk) ? oob : wo + nb * 64, 0, 0);
-            fa[j].v = __builtin_amdgcn_raw_buffer_load_b128(ra, (ao == oob || nb >= nk) ? oob : ao + nb * 64, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = MFMA16(xa[e], xw[e], acc);
-            // keep each block's reload where it is: left alone, the scheduler sinks all loads to the end of the unrolled body
-            // (shorter live ranges) and the next pass then waits out a full memory latency (measured: 40 -> 20 us at K = 3072)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int m = mt * 16 + kq * 4 + r, n = n0 + r16;
-        if (!(m < a.M && n < a.N)) continue;
-        float v = acc[r];
-        if (EPI == EPI_F32) {                                   // same operations, in the same order, as epi_store<EPI>
-            if (a.bias) v = v + pre_bias;
-            if (a.res) v = v + pre_res[r];
-            ((float*)a.C)[(long)m * a.ldc + n] = v;
-        } else if (EPI == EPI_F16_PLAIN) {
-            if (a.bias) v = v + pre_bias;
-            if (a.has_scale) v = v * a.scale;
-            ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
-        } else if (EPI == EPI_GELU_F16_KPERM) {
-            if (a.bias) v = v + pre_bias;
-            ((half_t*)a.C)[(long)m * a.ldc + skw_kperm(n)] = f2h(gelu_dev(v, a.gelu_tab));
-        } else if (EPI == EPI_DEC_QKV) {
-            const int d = a.n_ctx;
-            if (a.bias) v = v + pre_bias;
-            if (n < 2 * d) v = v * a.scale;
-            if (n < d) ((half_t*)a.C)[(long)m * a.ldc + n] = f2h(v);
-            else if (n < 2 * d) ((half_t*)a.C2)[(long)m * a.ldc2 + pre_po[r] + (n - d)] = f2h(v);
-            else ((half_t*)a.C3)[(long)m * a.ldc2 + pre_po[r] + (n - 2 * d)] = f2h(v);
-        } else epi_store<EPI>(a, m, n, acc[r]);
-    }
-}
-
-// The same with the contraction in FOUR contiguous K segments (D3'): a workgroup is one 16-column strip x one 16-row tile, wave s
+// ------------------------------------------------------------------ small-M GEMM (decode, M <= 64), exact precision
+// Weight-streaming form: fragments straight from global memory, a ring of SM_DEPTH k-blocks (16 B per lane per operand per block) in flight to hide HBM latency.
+// The contraction runs in FOUR contiguous K segments (D3'): a workgroup is one 16-column strip x one 16-row tile, wave s
 // chains segment s (k-blocks [s nk/4, (s+1) nk/4), k-ascending from zero), the partial tiles meet in LDS and wave 0 adds them in ascending
 // segment order, ((s0 + s1) + s2) + s3 — oracle/skw_oracle.c gemm_chain_seg4, bit for bit.  A quarter of the dependent-MFMA chain per wave.
 template <int EPI, int SM_DEPTH>
@@ -307,19 +217,13 @@ void skw_gemm(const SkwGemmArgs& a, hipStream_t s) {
         case EPI_F16_PLAIN: launch_gemm<EPI_F16_PLAIN>(a, s); break;
     }
 }
+// K % 128 == 0 (skw_model_load rejects any other decoder width: the oracle's segmented chain, gemm_chain_seg4, is defined for it)
 template <int EPI> static void launch_gemm_small(const SkwGemmArgs& a, hipStream_t s) {
-    const int nk = a.K >> 5;
-    if (!(a.K & 127)) {      // the decoder's contractions: four segments (D3'); every Whisper geometry takes this branch
-        const dim3 gs((a.N + 15) / 16, (a.M + 15) / 16); const int nkq = nk >> 2;
-        if (nkq % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 24>), gs, dim3(256), 0, s, a);
-        else if (nkq <= 6) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 6>), gs, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 8>), gs, dim3(256), 0, s, a);
-        return;
-    }
-    dim3 grid((a.N + 15) / 16, (a.M + 63) / 64);
-    // K = 768-class contractions keep the whole operand strip in flight (24 blocks = 192 VGPRs); others use an 8-deep ring
-    if (nk % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm<EPI, 24>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_gemm_smallm<EPI, 8>), grid, dim3(256), 0, s, a);
+    const int nk = a.K >> 5, nkq = nk >> 2;
+    const dim3 gs((a.N + 15) / 16, (a.M + 15) / 16);
+    if (nkq % 24 == 0) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 24>), gs, dim3(256), 0, s, a);
+    else if (nkq <= 6) hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 6>), gs, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gemm_smallm_seg<EPI, 8>), gs, dim3(256), 0, s, a);
 }
 void skw_gemm_smallm(const SkwGemmArgs& a, hipStream_t s) {
     switch (a.epi) {
@@ -345,7 +249,7 @@ __device__ __forceinline__ void att_store_m(half_t* out, int m, long ldo, int co
 __device__ __forceinline__ double wave_sum_f64(double v) { return skw_wave_sum_f64(v); }   // DPP + readlane, no LDS crossbar (skw_dev_common.h)
 // one wave per R rows; d <= 64 NC (NC = 12 for every width up to Whisper-small's, 24 up to 1536); FULL: d == 64 NC (Whisper-small: straight-line code, no tail predicates).
 // R = 2 for the encoder's 96 000-row launches: the kernel is a stream (442 MB per launch) and a wave with one 3 KiB row in flight leaves the CU short of bytes in flight;
-// the rows' arithmetic is skw_ln_rows' either way (same bits).  SKW_LN_ROWS=1 restores one row per wave.
+// the rows' arithmetic is skw_ln_rows' either way (same bits; profiles/r04i: 0.085 vs 0.11 ms per launch).
 template <int NC, bool FULL, int R = 1>
 __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32) {
     const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -366,8 +270,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* x, int rows, int
     skw_ln_rows<R, NC, FULL>(v, wv, bv, d, lane, live, o16, o32);
 }
 void skw_layernorm(const float* x, int rows, int d, const float* w, const float* b, half_t* out16, float* out32, hipStream_t s) {
-    static const int r_env = getenv("SKW_LN_ROWS") ? atoi(getenv("SKW_LN_ROWS")) : 0;
-    const bool two = (r_env ? r_env == 2 : rows >= 8192) && d == 768;
+    const bool two = rows >= 8192 && d == 768;
     const dim3 g(two ? (rows + 7) / 8 : (rows + 3) / 4);
     if (two) hipLaunchKernelGGL((k_layernorm<12, true, 2>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
     else if (d == 768) hipLaunchKernelGGL((k_layernorm<12, true>), g, dim3(256), 0, s, x, rows, d, w, b, out16, out32);
@@ -708,7 +611,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_encoder_v3(const half_t* Qh, co
 }
 
 void skw_attn_encoder(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s, float* dbg, float* dbg2, int f32_out) {
-    if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg && !getenv("SKW_ATTN_V1")) {     // Whisper's 1500-frame context
+    // Whisper's 1500-frame context; k_attn_encoder below is the form that carries the stage taps (layer 0 of a tapped run) and any other context length
+    if (Tpad == 1504 && Tpad - n_ctx < 16 && !dbg) {
         const int qtiles = (n_ctx + 63) / 64;
         constexpr int RT3 = 72;
         hipLaunchKernelGGL((k_attn_encoder_v3<94, RT3>), dim3(qtiles * H * B), dim3(256), (size_t)4 * (94 - RT3) * 64 * 16, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad,
@@ -1062,38 +966,19 @@ __global__ __launch_bounds__(256) void k_dec_attn(const half_t* q, long ldq, con
 // 16-byte load = 8 keys of one channel), B = p broadcast to every column, so each output channel is the same key-ascending fma chain
 // as the scalar form; an 8-deep ring keeps V^T in flight (4 .. 16 deep measure the same within 2 %).  HBM-bound: 55.3 MB per sequence per step over all layers.
 // (HIP's uint4 arrays defeat SROA and land in scratch; the rings use ext_vector types.)
-// FQ: the kernel also makes its own query.  The LayerNorm of the sequence's residual row (K3: the block-wide form of skw_ln_rows, same
-// operations per element, f64 sums) and the query projection of the workgroup's heads run in front of the score passes: lane = output
-// channel, wave s of a head = K segment s of the decoder's segmented contraction (D3'), each a k-ascending v_fma_mix chain, the four
-// partial sums added ((s0 + s1) + s2) + s3, bias, scale, f16 — oracle/skw_oracle.c gemm_chain_seg4, bit for bit.  The weight rows of a
-// head (64 rows x 128 B per step) arrive the way K rows do — coalesced into the ring registers, transposed through the wave's LDS slab —
-// and the K ring is refilled as its slots drain: two launches (LayerNorm, a 64 x 768 x 768 product: 10.4 us of a 125 us layer) become a prologue —
-// which measured 14.6 us (the HBM stream idles behind it on every CU at once), so the form is opt-in (skw_dec_cross_attn_vt_q_ok).
-// In both precisions the query is this exact chain.  Needs WPH == 4, d % 128 == 0, d <= 1536.
 #ifndef SKW_XATTN_RD16
 #define SKW_XATTN_RD16 16      // V^T blocks in flight per wave in the f16_mfma P.V (8: 56.4 us per launch in tools/xattn_probe.py, 12: 55.7, 16: 55.7, 24: 56.1)
 #endif
-struct SkwXQ { const float* x; const float* ln_w; const float* ln_b; const half_t* W; long ldw; const float* bias; float scale; int d; };
-template <int MAXT, int WPH, int HPW, bool FQ = false, bool PV16 = false>
+template <int MAXT, int WPH, int HPW, bool PV16 = false>
 __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW * WPH)) void k_dec_cross_attn(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk,
                                                            const half_t* vtbase, int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active, int active_stride,
-                                                               int f32_out, SkwXQ xq, const int* seq) {
-    // XCD-aware placement (bit 16 of f32_out; SKW_XATTN_XCD=1, measured: no effect, 54.5 - 55.2 us against 54.3): workgroups are dealt to the 8 XCDs round-robin by linear id, so
-    //  the (H / HPW) workgroups of one sequence — which together
-    // read every 1536-byte K row of that sequence, a 384-byte piece each — land on different XCDs; remapped, the pieces of a row are requested through one XCD's L2
-    int bx = blockIdx.x, by = blockIdx.y;
-    if ((f32_out >> 16) & 1) { const int G = gridDim.x, Lid = by * G + bx, j = Lid & 7, k = Lid >> 3; by = j + 8 * (k / G); bx = k % G; }
+                                                               int f32_out, const int* seq) {
+    const int bx = blockIdx.x, by = blockIdx.y;
     if (active && !active[by * active_stride]) return;      // uniform per workgroup (one sequence): a finished sequence stops streaming its 55 MB of cross K/V
-    // tools/xattn_probe.py only: 1 = no P.V MFMAs, 2 = no score chains, 4 = no LDS transposes either, 8 = no V^T loads (results are then garbage; timing only)
-    const int probe = (f32_out >> 8) & 0xff; f32_out &= 1;
     __shared__ float plds[HPW][MAXT * 64];
     __shared__ __attribute__((aligned(16))) half_t klds[HPW * WPH][64 * 72];
     __shared__ float smax[HPW][WPH];
     __shared__ double ssum[HPW][WPH];
-    __shared__ __attribute__((aligned(16))) half_t xln[FQ ? 1536 : 8];           // LayerNorm(x[b]) as f16, kperm order (what k_layernorm writes)
-    __shared__ float qred[FQ ? HPW : 1][4][64];
-    __shared__ __attribute__((aligned(16))) half_t qown[FQ ? HPW * WPH : 1][64];
-    __shared__ double lnred[HPW * WPH];
     __shared__ __attribute__((aligned(16))) half_t p16[PV16 ? HPW : 1][PV16 ? MAXT * 64 : 8];      // PV16: the probabilities as f16 in kperm order, the f16 MFMA's second operand
     // half = this wave's part of the head (keys in the score phase, channels in P.V); readfirstlane: keeps the buffer descriptor in SGPRs (no waterfall loops)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w / WPH, half = w % WPH;
@@ -1116,100 +1001,11 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
         for (int i = 0; i < 8; ++i) dst[i] = ldk16(K + (long)min(t * 64 + i * 8 + lrow, n_ctx - 1) * ldk + lseg * 8);
         __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (!FQ) {
+    {
         const u32x4* qp = (const u32x4*)(q + (long)b * ldq + h * 64);
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = qp[c8];
         kfill(k0, t_lo); kfill(k1, t_lo + 1);
-    } else {
-        static_assert(!FQ || WPH == 4, "one wave per K segment");
-        constexpr int NTH = 64 * HPW * WPH, NSL = (1536 + NTH - 1) / NTH;
-        const int d = xq.d, tid = threadIdx.x, nkq = d >> 7, nst = (nkq + 1) >> 1;   // 32-blocks per segment; steps of two blocks (one 128-byte line per weight row)
-        // the row, its gain and bias: one element per thread (two past d = 768)
-        float xv[NSL], gw[NSL], gb[NSL];
-        { const float* xr = xq.x + (long)b * d;
-#pragma unroll
-          for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; const bool in = i < d; xv[c] = in ? xr[i] : 0.0f; gw[c] = in ? xq.ln_w[i] : 0.0f; gb[c] = in ? xq.ln_b[i] : 0.0f; } }
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's weight rows (channel = 64 h + i*8 + lrow, 16-byte piece lseg of the step's 128 bytes); a step's second block may lie past the segment: it is fetched from
-        //  inside the row and not used
-        const char* Wseg = (const char*)(xq.W + (long)(h * 64) * xq.ldw + half * nkq * 32);      // wave-uniform base + one 32-bit lane offset: eight loads share the address registers
-        const unsigned wlo = (unsigned)((lrow * (int)xq.ldw + (lseg & 3) * 8) * 2);
-        auto wfill = [&](u32x4 (&dst)[8], int t) {
-            const unsigned off = wlo + (unsigned)min(2 * t + (lseg >> 2), nkq - 1) * 64u;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dst[i] = *(const u32x4*)(Wseg + (long)i * 16 * xq.ldw + off);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        wfill(k0, 0); if (nst > 1) wfill(k1, 1); if (nst > 2) wfill(k2, 2);
-        // LayerNorm of the row by the whole workgroup
-        double sm = 0.0;
-#pragma unroll
-        for (int c = 0; c < NSL; ++c) sm += (double)xv[c];
-        sm = wave_sum_f64(sm);
-        if (lane == 0) lnred[w] = sm;
-        __syncthreads();
-        sm = 0.0;
-#pragma unroll
-        for (int i = 0; i < HPW * WPH; ++i) sm += lnred[i];
-        const float mean = (float)(sm / (double)d);
-        __syncthreads();
-        double sm2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; if (i < d) { const float t = xv[c] - mean; xv[c] = t; sm2 += (double)(t * t); } }
-        sm2 = wave_sum_f64(sm2);
-        if (lane == 0) lnred[w] = sm2;
-        __syncthreads();
-        sm2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < HPW * WPH; ++i) sm2 += lnred[i];
-        const float variance = (float)(sm2 / (double)d);
-        const float scl = 1.0f / sqrtf(variance + 1e-5f);
-#pragma unroll
-        for (int c = 0; c < NSL; ++c) { const int i = tid + NTH * c; if (i < d) { float t = xv[c] * scl; t = t * gw[c]; t = t + gb[c]; xln[skw_kperm(i)] = f2h(t); } }
-        __syncthreads();
-        // the chain: one step = 64 k of this wave's segment for all 64 channels
-        float qa = 0.0f;
-        const half_t* xs = xln + half * nkq * 32;
-        auto wstep = [&](int t, u32x4 (&cur)[8]) {
-            if (t < nst) {      // workgroup-uniform
-#pragma unroll
-                for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = cur[i];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (2 * t + u < nkq) {
-                        H8v wq[4], xq4[4];      // the activations are the same for every lane: they ride in SGPRs
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { wq[r].v = *(const u32x4*)(kl + lane * 72 + u * 32 + r * 8); const u32x4 xr4 = *(const u32x4*)(xs + (2 * t + u) * 32 + r * 8);
-#pragma unroll
-                            for (int z = 0; z < 4; ++z) xq4[r].v[z] = __builtin_amdgcn_readfirstlane(xr4[z]); }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) qa = __builtin_fmaf(h2f(xq4[r].h[e]), h2f(wq[r].h[e]), qa);     // logical k = 32 blk + 4 e + r, ascending
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        // a drained slot takes the segment's next weight step while there is one (d > 768), and in the last round the first two K passes
-        const int T = ((nst + 2) / 3) * 3;
-        for (int t0 = 0; t0 < T; t0 += 3) {
-            const bool last = t0 + 3 >= T;
-            wstep(t0, k0);     if (t0 + 3 < nst) wfill(k0, t0 + 3); else if (last) kfill(k0, t_lo);
-            wstep(t0 + 1, k1); if (t0 + 4 < nst) wfill(k1, t0 + 4); else if (last) kfill(k1, t_lo + 1);
-            wstep(t0 + 2, k2); if (t0 + 5 < nst) wfill(k2, t0 + 5);
-        }
-        qred[hs][half][lane] = qa;
-        __syncthreads();
-        { float v = qred[hs][0][lane] + qred[hs][1][lane]; v = v + qred[hs][2][lane]; v = v + qred[hs][3][lane];
-          if (xq.bias) v = v + xq.bias[h * 64 + lane];
-          v = v * xq.scale;
-          qown[w][lane] = f2h(v); }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) qh[c8].v = *(const u32x4*)(qown[w] + c8 * 8);
     }
     // one pass = 64 keys: refill the free ring slot with pass t+2 first, then consume `cur`.  Roles rotate by name (three passes per
     // loop trip) so no register copies force early waits, and the scheduling barriers keep the loads where they are written.
@@ -1225,10 +1021,6 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
         if (t < t_hi) {       // wave-uniform
             const int key = t * 64 + lane;
             float a = 0.0f;
-            if (probe & 4) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a += __uint_as_float(cur[i][0] ^ cur[i][1] ^ cur[i][2] ^ cur[i][3]) * 1e-30f;
-            } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) *(u32x4*)(kl + (i * 8 + lrow) * 72 + lseg * 8) = cur[i];
             __builtin_amdgcn_wave_barrier();   // same wave, LDS in order: a compiler-level fence is all that is needed
@@ -1236,10 +1028,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
             for (int c8 = 0; c8 < 8; ++c8) asm volatile("" : "+v"(qh[c8].v));   // opaque: stops the 64 conversions being hoisted out of the loop into 64 live registers
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) { H8v t8; t8.v = *(const u32x4*)(kl + lane * 72 + c8 * 8);
-                if (probe & 2) { a += h2f(t8.h[0]); continue; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = __builtin_fmaf(h2f(qh[c8].h[e]), h2f(t8.h[e]), a); }
-            }
             __builtin_amdgcn_wave_barrier();
             if (key >= n_ctx) a = -INFINITY;
             pl[key] = a; lmax = fmaxf(lmax, a);
@@ -1288,7 +1078,7 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
     f32x4 oacc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) oacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < ((probe & 8) ? 0 : nkb); kb0 += RD) {
+    for (int kb0 = 0; kb0 < nkb; kb0 += RD) {
 #pragma unroll
         for (int j = 0; j < RD; ++j) {
             const int kb = kb0 + j;
@@ -1305,10 +1095,8 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
                 // Same products, summed in the matrix core's order for the block rather than key by key.
                 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
                 const f16x8_t pb = *(const f16x8_t*)(&p16[hs][kbc * 32 + g * 8]);
-                if (!(probe & 1)) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, vf[ct].v), pb, oacc[ct], 0, 0, 0);
-                }
+                for (int ct = 0; ct < CT; ++ct) oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, vf[ct].v), pb, oacc[ct], 0, 0, 0);
                 continue;
             }
             float pe[8], xv[CT][8];      // operands first, then the MFMAs back to back (a dependent MFMA directly behind its producer is the cheap case)
@@ -1317,15 +1105,10 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) xv[ct][e] = h2f(vf[ct].h[e]); }
             __builtin_amdgcn_sched_barrier(0);
-            if (probe & 1) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) oacc[ct][0] += xv[ct][0] + pe[0];
-            } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) oacc[ct] = MFMA16(xv[ct][e], pe[e], oacc[ct]);   // O^T[c][*] += V^T[c][key] * p[key]
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1348,14 +1131,31 @@ __global__ __launch_bounds__(64 * HPW * WPH, (HPW * WPH >= 12) ? 1 : 12 / (HPW *
 //            p = exp2((s - m) log2 e) rounded to f16 unnormalised (<= 1: no subnormal loss that 1 / sum would add), per-lane partial sums
 //   P.V      O^T[c][*] += V^T[c][keys] . p, four 16-channel tiles, one MFMA each
 // and the four partial (m, l, O) meet in LDS at the end (one barrier).  RD blocks (8 KB each) are in flight per wave, 12 waves per CU.
-// AUX = 2: the K / V^T loads carry the non-temporal policy (experiment: keep the once-read stream out of the Infinity Cache so that the step's weights stay in it)
-template <int HPW, int RD, bool FRAG = false, int AUX = 0>
+// K and V^T are the fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB, and the loads carry the non-temporal policy (aux = 2: the
+// once-read stream stays out of the caches the step's weights live in; 49.5 -> 45.7-46.2 us per full launch, profiles/r03h).  The four waves of a head take every fourth 32-key block, so
+// together they walk one sequential stream.  What lost against this form (profiles/r03g, r03h, r04i): the row layouts (16 x 64 B per load instruction), contiguous quarters per wave, 2 / 4
+// blocks in flight, one or two heads per workgroup, XCD-aware placement of a sequence's workgroups.
+// clk (bench.py's roofline line; null in every other run): the launch's own begin and end on the device's constant-rate clock — see SkwKClk in skw_kernels.h.
+template <int HPW, int RD>
 __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cross_attn16(const half_t* q, long ldq, const half_t* kbase, long k_batch_stride, long ldk, const half_t* vtbase,
                                                                                          int n_ctx, int Tpad, int H, half_t* out, long ldo, const int* active,
-                                                                                             int active_stride, int f32_out, const int* seq, int ofrag_k) {
+                                                                                             int active_stride, int f32_out, const int* seq, int ofrag_k, SkwKClk* clk) {
     typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int AUX = 2;
     const int b = blockIdx.y;
-    if (active && !active[b * active_stride]) return;
+    const bool row_live = !(active && !active[b * active_stride]);
+    SkwKClkRec* rec = nullptr;                                          // thread 0 only
+    if (clk && threadIdx.x == 0) {
+        // every workgroup of the launch takes a ticket (finished rows too: the launch index is ticket / workgroups per launch; launches of one graph node are serial on its stream)
+        const unsigned long long t_in = wall_clock64();
+        const unsigned launch = atomicAdd(&clk->arrive, 1u) / (gridDim.x * gridDim.y);
+        if (row_live && launch < clk->cap) {
+            rec = clk->rec + launch;
+            atomicMax(&rec->t0_inv, ~t_in);                             // earliest begin over the workgroups (stored inverted: the records start as zeros)
+            if (blockIdx.x == 0) atomicAdd(&rec->live_rows, 1u);
+        }
+    }
+    if (!row_live) return;
     __shared__ float cmb[HPW][4][66];                                   // per wave: m, l, O[64]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hs = w >> 2, part = w & 3;
     const int hraw = blockIdx.x * HPW + hs;
@@ -1363,40 +1163,21 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
     const int h = valid ? hraw : H - 1;
     const int bs = seq ? seq[b * active_stride] : b;
     const int r16 = lane & 15, g = lane >> 4;
-    // a wave's blocks: a contiguous quarter (first + n), or every fourth block (f32_out bit 1: the four waves of a head then walk one sequential stream together)
-    const int il = (f32_out >> 1) & 1; f32_out &= 1;
-    const int nkb = Tpad >> 5, per = (nkb + 3) >> 2;
-    const int first = il ? part : part * per, step = il ? 4 : 1, cnt = il ? (nkb - part + 3) >> 2 : max(0, min(nkb, part * per + per) - part * per);
+    // a wave's blocks: every fourth 32-key block (the four waves of a head walk one sequential stream together)
+    const int nkb = Tpad >> 5;
+    const int first = part, step = 4, cnt = (nkb - part + 3) >> 2;
     f16x8_t qb[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) qb[kk] = *(const f16x8_t*)(q + (long)b * ldq + h * 64 + kk * 32 + g * 8);
-    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + (long)bs * k_batch_stride), 0, (unsigned)((long)(FRAG ? Tpad : n_ctx) * ldk * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + (long)bs * k_batch_stride), 0, (unsigned)((long)Tpad * ldk * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(vtbase + ((long)bs * H + h) * 64 * Tpad), 0, (unsigned)(64 * Tpad * 2), 0x00020000);
-    const int krow = 4 * (r16 & 3) + (r16 >> 2);
-    const unsigned ko = (unsigned)((h * 64 + g * 8) * 2), kstride = (unsigned)(ldk * 2);
-    const unsigned vo = (unsigned)((r16 * Tpad + g * 8) * 2), vstride = (unsigned)(16 * Tpad * 2);
     u32x4 ring[RD][8];
-    // one block's loads: K rows of the two score tiles (per-lane row offset — clamped to the last real key —, the d half as the instruction's immediate), then the four V^T tiles
-    // (per-lane offset + block, the channel tile in the scalar offset)
+    // one block's loads: 4 KiB of K (two score tiles x two d halves) and 4 KiB of V^T (four channel tiles); pad keys of the last tile hold whatever memory held (masked below)
     auto issue = [&](u32x4 (&slot)[8], int kb) {
-        // fragment-order images (skw_kfrag_off / skw_vtfrag_off): every load instruction is one contiguous KiB; pad keys of the last tile hold whatever memory held (masked below)
-        if constexpr (FRAG) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, AUX);
+        for (int i = 0; i < 4; ++i) slot[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)(((h * (nkb * 2) + kb * 2) * 2 + i) * 1024 + lane * 16), 0, AUX);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)((kb * 4 + ct) * 1024 + lane * 16), 0, AUX);
-            __builtin_amdgcn_sched_barrier(0);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned off = (unsigned)min(kb * 32 + 16 * j + krow, n_ctx - 1) * kstride + ko;
-            slot[j * 2] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
-            slot[j * 2 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rk, off + 64, 0, 0);
-        }
-        const unsigned voff = vo + (unsigned)kb * 64;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff, ct * vstride, 0);
+        for (int ct = 0; ct < 4; ++ct) slot[4 + ct] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)((kb * 4 + ct) * 1024 + lane * 16), 0, AUX);
         __builtin_amdgcn_sched_barrier(0);
     };
 #pragma unroll
@@ -1466,130 +1247,35 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
         num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }
         att_store_m(out, b, ldo, h * 64 + lane, num / den, f32_out, ofrag_k);
     }
+    if (rec) atomicMax(&rec->t1, wall_clock64());                       // latest end over the workgroups (thread 0 sits in a wave that does the final combine and store)
 }
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
-    int f32_out, int pv16, const int* seq,
-                           hipEvent_t ev_start, hipEvent_t ev_stop, int ofrag) {
-    static const int wph = getenv("SKW_XATTN_WPH") ? atoi(getenv("SKW_XATTN_WPH")) : 4;
+    int f32_out, int pv16, const int* seq, hipEvent_t ev_start, hipEvent_t ev_stop, int ofrag, SkwKClk* clk) {
     const int as = (int)(sizeof(SkwSeqState) / 4);
-    const SkwXQ none{};
-    // heads per workgroup: 3 (256 workgroups of 12 waves at 64 rows x 12 heads: every CU)
-    static const int hpw_env = getenv("SKW_XATTN_HPW") ? atoi(getenv("SKW_XATTN_HPW")) : 0;
-    const int hpw = hpw_env ? hpw_env : 3;        // (one head per workgroup measured 1.5 % slower for 32-row groups: more, smaller workgroups do not stream faster)
-    static const int xcd_env = getenv("SKW_XATTN_XCD") ? atoi(getenv("SKW_XATTN_XCD")) : 0;
-    if (xcd_env && (B & 7) == 0) f32_out |= 1 << 16;
-    // f16_mfma precision, pv16 == 2: cross K / V^T are fragment-order images and the launch is the one-pass streaming kernel (interleaved block assignment: SKW_XATTN16_IL=0 for quarters).
-    // pv16 == 1 (row layouts): the two-phase kernel with the f16 P.V below; SKW_XATTN16=1 runs the one-pass kernel on the row layouts instead (measured slower: 55.0 vs 53.6 us — an MFMA
-    // operand tile read from rows is 16 x 64 B per instruction, twice the requests per byte; that is what the fragment order removes: 49.5 us)
-    static const int x16 = getenv("SKW_XATTN16") ? atoi(getenv("SKW_XATTN16")) : 0, x16il = getenv("SKW_XATTN16_IL") ? atoi(getenv("SKW_XATTN16_IL")) : 1;
-    if ((pv16 == 2 || (pv16 && x16)) && !(f32_out >> 8)) {
-        const int fo = (f32_out & 1) | (x16il ? 2 : 0);
-        const dim3 grid((H + 2) / 3, B), blk(768);
-        const long kbs = (long)(pv16 == 2 ? Tpad : n_ctx) * d;
-        // the once-read K / V^T stream with the non-temporal policy: 47.8 -> 46.0-46.3 us per launch in step (same-box A/B, profiles/r03h/r03h_xattn16_nt_ab.txt; on the
-        //  two-phase kernel over the row layouts the same policy had cost 2 us)
-        static const int x16nt = getenv("SKW_XATTN16_NT") ? atoi(getenv("SKW_XATTN16_NT")) : 1;
-        static const int x16rd = getenv("SKW_XATTN16_RD") ? atoi(getenv("SKW_XATTN16_RD")) : 3;
-        // 1: one head (4 waves) per workgroup — smaller workgroups spread over every CU when a row group is small
-        static const int x16hpw = getenv("SKW_XATTN16_HPW") ? atoi(getenv("SKW_XATTN16_HPW")) : 3;
-        if (pv16 == 2 && x16nt && (x16hpw == 1 || x16hpw == 2)) {      // fewer heads per workgroup WITH the non-temporal policy (measurement: more, smaller workgroups for 32-row groups)
-            if (x16hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true, 2>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo,
-                seq, ofrag ? d : 0);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<2, 3, true, 2>), dim3((H + 1) / 2, B), dim3(512), 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo,
-                seq, ofrag ? d : 0);
-        } else if (pv16 == 2 && x16hpw == 1) {
-            const dim3 grid1(H, B), blk1(256);
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
-                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<1, 3, true>), grid1, blk1, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-        } else if (pv16 == 2 && x16nt && x16rd != 3) {      // (blocks in flight per wave: 2 / 4, measurement)
-            if (x16rd == 2) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 2, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
-                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 4, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H,
-                out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-        } else if (pv16 == 2 && x16nt) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx,
-                Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true, 2>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-        } else if (pv16 == 2) {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad,
-                H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, true>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-        } else {
-            if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad,
-                H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-            else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3, false>), grid, blk, 0, s, q, (long)d, ck, kbs, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, fo, seq, ofrag ? d : 0);
-        }
+    const dim3 grid((H + 2) / 3, B), blk(768);        // three heads per workgroup: 256 workgroups of 12 waves at 64 rows x 12 heads, one per CU
+    // (with events: hipExtLaunchKernelGGL stamps them at the kernel's own begin and end — the duration rocprofv3 reports — instead of an event pair around the launch, which adds the dispatch gap)
+    if (pv16 == 2) {          // f16_mfma precision, fragment-order cross K / V^T: the one-pass streaming kernel
+        if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn16<3, 3>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)Tpad * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d,
+            active, as, f32_out & 1, seq, ofrag ? d : 0, clk);
+        else hipLaunchKernelGGL((k_dec_cross_attn16<3, 3>), grid, blk, 0, s, q, (long)d, ck, (long)Tpad * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out & 1, seq,
+            ofrag ? d : 0, clk);
         return;
     }
-    if (pv16 == 2) pv16 = 1;       // (probe launches with parts switched off exist for the two-phase kernel only)
-    if (hpw == 1) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 1>), dim3(H, B), dim3(256), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
-        (long)d, active, as, f32_out, none, seq);
-    // (profiling: hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end — the duration rocprofv3 reports —
-    //  instead of an event pair around the launch, which adds the dispatch gap)
-    else if (wph == 4 && pv16 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0,
-        q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, ev_start, ev_stop, 0, q, (long)d, ck,
-        (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4 && pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, false, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d,
-        (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else if (wph == 4) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), dim3((H + 2) / 3, B), dim3(768), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx,
-        Tpad, H, out, (long)d, active, as, f32_out, none, seq);
-    else hipLaunchKernelGGL((k_dec_cross_attn<24, 2, 3>), dim3((H + 2) / 3, B), dim3(384), 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
-        (long)d, active, as, f32_out, none, seq);
-}
-// ------------------------------------------------------------------ cache warming: read `bytes` of a buffer and keep nothing.  The decode step's small launches leave HBM idle
-// (16.5 MB of weights per layer in ~58 us); a reader that runs beside them moves the next cross attention's K rows into the Infinity Cache (memory side, 256 MiB), from
-// where that launch then streams them faster than from HBM.  One wave per SIMD at most, <= 56 registers, no LDS: it fits beside every decode kernel's workgroups.
-__global__ __launch_bounds__(256) void k_touch(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    u32x4 acc = (u32x4){0u, 0u, 0u, 0u};
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 7 * stride < n16; i += 8 * stride) {
-        u32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= v[u];
-    }
-    for (; i < n16; i += stride) acc ^= p[i];
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) *sink = 1u;     // (never true in practice: keeps the loads)
-}
-void skw_touch(const void* p, size_t bytes, int n_wg, unsigned* sink, hipStream_t s) {
-    if (!bytes) return;
-    hipLaunchKernelGGL(k_touch, dim3(n_wg), dim3(256), 0, s, (const u32x4*)p, bytes / 16, sink);
-}
-// LayerNorm + query projection + cross attention in one launch (k_dec_cross_attn<.., FQ>): x f32 [B][d] residual rows, Wq f16 [d][ldw] kperm.
-// Returns false (nothing launched) for geometries the fused prologue does not cover; the caller then runs the three launches.
-bool skw_dec_cross_attn_vt_q_ok(int H, int d) {
-    // Off unless SKW_XATTN_FUSEQ=1: measured at B = 64, Whisper-small, the fused launch takes 75.0 us where the three launches take 4.9 + 5.5 + 60.4:
-    // the prologue (one row's LayerNorm across the workgroup, 3 weight steps through LDS, the 4-segment exchange) runs with the HBM stream not yet
-    // started, and every CU does it at the same time (one workgroup per CU, all in phase).  Kept: bit-identical to the oracle at every Whisper width
-    // (tests/test_gpu_parity.py::test_fused_query_cross_attention_matches_oracle).
-    static const bool on = getenv("SKW_XATTN_FUSEQ") && atoi(getenv("SKW_XATTN_FUSEQ")) != 0 && !getenv("SKW_XATTN_WPH") && !getenv("SKW_XATTN_HPW");
-    return on && !(d & 127) && d <= 1536 && d == H * 64;
-}
-bool skw_dec_cross_attn_vt_q(const float* x, const float* ln_w, const float* ln_b, const half_t* Wq, long ldw, const float* bq, float scale,
-                             const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s) {
-    if (!skw_dec_cross_attn_vt_q_ok(H, d)) return false;
-    const int as = (int)(sizeof(SkwSeqState) / 4);
-    const SkwXQ xq{x, ln_w, ln_b, Wq, ldw, bq, scale, d};
-    hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), dim3((H + 2) / 3, B), dim3(768), 0, s, nullptr, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H,
-        out, (long)d, active, as, 0, xq, (const int*)nullptr);
-    return true;
+    // row layouts: the two-phase kernel; pv16 == 1 (f16_mfma with SKW_XATTN_FRAG=0) takes a 32-key block of P.V in one f16 MFMA, the exact precision chains f32 MFMAs key by key
+    if (pv16 && ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
+        (long)d, active, as, f32_out & 1, seq);
+    else if (ev_start) hipExtLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), grid, blk, 0, s, ev_start, ev_stop, 0, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out,
+        (long)d, active, as, f32_out & 1, seq);
+    else if (pv16) hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3, true>), grid, blk, 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out & 1, seq);
+    else hipLaunchKernelGGL((k_dec_cross_attn<24, 4, 3>), grid, blk, 0, s, q, (long)d, ck, (long)n_ctx * d, (long)d, cvt, n_ctx, Tpad, H, out, (long)d, active, as, f32_out & 1, seq);
 }
 
 void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, const int* pos, int B, int H, int d, int n_text_ctx, half_t* out, const int* active,
     hipStream_t s, int f32_out, SkwQ8Out q8, const int* seq, int fastv, int ofrag) {
-    static const int fastv_env = getenv("SKW_DEC_ATTN_FASTV") ? atoi(getenv("SKW_DEC_ATTN_FASTV")) : 1;
-    if (fastv && fastv_env && !q8.q && !f32_out) { hipLaunchKernelGGL((k_dec_attn<7, true>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
+    if (fastv && skw_sw(SW_DEC_ATTN_FASTV) && !q8.q && !f32_out) { hipLaunchKernelGGL((k_dec_attn<7, true>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
                        pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq, ofrag ? d : 0); return; }
     hipLaunchKernelGGL((k_dec_attn<7>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, kc, vc, (long)n_text_ctx * d, (long)d,
                        pos, (int)(sizeof(SkwSeqState) / 4), 0, H, out, (long)d, active, (int)(sizeof(SkwSeqState) / 4), f32_out, q8, seq, (ofrag && !q8.q && !f32_out) ? d : 0);
-}
-void skw_dec_cross_attn(const half_t* q, const half_t* ck, const half_t* cv, int B, int H, int d, int n_ctx, half_t* out, hipStream_t s) {
-    hipLaunchKernelGGL((k_dec_attn<24>), dim3((H + 3) / 4, B), dim3(256), 0, s, q, (long)d, ck, cv, (long)n_ctx * d, (long)d,
-                       (const int*)nullptr, 0, n_ctx, H, out, (long)d, (const int*)nullptr, 0, 0, SkwQ8Out{nullptr, nullptr, nullptr, 0}, (const int*)nullptr, 0);
 }
 
 // ------------------------------------------------------------------ K11: logits -> token (+ state update)
@@ -2244,7 +1930,7 @@ __global__ void k_resample_lerp(const float* in, int channels, const int* pos, c
 }
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
                                 float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal) {
-    static const bool force_scan = getenv("SKW_RESAMPLE_SCAN") != nullptr;     // measurement switch: the single-lane walk only
+    const bool force_scan = skw_sw(SW_RESAMPLE_SCAN) != 0;     // the single-lane walk only (the fallback of both proposals; tests hold it to the same bits)
     if (force_scan) hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
     else {
         // flag[0]: 0 = first proposal stands, 1 = it failed, 2 = second proposal to be checked; flag[1]: the second one failed too

@@ -629,7 +629,7 @@ template <int EPI> static void launch_gemm16w(const SkwGemmArgs& a_in, hipStream
     const int Mv = Epi16<EPI>::X_IS_M ? (a.M / a.n_ctx) * a.Tpad : a.M;
     const int nbn_ = (a.N + 255) / 256, nbm_ = (Mv + 127) / 128;
     // feature-split walk (k_gemm16w's tile_origin): when the weight does not fit beside the token panels in an XCD's 4 MiB L2.  SKW_GEMM16W_NGROUPS: 0 automatic, 1 off, 2 / 4 / 8 forced
-    static const int ng_env = getenv("SKW_GEMM16W_NGROUPS") ? atoi(getenv("SKW_GEMM16W_NGROUPS")) : 0;
+    const int ng_env = skw_sw(SW_GEMM16W_NGROUPS);
     int ng = 1;
     if (ng_env > 1) ng = ng_env;
     else if (ng_env == 0 && !Epi16<EPI>::X_IS_M) { const double wb = 2.0 * a.N * a.K; while (ng < 8 && wb / ng > 2.6e6 && nbn_ % (2 * ng) == 0) ng *= 2; }
@@ -642,19 +642,17 @@ template <int EPI> static void launch_gemm16w(const SkwGemmArgs& a_in, hipStream
 }
 // the weights-from-image form applies when the weight has an image, the K axis is whole 64-steps and the feature count whole strips
 static bool gemm16w_ok(const SkwGemmArgs& a) {
-    static const int on = getenv("SKW_GEMM16W") ? atoi(getenv("SKW_GEMM16W")) : 1;
-    return on && a.Wf && !(a.probe & 1023) && (a.K & 63) == 0 && (a.N & 15) == 0 && a.M >= 128;      // (probe bits 0-9 are k_gemm16's; 10+ this kernel's)
+    return skw_sw(SW_GEMM16W) && a.Wf && !(a.probe & 1023) && (a.K & 63) == 0 && (a.N & 15) == 0 && a.M >= 128;      // (probe bits 0-9 are k_gemm16's; 10+ this kernel's)
 }
+bool skw_gemm16_takes_w(const SkwGemmArgs& a) { return gemm16w_ok(a); }      // tests: which of the two kernels skw_gemm16 would launch for these arguments
 template <int EPI> static void launch_gemm16(const SkwGemmArgs& a_in, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves, one workgroup per CU) when both extents fill it, 128 x 128 (4 waves, two per CU) otherwise;
     // persistent workgroups: one grid slot per resident workgroup (rounded to the 8 XCDs), each walks tile ids slot, slot + grid, ...
-    static const int force = getenv("SKW_GEMM16_TILE") ? atoi(getenv("SKW_GEMM16_TILE")) : 0;
     const int Mv = Epi16<EPI>::X_IS_M ? (a_in.M / a_in.n_ctx) * a_in.Tpad : a_in.M;
-    const bool big = force ? force == 256 : (Mv >= 256 && a_in.N >= 256 && Mv % 256 == 0 && a_in.N % 256 == 0);
+    const bool big = Mv >= 256 && a_in.N >= 256 && Mv % 256 == 0 && a_in.N % 256 == 0;
     const int cus = skw_cu_count() & ~7;
     const SkwGemmArgs& a = a_in;
-    static const int oldloop = getenv("SKW_GEMM16_OLDLOOP") ? atoi(getenv("SKW_GEMM16_OLDLOOP")) : 0;      // (A/B: the K loop with the staging branch, as it was)
-    if (big && (a.probe || oldloop)) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256);
+    if (big && a.probe) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256);
     hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4, true>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else if (big) { const int nblk = ((Mv + 255) / 256) * ((a.N + 255) / 256); hipLaunchKernelGGL((k_gemm16<EPI, 256, 256, 2, 4>), dim3(std::min(nblk, cus)), dim3(512), 0, s, a); }
     else { const int nblk = ((Mv + 127) / 128) * ((a.N + 127) / 128); hipLaunchKernelGGL((k_gemm16<EPI, 128, 128, 2, 2>), dim3(std::min(nblk, 2 * cus)), dim3(256), 0, s, a); }
@@ -704,7 +702,7 @@ void skw_gemm16(const SkwGemmArgs& a, hipStream_t s) {
 struct SkwXPrefill { const int* row0; const int* nq; const int* slot; long ldq; long k_seq_stride; long ldk; int frag; int ofrag_k; };
 template <bool XP, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void k_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out,
-                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp, int ksw_r3) {
+                                                           int H, int n_ctx, int Tpad, float kq_scale, int qblocks, SkwXPrefill xp) {
     __shared__ __attribute__((aligned(1024))) char lds[2][2][64 * 128];   // [buffer][K | V^T][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = gridDim.x; int bid = blockIdx.x;
@@ -741,7 +739,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_encoder16(const half_t* Qh, c
     for (int i = 0; i < 2; ++i) {
         const int c = tid + 256 * i, row = c >> 3, pos = c & 7;
         st_lds[i] = (unsigned)(row * 128 + ((pos ^ (row & 7)) << 4));
-        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ (ksw_r3 ? (((row & 1) << 2) | ((row >> 2) & 3)) : ((row >> 1) & 6))) << 4));      // (ksw_r3: round 3's swizzle, SKW_ATTN_KSW_R3=1, for the A/B)
+        st_ldsk[i] = (unsigned)(row * 128 + ((pos ^ ((row >> 1) & 6)) << 4));      // (round 3's swizzle had a two-way conflict on every K read: profiles/r04c)
         st_k[i] = (unsigned)((row * krow + pos * 8) * 2);            // + kb * 64 rows; rows past Tpad (XP: past n_ctx) fall outside the descriptor: zeros
         st_v[i] = (unsigned)((row * Tpad + pos * 8) * 2);            // + kb * 64 keys; chunks past Tpad are replaced by zeros below
         // the same 16-byte chunks at their fragment-order addresses: a 64-key block is 8 KiB of either image (K: key tile row >> 4 of the block, row 4 (r & 3) + (r >>
@@ -755,7 +753,7 @@ __global__ __launch_bounds__(256, OCC) void k_attn_encoder16(const half_t* Qh, c
     }
     const int nkb = (Tpad + 63) >> 6;
     const int kappa = 4 * (r16 & 3) + (r16 >> 2);
-    const int k_off = kappa * 128, k_sw = ksw_r3 ? (r16 & 7) : ((r16 & 3) << 1), v_off = r16 * 128, v_sw = r16 & 7;      // k_sw = (kappa >> 1) & 6: the stored swizzle of the row this lane reads
+    const int k_off = kappa * 128, k_sw = (r16 & 3) << 1, v_off = r16 * 128, v_sw = r16 & 7;      // k_sw = (kappa >> 1) & 6: the stored swizzle of the row this lane reads
     u32x4 sk[2], sv[2];
     auto load_k = [&](int kb) {
 #pragma unroll
@@ -864,22 +862,18 @@ __global__ __launch_bounds__(256, OCC) void k_attn_encoder16(const half_t* Qh, c
         }
     }
 }
-static int attn_ksw_r3() { static const int v = getenv("SKW_ATTN_KSW_R3") ? atoi(getenv("SKW_ATTN_KSW_R3")) : 0; return v; }
 void skw_attn_encoder16(const half_t* Qh, const half_t* Kh, const half_t* Vt, half_t* out, long ld_out, int B, int H, int n_ctx, int Tpad, hipStream_t s) {
     const int qblocks = (n_ctx + A16_QB - 1) / A16_QB;
     // registers capped at 128 (13 dwords of scratch per lane) so that four workgroups share a CU instead of three: 9.44-9.50 against 9.64-9.77 ms per batch in a same-box A/B
-    // (profiles/r04i/r04t); the waves of different workgroups are what overlaps one's exponentials with another's MFMAs.  SKW_ATTN_OCC=2: 143 registers, three per CU
-    static const int occ4 = getenv("SKW_ATTN_OCC") ? atoi(getenv("SKW_ATTN_OCC")) == 4 : 1;
-    if (occ4) hipLaunchKernelGGL((k_attn_encoder16<false, 4>), dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{},
-        attn_ksw_r3());
-    else hipLaunchKernelGGL((k_attn_encoder16<false, 2>), dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{}, attn_ksw_r3());
+    // (profiles/r04i/r04t); the waves of different workgroups are what overlaps one's exponentials with another's MFMAs (uncapped: 143 registers, three per CU)
+    hipLaunchKernelGGL((k_attn_encoder16<false, 4>), dim3(qblocks * H * B), dim3(256), 0, s, Qh, Kh, Vt, out, ld_out, H, n_ctx, Tpad, 1.0f / sqrtf(64.0f), qblocks, SkwXPrefill{});
 }
 // the prompt pass's cross attention: n_seq sequences, sequence i's queries are rows row0[i] .. row0[i] + nq[i] of q [rows][d] (already scaled, like K), its K / V^T those of window slot slot[i]
 void skw_xattn_prefill16(const half_t* q, const half_t* ck, const half_t* cvt, half_t* out, int n_seq, int nq_max, const int* row0, const int* nq, const int* slot,
                          int H, int d, int n_ctx, int Tpad, hipStream_t s, int frag, int ofrag) {
     const int qblocks = (nq_max + A16_QB - 1) / A16_QB;
     const SkwXPrefill xp{row0, nq, slot, (long)d, (long)(frag ? Tpad : n_ctx) * d, (long)d, frag, ofrag ? d : 0};
-    hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp, attn_ksw_r3());
+    hipLaunchKernelGGL(k_attn_encoder16<true>, dim3(qblocks * H * n_seq), dim3(256), 0, s, q, ck, cvt, out, (long)d, H, n_ctx, Tpad, 1.0f, qblocks, xp);
 }
 
 // what a wave does with a finished 16 x 16 tile: lane (r16, g) holds rows-of-W 4g .. 4g+3 (four adjacent outputs) of row m
@@ -895,11 +889,7 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
             if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + p0); v[0] = v[0] + b[0]; v[1] = v[1] + b[1]; v[2] = v[2] + b[2]; v[3] = v[3] + b[3]; }
             if (a.res) { if (a.ldres & 3) pre_res = (f32x4){a.res[(long)m * a.ldres + p0], a.res[(long)m * a.ldres + p0 + 1], a.res[(long)m * a.ldres + p0 + 2], a.res[(long)m * a.ldres + p0 + 3]};
                          v[0] = v[0] + pre_res[0]; v[1] = v[1] + pre_res[1]; v[2] = v[2] + pre_res[2]; v[3] = v[3] + pre_res[3]; }
-            float* dst = (float*)a.C + (long)m * a.ldc + p0;
-            if (a.ln_cnt) {                              // the LayerNorm tail reads these from another XCD: written through (agent scope), no L2 write-back needed later
-#pragma unroll
-                for (int r = 0; r < 4; ++r) __hip_atomic_store(dst + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else *(f32x4*)dst = v;
+            *(f32x4*)((float*)a.C + (long)m * a.ldc + p0) = v;
         }
     } else if (EPI == EPI_F16_PLAIN) { int x[4] = {p0, p0 + 1, p0 + 2, p0 + 3}; epi_store4<EPI_F16_PLAIN>(a, m, p0, x, v); }
     else if (EPI == EPI_GELU_F16_KPERM) {
@@ -917,55 +907,6 @@ __device__ __forceinline__ void gemm16_small_finish(const SkwGemmArgs& a, int m,
             half_t* dst = (p0 < 2 * d) ? (half_t*)a.C2 + (long)m * a.ldc2 + po + (p0 - d) : (half_t*)a.C3 + (long)m * a.ldc2 + po + (p0 - 2 * d);
             *(f16x4*)dst = o;
         }
-    }
-}
-
-// LayerNorm by the last arrival.  The decode GEMMs that write the residual stream x (C f32 [M][d], one workgroup per 16-column strip)
-// are each followed by a LayerNorm of x that feeds the next GEMM: a 5 us launch for 0.2 MB of work, 37 times per step.  Instead every
-// workgroup publishes its strip (agent-scope stores), counts itself in on its row block's counter, and the one that completes the
-// block — whichever it is: the result does not depend on it — re-reads the block's rows (agent-scope loads) and writes their f16 kperm
-// LayerNorm (skw_ln_rows: the bits k_layernorm would produce).  Nobody waits on anybody: a workgroup that is not last just exits.
-template <int MT, int NW>
-__device__ __forceinline__ void gemm16_small_ln_tail(const SkwGemmArgs& a, int my0, int w, int lane) {
-    __shared__ int s_last;
-    // C went out as agent-scope (write-through) stores: once they are acknowledged every XCD can read them, so the release is a wait,
-    // not an L2 write-back (buffer_wbl2 from 192 workgroups at once cost 20 us here)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // Two levels of counters, each on its own 256-byte line: same-address atomics from different XCDs retire one every ~60 ns, so 48
-        // strips on one counter (let alone four row blocks sharing a line) would cost more than the LayerNorm launch this replaces.
-        unsigned* base = a.ln_cnt + (size_t)blockIdx.y * SKW_LN_CNT_STRIDE;
-        const unsigned grp = blockIdx.x >> 3, ngrp = (gridDim.x + 7) >> 3, gsz = min(8u, gridDim.x - 8 * grp);
-        unsigned* sub = base + 64 * (1 + grp);
-        int last = 0;
-        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gsz) {
-            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       // re-armed for the next launch on this stream
-            if (__hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == ngrp) { __hip_atomic_store(base, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the block's rows are read back with agent-scope loads (they miss any stale line this XCD's L2 holds): no cache invalidate either
-    const int d = a.N;
-    constexpr int RPW = 16 * MT / NW;                              // rows per wave
-    static_assert((RPW >= 1 && RPW % 2 == 0) || RPW == 1, "rows per wave");
-    constexpr int R = RPW >= 4 ? 4 : RPW;
-    float wv[24], bv[24];
-#pragma unroll
-    for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; const bool in = i < d; wv[c] = in ? a.ln_w[i] : 0.0f; bv[c] = in ? a.ln_b[i] : 0.0f; }
-    for (int r0 = 0; r0 < RPW; r0 += R) {
-        float v[R][24]; bool live[R]; half_t* o16[R]; float* o32[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = my0 + w * RPW + r0 + r; live[r] = row < a.M;
-            const float* xr = (const float*)a.C + (long)(live[r] ? row : 0) * a.ldc;
-            o16[r] = a.ln_out + (long)row * d; o32[r] = nullptr;
-#pragma unroll
-            for (int c = 0; c < 24; ++c) { const int i = lane + 64 * c; v[r][c] = (i < d && live[r]) ? __hip_atomic_load(xr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
-        }
-        skw_ln_rows<R>(v, wv, bv, d, lane, live, o16, o32);
     }
 }
 
@@ -1057,16 +998,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemm16_small(SkwGemmArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) red[w][t][lane] = acc[t];
     __syncthreads();
-    const bool ln_tail = EPI == EPI_F32 && a.ln_cnt != nullptr;      // (uniform)
-    if (w >= MT && !ln_tail) return;
-    if (w < MT) {
+    if (w >= MT) return;
+    {
         const int t = w;                                   // wave t finishes row tile t
         f32x4 v = red[0][t][lane];
 #pragma unroll
         for (int s = 1; s < NW; ++s) { const f32x4 o = red[s][t][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }   // fixed order: deterministic
         if (!((a.probe & 8) && v[0] != 12345.678f)) gemm16_small_finish<EPI>(a, my0 + t * 16 + r16, n0 + 4 * g, v, pre_res, pre_po);
     }
-    if (EPI == EPI_F32) { if (ln_tail) gemm16_small_ln_tail<MT, NW>(a, my0, w, lane); }
 }
 // ------------------------------------------------------------------ decode GEMM whose A operand is LayerNorm(x), normalised in registers
 // The f16_mfma precision owes no CPU a summation order, so the LayerNorm launches in front of the decode step's QKV, cross-query and FC1 products
@@ -1188,13 +1127,12 @@ __global__ __launch_bounds__(256) void k_gemm16_small_lnA(SkwGemmArgs a) {
 template <int EPI> static bool launch_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s) {
     // Workgroup shape: its ingest is what bounds these kernels (one CU takes in ~70 GB/s).  x is f32 — twice the bytes of a ready-made f16 row — and every
     // workgroup of a row block loads and normalises the same rows, so a workgroup takes 16 rows and NT strips: NT MFMAs per normalised fragment.
-    static const int nt_wide = getenv("SKW_DEC_LNA_NT") ? atoi(getenv("SKW_DEC_LNA_NT")) : 4;      // N >= 2048: the QKV and FC1 products
-    static const int nt_narrow = getenv("SKW_DEC_LNA_NT_NARROW") ? atoi(getenv("SKW_DEC_LNA_NT_NARROW")) : 1;   // the cross-attention query product
-    const int nkw = a.K >> 7, nt = a.N >= 2048 ? nt_wide : nt_narrow;
+    // four strips for the QKV and FC1 products (N >= 2048), one for the cross-attention query (measured: profiles/r03b/r03b_lnfold_v*.txt, r04i)
+    const int nkw = a.K >> 7, nt = a.N >= 2048 ? 4 : 1;
     const dim3 block(256);
 #define SKW_LNA(NKWV, NTV) do { hipLaunchKernelGGL((k_gemm16_small_lnA<EPI, 1, NKWV, NTV>), dim3((a.N + 16 * NTV - 1) / (16 * NTV), (a.M + 15) / 16), block, 0, s, a); return true; } while (0)
-    if (nkw <= 6) { if (nt == 4) SKW_LNA(6, 4); if (nt == 2) SKW_LNA(6, 2); SKW_LNA(6, 1); }
-    if (nkw <= 12) { if (nt >= 2) SKW_LNA(12, 2); SKW_LNA(12, 1); }
+    if (nkw <= 6) { if (nt == 4) SKW_LNA(6, 4); SKW_LNA(6, 1); }
+    if (nkw <= 12) { if (nt == 4) SKW_LNA(12, 2); SKW_LNA(12, 1); }
 #undef SKW_LNA
     return false;
 }
@@ -1204,115 +1142,6 @@ bool skw_gemm16_small_lnA(const SkwGemmArgs& a, hipStream_t s) {
         case EPI_F16_PLAIN: return launch_gemm16_small_lnA<EPI_F16_PLAIN>(a, s);
         case EPI_GELU_F16_KPERM: return launch_gemm16_small_lnA<EPI_GELU_F16_KPERM>(a, s);
         case EPI_DEC_QKV: return launch_gemm16_small_lnA<EPI_DEC_QKV>(a, s);
-        default: return false;
-    }
-}
-
-// ------------------------------------------------------------------ decode GEMM with the LayerNorm that feeds it folded in
-// C = LN(x) . W^T for a 16-row block: the workgroup normalises its 16 rows itself (wave w takes rows 4w .. 4w+3 with exactly the
-// arithmetic of k_layernorm: f64 statistics, then scale, gain, bias, f16 rounding) into an LDS image in kperm order, and the four
-// waves then take their K quarter's fragments from LDS.  Every column strip repeats the normalisation of its rows (49 KB of x per
-// workgroup instead of 25 KB of ready-made f16), which costs ~0.7 us inside the kernel and removes a 5 us LayerNorm launch plus a
-// kernel boundary from the serial chain of a decode step — 36 times per step.
-__device__ __forceinline__ double wave_sum_f64_(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm16_small_ln(SkwGemmArgs a) {
-    constexpr bool PERM = (EPI == EPI_GELU_F16_KPERM);
-    constexpr int RD = 12;                                      // K = d <= 1536: a wave's whole K quarter of W is in flight at once
-    __shared__ __attribute__((aligned(16))) half_t ya[16 * 1536];
-    __shared__ f32x4 gb[2 * 384];                               // LayerNorm gain | bias
-    __shared__ f32x4 red[4][64];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 16, my0 = blockIdx.y * 16;
-    const int r16 = lane & 15, g = lane >> 4, d = a.K;
-    const int nkw = (d >> 5) >> 2, kb_lo = w * nkw;
-    int wn = n0 + r16; if (PERM) wn = (wn & ~31) | inv_kperm32(wn & 31);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)((long)a.N * a.ldw * 2), 0x00020000);
-    const unsigned oob = 0x7fffff00u;
-    const unsigned wo = (wn < a.N) ? (unsigned)(((long)wn * a.ldw + kb_lo * 32 + g * 8) * 2) : oob;
-    u32x4 fw[RD];
-#pragma unroll
-    for (int j = 0; j < RD; ++j) fw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (j < nkw && wo != oob) ? wo + j * 64 : oob, 0, SKW_DEC_W_AUX);
-    const int em = my0 + r16, ep0 = n0 + 4 * g;                 // wave 0 finishes the tile
-    f32x4 pre_res = {0.f, 0.f, 0.f, 0.f}; long pre_po = 0;
-    if (EPI == EPI_F32 && a.res && w == 0 && em < a.M && ep0 + 3 < a.N && !(a.ldres & 3)) pre_res = *(const f32x4*)(a.res + (long)em * a.ldres + ep0);
-    if (EPI == EPI_DEC_QKV && a.pos_ptr && w == 0 && em < a.M) pre_po = (long)a.pos_ptr[(long)em * a.pos_stride] * a.n_ctx;
-    // ---- LayerNorm of the block's 16 rows -> ya (row stride d halves; 16-byte chunk c of row r sits at chunk c ^ (r & 7)).
-    // Sixteen threads per row, all rows at once; a thread takes 16-byte pieces t16, t16 + 16, ... of its row (coalesced f32x4 loads, all
-    // issued before anything waits).  Gain and bias are the same for every row: the workgroup copies them to LDS once, while the rows'
-    // statistics are being reduced.  Statistics as ggml_norm: f64 sums, mean and variance rounded to f32, then scale, gain, bias, f16;
-    // the four k of a piece land in four different kperm groups of the image (2-byte LDS writes).
-    {
-        const int lr = threadIdx.x >> 4, t16 = threadIdx.x & 15, row = my0 + lr;
-        const int npc = d >> 2;                                   // 16-byte pieces per row
-        const f32x4* xr = (const f32x4*)(a.ln_x + (long)min(row, a.M - 1) * d);
-        constexpr int PMAX = 24;                                  // d <= 1536: 384 pieces / 16 threads
-        f32x4 v[PMAX];
-#pragma unroll
-        for (int j = 0; j < PMAX; ++j) { const int pi = t16 + 16 * j; v[j] = (pi < npc) ? xr[pi] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        for (int i = threadIdx.x; i < npc; i += 256) { gb[i] = ((const f32x4*)a.ln_w)[i]; gb[npc + i] = ((const f32x4*)a.ln_b)[i]; }
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < PMAX; ++j) if (t16 + 16 * j < npc) { sum += (double)v[j][0]; sum += (double)v[j][1]; sum += (double)v[j][2]; sum += (double)v[j][3]; }
-        sum += skw_dpp_f64<0xB1>(sum); sum += skw_dpp_f64<0x4E>(sum); sum += skw_dpp_f64<0x141>(sum); sum += skw_dpp_f64<0x140>(sum);      // the 16 lanes of a row: DPP, no LDS crossbar
-        const float mean = (float)(sum / (double)d);
-        double sum2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < PMAX; ++j) if (t16 + 16 * j < npc) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float t = v[j][e] - mean; v[j][e] = t; sum2 += (double)(t * t); }
-        }
-        sum2 += skw_dpp_f64<0xB1>(sum2); sum2 += skw_dpp_f64<0x4E>(sum2); sum2 += skw_dpp_f64<0x141>(sum2); sum2 += skw_dpp_f64<0x140>(sum2);
-        const float variance = (float)(sum2 / (double)d);
-        const float scale = 1.0f / sqrtf(variance + 1e-5f);
-        __syncthreads();                                          // gain / bias are in LDS
-#pragma unroll
-        for (int j = 0; j < PMAX; ++j) {
-            const int pi = t16 + 16 * j;
-            if (pi < npc) {
-                const f32x4 g4 = gb[pi], b4 = gb[npc + pi];
-                const int k0 = pi << 2, blk = k0 >> 5, q8 = (k0 >> 2) & 7;          // k = k0 + e sits at position 8 e + q8 of its 32-block: kperm group 4 blk + e
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = v[j][e] * scale; t = t * g4[e]; t = t + b4[e];
-                    const int grp = 4 * blk + e;
-                    ya[lr * d + ((grp ^ (lr & 7)) << 3) + q8] = f2h(t);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < RD; ++j) {
-        if (j < nkw) {                                           // uniform
-            const f16x8 xa = *(const f16x8*)(ya + r16 * d + ((((kb_lo + j) * 4 + g) ^ (r16 & 7)) << 3));
-            acc = MFMA16X32(__builtin_bit_cast(f16x8, fw[j]), xa, acc);
-        }
-    }
-    red[w][lane] = acc;
-    __syncthreads();
-    if (w != 0) return;
-    f32x4 v = red[0][lane];
-#pragma unroll
-    for (int s2 = 1; s2 < 4; ++s2) { const f32x4 o = red[s2][lane]; v[0] = v[0] + o[0]; v[1] = v[1] + o[1]; v[2] = v[2] + o[2]; v[3] = v[3] + o[3]; }
-    gemm16_small_finish<EPI>(a, em, ep0, v, pre_res, pre_po);
-}
-template <int EPI> static void launch_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((k_gemm16_small_ln<EPI>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
-}
-// A = LayerNorm(a.ln_x; a.ln_w, a.ln_b) over K = d; false when the geometry is outside what it handles (the caller then runs the
-// LayerNorm kernel and a plain GEMM)
-bool skw_gemm16_small_ln(const SkwGemmArgs& a, hipStream_t s) {
-    if ((a.K & 127) || a.K > 1536 || !a.ln_x) return false;
-    switch (a.epi) {
-        case EPI_F16_PLAIN: launch_gemm16_small_ln<EPI_F16_PLAIN>(a, s); return true;
-        case EPI_GELU_F16_KPERM: launch_gemm16_small_ln<EPI_GELU_F16_KPERM>(a, s); return true;
-        case EPI_DEC_QKV: launch_gemm16_small_ln<EPI_DEC_QKV>(a, s); return true;
         default: return false;
     }
 }
@@ -1432,13 +1261,11 @@ template <int MT, int RD, int NWV> static void launch_gemm16_vocab_n(const SkwGe
 }
 template <int MT, int RD> static void launch_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
     // waves per workgroup: a workgroup walks ~12.7 strips = 6.4 strip pairs at Whisper-small's vocabulary; with four waves some take two pairs and some one
-    static const int nwv = getenv("SKW_DEC_VOCAB_WAVES") ? atoi(getenv("SKW_DEC_VOCAB_WAVES")) : 8;      // eight: 21.0 us per launch against 22.5 (tools/dec_gemm_probe.py), same arithmetic per output
-    if (nwv == 4) launch_gemm16_vocab_n<MT, RD, 4>(a, s); else launch_gemm16_vocab_n<MT, RD, 8>(a, s);
+    launch_gemm16_vocab_n<MT, RD, 8>(a, s);      // eight: 21.0 us per launch against 22.5 with four (tools/dec_gemm_probe.py), same arithmetic per output
 }
 // plain f32 output with optional bias, no residual; false when the geometry is outside what it handles
 static bool skw_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
-    static const int off = getenv("SKW_DEC_VOCAB_KERNEL") ? !atoi(getenv("SKW_DEC_VOCAB_KERNEL")) : 0;
-    if (off || a.epi != EPI_F32 || a.res || (a.K & 127) || a.K > 2048) return false;
+    if (a.epi != EPI_F32 || a.res || (a.K & 127) || a.K > 2048) return false;
     if (a.ln_x) return false;
     const int nk = a.K >> 5;
     const bool mt4 = 64 * (a.K * 2 + 16) <= 150 * 1024;                          // 64 rows of A in LDS (K <= 1024), else 32
@@ -1453,19 +1280,9 @@ static bool skw_gemm16_vocab(const SkwGemmArgs& a, hipStream_t s) {
 // Rows per workgroup: every workgroup re-reads its row block of A from L2 (the weights are the small operand here), and one CU
 // takes in only ~70 GB/s, so fewer rows per workgroup = more workgroups each loading less: 16-row blocks unless told otherwise.
 template <int EPI> static void launch_gemm16_small(const SkwGemmArgs& a, hipStream_t s) {
-    static const int mt_env = getenv("SKW_DEC_MT") ? atoi(getenv("SKW_DEC_MT")) : 1;
-    static const int mt_wide = getenv("SKW_DEC_MT_WIDE") ? atoi(getenv("SKW_DEC_MT_WIDE")) : 4;      // N in [2048, 8192): the QKV and fc1 products
-    static const int mt_vocab = getenv("SKW_DEC_MT_VOCAB") ? atoi(getenv("SKW_DEC_MT_VOCAB")) : 4;   // the logits product: thousands of strips, W read once
-    static const int nw_deep = getenv("SKW_DEC_NW_DEEP") ? atoi(getenv("SKW_DEC_NW_DEEP")) : 4;      // K >= 2048 (fc2); eight waves measured slower: a launch costs ~0.8 us per 1000 waves
-    static const int nw_env = getenv("SKW_DEC_NW") ? atoi(getenv("SKW_DEC_NW")) : 4;
-    // fc2: 24 = the whole K quarter of a wave in flight at once instead of two rounds of 12 k-blocks; measured slower (decode 167.6 vs 166.3 ms)
-    static const int rd_deep = getenv("SKW_DEC_RD_DEEP") ? atoi(getenv("SKW_DEC_RD_DEEP")) : 12;
-    const int mt = a.N >= 8192 ? mt_vocab : (a.N >= 2048 ? mt_wide : mt_env);
-    const int nw = (a.K >= 2048 ? nw_deep : nw_env) == 8 && !(a.K & 255) && mt == 1 ? 8 : 4;
-    if (mt == 4) hipLaunchKernelGGL((k_gemm16_small<EPI, 4, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL((k_gemm16_small<EPI, 2, 4>), dim3((a.N + 15) / 16, (a.M + 31) / 32), dim3(256), 0, s, a);
-    else if (nw == 8) hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 8>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(512), 0, s, a);
-    else if (EPI == EPI_F32 && rd_deep == 24 && (a.K >> 7) > 12 && (a.K >> 7) <= 24) hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 4, 24>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
+    // N >= 2048 (the QKV and FC1 products; the logits product where the vocabulary kernel does not apply): 64-row blocks, W read once per 64 rows; else 16-row blocks.
+    // Measured and lost (profiles/r02c, r03j): 32-row blocks, eight waves per strip (a launch costs ~0.8 us per 1000 waves), a wave's whole K quarter of FC2 in flight at once.
+    if (a.N >= 2048) hipLaunchKernelGGL((k_gemm16_small<EPI, 4, 4>), dim3((a.N + 15) / 16, (a.M + 63) / 64), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_gemm16_small<EPI, 1, 4>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, a);
 }
 // f16-MFMA form of skw_gemm_smallm; returns false when the geometry is outside what it handles (K % 128 != 0): the caller then

@@ -271,16 +271,14 @@ template <int EPI> static void launch_gemm_q8(const SkwGemmArgs& a, const SkwQ8A
         if (qa.form == 1) launch_gemm_q8_small<EPI, 1>(a, qa, s); else if (qa.form == 2) launch_gemm_q8_small<EPI, 2>(a, qa, s); else launch_gemm_q8_small<EPI, 3>(a, qa, s);
         return;
     }
-    static const int tw_env = getenv("SKW_Q8_TW") ? atoi(getenv("SKW_Q8_TW")) : 4;
-    static const int lds_env = getenv("SKW_Q8_LDS") ? atoi(getenv("SKW_Q8_LDS")) : 1;
-    if (lds_env && tw_env == 4 && a.M >= 1024 && !(a.N & 127) && !(a.K & 63) && !(a.M & 3)) {
+    if (skw_sw(SW_Q8_LDS) && a.M >= 1024 && !(a.N & 127) && !(a.K & 63) && !(a.M & 3)) {
         const dim3 grid(a.N / 128, (a.M + 127) / 128);
         if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 1>), grid, dim3(256), 0, s, a, qa);
         else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 2>), grid, dim3(256), 0, s, a, qa);
         else hipLaunchKernelGGL((k_gemm_q8_lds<EPI, 3>), grid, dim3(256), 0, s, a, qa);
         return;
     }
-    if (tw_env == 4 && a.M >= 1024) {
+    if (a.M >= 1024) {
         const dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
         if (qa.form == 1) hipLaunchKernelGGL((k_gemm_q8<EPI, 1, 4>), grid, dim3(256), 0, s, a, qa);
         else if (qa.form == 2) hipLaunchKernelGGL((k_gemm_q8<EPI, 2, 4>), grid, dim3(256), 0, s, a, qa);

@@ -420,8 +420,8 @@ __global__ void k_tts_istft(const float* o, int P, float* y, long n_out) {
 }
 
 // ------------------------------------------------------------------ engine
-static int g_conv_mode = [] { const char* e = getenv("SKW_TTS_CONV"); return e ? atoi(e) : 0; }();
-static int g_lstm_mode = [] { const char* e = getenv("SKW_TTS_LSTM"); return e ? atoi(e) : 0; }();      // 0 automatic, 1 one workgroup per direction, 2 H / 32 workgroups per direction
+static int g_conv_mode = 0;      // skw_tts_debug_conv_mode: 0 automatic, 1 the untiled kernel, 2 the tiled one
+static int g_lstm_mode = 0;      // skw_tts_debug_lstm_mode: 0 automatic, 1 one workgroup per direction, 2 H / 32 workgroups per direction
 extern "C" void skw_tts_debug_conv_mode(int mode) { g_conv_mode = mode; }
 extern "C" void skw_tts_debug_lstm_mode(int mode) { g_lstm_mode = mode; }
 struct skw_tts {
@@ -472,7 +472,7 @@ struct GpuBackend {
         return b;
     }
     const float* word_tab = nullptr;
-    // g_conv_mode (SKW_TTS_CONV / skw_tts_debug_conv_mode): 1 forces the untiled kernel, 2 the tiled one — both evaluate the same chain and the tests run one against the other;
+    // g_conv_mode (skw_tts_debug_conv_mode): 1 forces the untiled kernel, 2 the tiled one — both evaluate the same chain and the tests run one against the other;
     // 0 = tiled when the launch is long enough to fill tiles
     template <int MT, int NT> void launch_conv_t(const float* x, int T, int Ci, const float* wp, int Co, int Co16, const float* bias, int K, int stride, int dil,
         int pad, int To, float* out, int os, int oo) {

@@ -1,9 +1,21 @@
 """Multi-GPU sharding of the Oneshot batch path: clips are independent, so the only exchange is one
 gather of fixed-size int32 token buffers (count, n_segments, token ids padded with -1) to every rank."""
+import os
+
 import numpy as np
 
 TOKENS_PER_CLIP = 224
 ROW = 2 + TOKENS_PER_CLIP
+
+# ONE limit for every place in this repository that STARTS rank processes itself (bench.py's launch_ranks when no launcher set RANK, tests/test_gpu_dist.py):
+# the GPU pool these run on allows at most six of a user's processes on its cards at once, so a self-started job never has more ranks than that.  Ranks started
+# by a launcher (the driver's `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) are the launcher's to count: bench.py then is ONE of the
+# ranks and starts nothing.  SKW_SELF_STARTED_RANK_LIMIT overrides it on a node without that guard.
+SELF_STARTED_RANK_LIMIT = 6
+
+
+def self_started_rank_limit():
+    return int(os.environ.get("SKW_SELF_STARTED_RANK_LIMIT", SELF_STARTED_RANK_LIMIT))
 
 
 def shard_clip_ids(n_total, rank, world):

@@ -42,7 +42,8 @@ class Result(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("mel_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32), ("n_row_steps", C.c_int32)]
+                ("n_windows", C.c_int32), ("n_decode_steps", C.c_int32), ("n_tokens", C.c_int32), ("n_row_steps", C.c_int32),
+                ("decode_groups", C.c_int32), ("decode_group_rows", C.c_int32)]
 
 
 class Trace(C.Structure):
@@ -115,6 +116,14 @@ def lib():
         L.skw_debug_enable.argtypes = [C.c_int]
         L.skw_debug_get.restype = C.c_long
         L.skw_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+        L.skw_ctx_kernel_clock.argtypes = [C.c_void_p, C.c_int]
+        L.skw_ctx_kernel_clock_get.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.skw_debug_xattn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.skw_debug_switch_name.restype = C.c_char_p; L.skw_debug_switch_name.argtypes = [C.c_int]
+        L.skw_debug_switch_what.restype = C.c_char_p; L.skw_debug_switch_what.argtypes = [C.c_int]
+        L.skw_debug_switch_default.argtypes = [C.c_int]
+        L.skw_debug_switch_get.argtypes = [C.c_char_p]
+        L.skw_debug_switch_set.argtypes = [C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -173,6 +182,9 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError("skw engine: " + lib().skw_ctx_last_error(self.h).decode())
+
+    def last_error(self):
+        return lib().skw_ctx_last_error(self.h).decode()
 
     PRECISIONS = {"exact": 0, "f16_mfma": 1}
 
@@ -245,6 +257,15 @@ class Context:
                 out[name.value.decode()] = dict(count=cnt.value, ms=ms.value, flops=fl.value, bytes=by.value)
         return out
 
+    def kernel_clock(self, on=True):
+        """Arms / disarms the in-kernel launch clock of the decode step's cross attention (include/skw_engine.h, skw_ctx_kernel_clock)."""
+        self._check(lib().skw_ctx_kernel_clock(self.h, 1 if on else 0))
+
+    def kernel_clock_get(self):
+        n = C.c_long(); su = C.c_double(); sl = C.c_double(); mn = C.c_double(); mx = C.c_double(); khz = C.c_int()
+        self._check(lib().skw_ctx_kernel_clock_get(self.h, C.byref(n), C.byref(su), C.byref(sl), C.byref(mn), C.byref(mx), C.byref(khz)))
+        return dict(launches=n.value, sum_us=su.value, sum_live_rows=sl.value, min_us=mn.value, max_us=mx.value, clock_khz=khz.value)
+
     def stream(self):
         return lib().skw_ctx_stream(self.h)
 
@@ -311,6 +332,29 @@ class Context:
         if self.h:
             lib().skw_ctx_free(self.h)
             self.h = None
+
+
+def switches():
+    """The engine's switchboard (skw_kernels.h SkwSw / skw_engine.hip g_sw_defs): {name: (default, current, what)}.  No GPU needed."""
+    L = lib()
+    return {L.skw_debug_switch_name(i).decode(): (L.skw_debug_switch_default(i), L.skw_debug_switch_get(L.skw_debug_switch_name(i)), L.skw_debug_switch_what(i).decode())
+            for i in range(L.skw_debug_switch_count())}
+
+
+class switch:
+    """`with engine.switch("GEMM16W", 0): ...` — flips one row of the switchboard in-process (what the environment variable SKW_GEMM16W=0 selects at start-up) and restores it."""
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.old = lib().skw_debug_switch_get(self.name)
+        if lib().skw_debug_switch_set(self.name, self.value) != 0:
+            raise KeyError("no such switch: %s" % self.name.decode())
+        return self
+
+    def __exit__(self, *exc):
+        lib().skw_debug_switch_set(self.name, self.old)
+        return False
 
 
 def debug_enable(on=True):

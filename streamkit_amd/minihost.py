@@ -1,4 +1,4 @@
-"""ctypes binding of libskw_minihost.so (C++ stand-in for the StreamKit host side of the plugin boundary)."""
+"""ctypes binding of libskw_minihost.so (C++ stand-in for the StreamKit host side of the plugin boundary): what tests, tools and bench.py's plugin-path legs drive the plugins through."""
 import ctypes as C
 import json
 import os

@@ -80,6 +80,12 @@ def quantized_model(size, kind, seed=1234):
 
 
 @pytest.fixture(scope="session")
+def eng():
+    from streamkit_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="session")
 def built():
     _ensure_built()
     return ROOT

@@ -33,8 +33,9 @@ def main():
     ids = skd.shard_clip_ids(a.clips_per_rank * world, rank, world)
     p = ctx.default_params(); p.suppress_nst = 1
     res = ctx.full_batch([synth.clip(c, int(16000 * a.seconds)) for c in ids], p)
-    table = skd.gather_tokens(skd.pack_tokens(res), world, device=torch.device("cuda", dev) if (a.backend == "nccl" and world > 1) else None)
-    json.dump({"rank": rank, "device": dev, "clip_ids": ids, "table": {str(k): v for k, v in table.items()}}, open(a.out, "w"))
+    rows = skd.pack_tokens(res)
+    table = skd.gather_tokens(rows, world, device=torch.device("cuda", dev) if (a.backend == "nccl" and world > 1) else None)
+    json.dump({"rank": rank, "device": dev, "clip_ids": ids, "gather_shape": list(rows.shape), "gather_dtype": str(rows.dtype), "table": {str(k): v for k, v in table.items()}}, open(a.out, "w"))
     if world > 1:
         dist.destroy_process_group()
 

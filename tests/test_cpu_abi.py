@@ -6,7 +6,7 @@ import re
 
 import pytest
 
-import minihost
+from streamkit_amd import minihost
 from conftest import HAVE_GPU, ROOT
 
 

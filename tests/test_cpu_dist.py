@@ -59,3 +59,16 @@ def test_bench_launcher_refuses_more_ranks_than_devices():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 2 but only" in r.stderr and "{" not in r.stdout
+
+
+def test_one_rank_limit_for_everything_that_starts_ranks_itself():
+    """bench.py's own launcher and the RCCL test share ONE limit on self-started rank processes (streamkit_amd/dist.py): `--gpus 8` without a launcher is refused
+    with a pointer to the driver's torchrun line, before anything counts devices; under a launcher (RANK set) bench.py is one of the ranks and the limit does not apply."""
+    import subprocess
+    from streamkit_amd import dist as skd
+    assert skd.self_started_rank_limit() == skd.SELF_STARTED_RANK_LIMIT == 6
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SKW_SELF_STARTED_RANK_LIMIT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "self-started jobs are limited to 6" in r.stderr and "torch.distributed.run" in r.stderr and "{" not in r.stdout
+    src = open(os.path.join(ROOT, "tests", "test_gpu_dist.py")).read()
+    assert "self_started_rank_limit()" in src and "min(R, 6)" not in src

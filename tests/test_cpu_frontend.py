@@ -5,7 +5,7 @@ import json
 import numpy as np
 import pytest
 
-import minihost
+from streamkit_amd import minihost
 import oracle_lib
 
 GOLD = json.load(open(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "segmentation_goldens.json")))

@@ -10,8 +10,7 @@ import numpy as np
 import pytest
 
 import kokoro_lib
-import minihost
-
+from streamkit_amd import minihost
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KOKORO = os.path.join(ROOT, "streamkit_amd", "libkokoro.so")
 

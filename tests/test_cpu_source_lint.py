@@ -73,3 +73,33 @@ def test_workspace_table_is_one_buffer_per_line():
         assert need in names, need
     # and skw_ctx_create / the entry points verify the table by name
     assert "ws_first_null(c)" in src and src.count("WS_READY(c);") >= 5
+
+
+def test_one_switchboard_one_getenv():
+    """the product used to ship ~50 `getenv` switches, most of them measured-and-lost experiments no parity test had seen.  Now: ONE table
+    (skw_engine.hip g_sw_defs), ONE getenv in the engine library (the table's loader) plus the reference's own KOKORO_EXECUTION_PROVIDER (config.rs:55-58), and every row of
+    the table has a case in tests/test_gpu_switches.py.  No GPU needed: the table is read through the library's debug entry points."""
+    import importlib.util
+    import sys
+    calls = []
+    for p in SOURCES:
+        if os.sep + "oracle" + os.sep in p:
+            continue
+        for n, line in enumerate(open(p, encoding="utf-8").read().split("\n"), 1):
+            c = _comment_start(line)
+            code = line if c < 0 else line[:c]
+            if "getenv(" in code:
+                calls.append((os.path.basename(p), n, code.strip()))
+    assert len(calls) == 2, calls
+    assert any(f == "skw_engine.hip" and "g_sw_defs[i].name" in code for f, _, code in calls) and any("KOKORO_EXECUTION_PROVIDER" in code for _, _, code in calls), calls
+    sys.path.insert(0, ROOT)
+    from streamkit_amd import engine
+    table = engine.switches()
+    assert all(cur == dflt for dflt, cur, _ in table.values()) or any(k.startswith("SKW_") for k in os.environ)
+    spec = importlib.util.spec_from_file_location("_sw_cases", os.path.join(ROOT, "tests", "test_gpu_switches.py"))
+    src = open(spec.origin).read()
+    names = set(re.findall(r'^\s*\("([A-Z0-9_]+)", -?\d+, "(?:same_bits|tolerance|quant|resample)"\)', src, flags=re.M)) | set(re.findall(r'\("([A-Z0-9_]+)", -?\d+, "(?:same_bits|tolerance|quant|resample)"\)', src))
+    assert names == set(table), (sorted(names), sorted(table))
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for name in table:
+        assert "SKW_" + name in readme, "README.md does not document SKW_" + name

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-import minihost
+from streamkit_amd import minihost
 from oracle_lib import OracleModel
 from streamkit_amd import synth
 
@@ -55,6 +55,20 @@ def test_sharded_oneshot_two_ranks_on_one_gpu(tiny_model_path, tmp_path):
     _check_tables(two, one, om, 8, 12.0)
 
 
+def test_config2_per_rank_shape_two_ranks_on_one_gpu(small_model_path, tmp_path):
+    """BASELINE configs[2] at its real per-rank shape on the one GPU a test box has: Whisper-small, 64 clips of 30 s PER RANK, two fresh rank processes sharing GPU 0
+    (gloo for the gather: RCCL needs a device per rank), clip c -> rank c mod 2, the real int32 [64 x 226] token buffers through all_gather.  Every rank must end up with
+    all 128 transcripts; each equals what ONE rank computes alone over the same 128 clips (exact precision), and a sample (first clip of each rank + the last clip) equals
+    the CPU oracle.  What differs from the 8-GPU run is the transport of the gather and the number of ranks, not the per-rank work or the buffers."""
+    om = OracleModel(small_model_path)
+    two = _run_ranks(2, small_model_path, tmp_path, "gloo", True, clips_per_rank=64, seconds=30.0)
+    one = _run_ranks(1, small_model_path, tmp_path, "gloo", True, clips_per_rank=128, seconds=30.0)[0]
+    two = sorted(two, key=lambda r: r["rank"])
+    assert [r["clip_ids"] for r in two] == [list(range(0, 128, 2)), list(range(1, 128, 2))]
+    assert all(r["gather_shape"] == [64, 226] and r["gather_dtype"] == "int32" for r in two)
+    _check_tables(two, one, om, 128, 30.0, oracle_clips=[0, 1, 127])
+
+
 def test_sharded_oneshot_rccl_all_visible_gpus(small_model_path, tmp_path):
     """BASELINE configs[2] as written, on every visible GPU: Whisper-small, 64 clips of 30 s per rank (R x 64 clips, clip c -> rank c mod R), one rank per GPU, NCCL (= RCCL)
     all_gather of the token buffers.  Every rank must hold every clip's transcript; all of them equal what ONE rank computes alone in the exact precision over the same
@@ -63,7 +77,8 @@ def test_sharded_oneshot_rccl_all_visible_gpus(small_model_path, tmp_path):
     R = torch.cuda.device_count()
     if R < 2:
         pytest.skip("needs >= 2 GPUs (the driver's 8-GPU node); the one-GPU rehearsal above covers the rank logic")
-    R = min(R, 6)                                                                 # process guard of the GPU pool: at most 6 processes on the cards at once
+    from streamkit_amd import dist as skd
+    R = min(R, skd.self_started_rank_limit())                                     # the one limit on self-started ranks (bench.py's launch_ranks applies the same one)
     om = OracleModel(small_model_path)
     many = _run_ranks(R, small_model_path, tmp_path, "nccl", False, clips_per_rank=64, seconds=30.0)
     one = _run_ranks(1, small_model_path, tmp_path, "nccl", False, clips_per_rank=64 * R, seconds=30.0)[0]

@@ -349,18 +349,14 @@ def test_weight_image_is_the_documented_permutation(eng, N, K, perm):
 
 @pytest.mark.parametrize("n_rows", [20, 24, 31])
 def test_decode_row_groups_do_not_share_a_fragment_tile(eng, tiny_model_path, n_rows):
-    """SKW_DECODE_GROUPS=2 with a batch of 16 .. 31 rows: the f16_mfma step hands its attention and FC1 outputs on as fragment-order images,
+    """Switch DECODE_GROUPS = 2 with a batch of 16 .. 31 rows: the f16_mfma step hands its attention and FC1 outputs on as fragment-order images,
     which spread a group's rows over whole 16-row tiles — so groups are cut at multiples of 16 rows.  A row's arithmetic does not depend on its batch
     mates: two groups must give the transcripts of one, bit for bit (tokens and log-probs)."""
-    import os
     pcms = [synth.clip(100 + c, 16000 * (4 + c % 5)) for c in range(n_rows)]
     out = {}
     for groups in ("1", "2"):
-        os.environ["SKW_DECODE_GROUPS"] = groups
-        try:
+        with eng.switch("DECODE_GROUPS", int(groups)):      # read at context creation
             m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=32, max_samples=16000 * 10)
-        finally:
-            del os.environ["SKW_DECODE_GROUPS"]
         ctx.set_precision("f16_mfma")
         out[groups] = ctx.full_batch(pcms)
         ctx.close(); m.close()

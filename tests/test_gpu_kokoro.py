@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import kokoro_lib
-import minihost
+from streamkit_amd import minihost
 from streamkit_amd import synth
 
 pytestmark = pytest.mark.gpu

@@ -112,38 +112,6 @@ def test_decoder_logits_bit_exact_other_widths(eng, size):
     assert [t[0] for t in rg["tokens"]] == [t[0] for t in ro["tokens"]] and rg["min_margin"] == ro["min_margin"]
 
 
-_FUSEQ_CHILD = r"""
-import sys
-import numpy as np
-from conftest import synth_model
-from oracle_lib import OracleModel
-from streamkit_amd import engine, synth
-for size in sys.argv[1:]:
-    path = synth_model(size)
-    m = engine.Model(path); ctx = engine.Context(m, max_batch=4, max_samples=16000 * 32); om = OracleModel(path)
-    pcm = synth.clip(5, 16000 * 9)
-    mel_o, _ = om.log_mel(pcm); _, ck, cv = om.encode(mel_o); ctx.encode(pcm)
-    toks = [50258, 50259, 50359, 50364, 1234, 777]
-    a = np.ascontiguousarray(ctx.decode_logits(toks), np.float32); b = np.ascontiguousarray(om.decoder(ck, cv).step(toks, 0), np.float32)
-    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), size
-    pcms = [pcm, synth.clip(6, 16000 * 4), synth.clip(7, 16000 * 11)]
-    for rg, x in zip(ctx.full_batch(pcms), pcms):
-        ro = om.full(x)
-        assert [t[0] for t in rg["tokens"]] == [t[0] for t in ro["tokens"]] and rg["min_margin"] == ro["min_margin"], size
-print("fuseq ok")
-"""
-
-
-def test_fused_query_cross_attention_matches_oracle(built):
-    """The opt-in one-launch form of LayerNorm + query projection + cross attention (SKW_XATTN_FUSEQ=1, read once per process: hence a child
-    process) at every prologue shape — micro (one half step per K segment), tiny (one and a half), w512 (2), w1024 (4), w1280 (5); small (3) is
-    what tools/ and bench.py run under the same switch — logits bit for bit, tokens and margins equal to the oracle's."""
-    import subprocess, sys
-    env = dict(os.environ, SKW_XATTN_FUSEQ="1", PYTHONPATH=os.pathsep.join([os.path.dirname(HERE), HERE, os.environ.get("PYTHONPATH", "")]))
-    r = subprocess.run([sys.executable, "-c", _FUSEQ_CHILD, "micro", "tiny", "w512", "w1024", "w1280"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "fuseq ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 CLIPS = [(0, 480000), (1, 480000), (2, 16000 * 7 + 123), (3, 480768), (4, 16000 * 2), (5, 1500), (6, 16000 * 12), (7, 4800), (8, 14400), (9, 488000)]
 
 

@@ -6,7 +6,7 @@ import threading
 import numpy as np
 import pytest
 
-import minihost
+from streamkit_amd import minihost
 import oracle_lib
 from oracle_lib import OracleModel
 from streamkit_amd import synth

@@ -3,7 +3,7 @@ through the engine C ABI and through the `resampler` native plugin driven by the
 import numpy as np
 import pytest
 
-import minihost
+from streamkit_amd import minihost
 import oracle_lib
 
 pytestmark = pytest.mark.gpu

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--precision", default="f16_mfma", choices=["exact", "f16_mfma"])
     a = ap.parse_args()
     import torch  # noqa: F401  (libamdhip64 first, as bench.py does)
-    import minihost
+    from streamkit_amd import minihost
     from conftest import synth_model
     from streamkit_amd import synth
     path = synth_model(a.size)
