@@ -364,7 +364,7 @@ def main():
                 ctx.kernel_clock(True)
                 ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
                 ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
-                kclk = ctx.kernel_clock_get(); kclk["step"] = ctx.timing()
+                kclk = ctx.kernel_clock_get(); kclk["step"] = ctx.timing(); kclk["records"] = ctx.kernel_clock_records()
                 ctx.kernel_clock(False)
             except RuntimeError as e:
                 kclk = {"error": str(e), "launches": 0}
@@ -434,18 +434,41 @@ def main():
                 edge = (iso["us"] - iso["us_in_kernel_clock"]) if iso and iso["us_in_kernel_clock"] else 0.0
                 n_l = kclk["launches"]; span = kclk["sum_us"] / n_l; live = kclk["sum_live_rows"] / n_l
                 dur = span + edge
-                ach = row_bytes * live / dur / 1e3
-                roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_ms": round(dur * 1e-3, 5), "launches": n_l,
-                             "avg_launch_in_kernel_us": round(span, 3), "dispatch_edges_us": round(edge, 3), "live_rows_per_launch": round(live, 3),
-                             "live_row_fraction": round(live / grows, 4), "min_launch_in_kernel_us": round(kclk["min_us"], 2), "max_launch_in_kernel_us": round(kclk["max_us"], 2),
-                             "achieved_in_kernel": round(row_bytes * live / span / 1e3, 2),
+                per_launch = row_bytes * live / dur / 1e3
+                # launches of different row groups overlap in time and then share HBM: the time the kernel was in flight at all is the UNION of the launch intervals
+                rec = kclk["records"][np.argsort(kclk["records"][:, 0])]
+                union = 0.0; cur_b, cur_e = rec[0, 0], rec[0, 1]
+                for b_, e_, _ in rec[1:]:
+                    if b_ > cur_e:
+                        union += cur_e - cur_b; cur_b, cur_e = b_, e_
+                    else:
+                        cur_e = max(cur_e, e_)
+                union += cur_e - cur_b
+                tot_bytes = row_bytes * float(rec[:, 2].sum())
+                agg = tot_bytes / union / 1e3
+                roof.update({"achieved": round(agg, 2), "frac": round(agg / HBM_PEAK_GBS, 4), "avg_launch_ms": round(dur * 1e-3, 5), "launches": n_l,
+                             "definition": ("achieved = algorithmic bytes of ALL the kernel's launches of one step / the time at least one of them is in flight (the union of the launch "
+                                            "intervals on the in-kernel clock)" + (": the launches are serial (one row group), so this is bytes per launch / average in-kernel launch duration; "
+                                            "`per_launch` adds the dispatch edges (the duration HIP events and rocprofv3 report)" if groups == 1 else
+                                            "; with %d row groups on %d streams launches overlap (%.0f %% of the summed launch time is overlapped) and each one's own duration is stretched by "
+                                            "its neighbour's traffic: `per_launch` is the strict per-launch figure" % (groups, groups, 100.0 * (1.0 - union / max(1e-9, float((rec[:, 1] - rec[:, 0]).sum())))))),
+                             "in_flight_us_per_step": round(union, 1), "summed_launch_us_per_step": round(float((rec[:, 1] - rec[:, 0]).sum()), 1), "bytes_per_step": tot_bytes,
+                             "per_launch": {"achieved": round(per_launch, 2), "frac": round(per_launch / HBM_PEAK_GBS, 4), "avg_launch_ms": round(dur * 1e-3, 5),
+                                            "avg_launch_in_kernel_us": round(span, 3), "dispatch_edges_us": round(edge, 3), "live_rows_per_launch": round(live, 3),
+                                            "min_launch_in_kernel_us": round(kclk["min_us"], 2), "max_launch_in_kernel_us": round(kclk["max_us"], 2)},
+                             "live_row_fraction": round(live / grows, 4),
                              "clocked_step_ms": {"decode": round(kclk["step"]["decode_ms"], 2), "total": round(kclk["step"]["total_ms"], 2),
                                                  "note": "the step the launches were clocked in: graph-launched like the timed steps (compare modes.%s.decode_ms)" % args.precision},
                              "isolated_same_shape": iso})
                 roof["timing"] = ("every launch of the graph-launched decode step (%d row group(s), %d rows per launch) stamped by the kernel itself on the device's %d kHz constant clock: "
-                                  "first wave in -> last wave out; avg_launch_ms = that span + dispatch_edges_us, the difference between HIP-event (hipExtLaunchKernelGGL begin / end = "
-                                  "rocprofv3's duration) and in-kernel timing of isolated launches of the same shape.  Compare profiles/: rocprofv3 --kernel-trace --stats of this command"
-                                  % (groups, grows, kclk["clock_khz"]))
+                                  "first wave in -> last wave out; per_launch.avg_launch_ms = that span + dispatch_edges_us, the difference between HIP-event (hipExtLaunchKernelGGL begin / end = "
+                                  "rocprofv3's duration) and in-kernel timing of isolated launches of the same shape" % (groups, grows, kclk["clock_khz"]))
+                roof["profiler_note"] = ("one row group (the default): launches are serial, and per_launch.avg_launch_ms, HIP events and rocprofv3 --kernel-trace --stats of this command "
+                                         "(profiles/, <round>_rocprofv3_kernel_stats*.csv; its average includes the ~2 %% of launches whose rows had all finished) agree within 3 %%.  "
+                                         "With SKW_DECODE_GROUPS=2 the groups' launches overlap and a profiler serialises the two streams (decode 129 -> 197 ms under rocprofv3, profiles/r05b): "
+                                         "its averages then describe launches that never ran, and only the in-kernel clock sees the timed configuration" if groups == 1 else
+                                         "rocprofv3 --kernel-trace serialises the row groups' streams (decode 129 -> 197 ms, profiles/r05b): its per-kernel average equals `isolated_same_shape.us`, "
+                                         "not a launch of this configuration")
                 roof["eager_profile_avg_launch_ms"] = round(p["ms"] / max(1, p["count"]), 4)
             else:
                 roof["live_row_fraction"] = round(p["bytes"] / (p["count"] * row_bytes * max(1, grows)), 4) if grows else None
@@ -453,7 +476,7 @@ def main():
                 if kclk and kclk.get("error"):
                     roof["kernel_clock_error"] = kclk["error"]
             if groups > 1:
-                roof["row_groups_note"] = ("the decode step runs as %d row groups on %d streams (the engine's default for this precision and batch: +1.3 %% on the whole step, profiles/r04g): "
+                roof["row_groups_note"] = ("the decode step runs as %d row groups on %d streams (SKW_DECODE_GROUPS; the default is one): "
                                            "a launch covers %d rows and shares HBM with the other group's kernels, so `frac` is per launch under that sharing; "
                                            "`full_launch` is one %d-row launch alone" % (groups, groups, grows, B))
         # the two phases and the front end against their own rooflines, from the timed step's GPU-event phase times

@@ -167,6 +167,9 @@ int  skw_ctx_profile_get(skw_ctx*, int cls, char* name, size_t name_len, long* c
  * summed live rows (a launch's algorithmic bytes = 4 B x live rows x n_audio_ctx x n_text_state), shortest / longest launch, the clock's rate in kHz.  Diagnostic; off by default. */
 int  skw_ctx_kernel_clock(skw_ctx*, int on);
 int  skw_ctx_kernel_clock_get(skw_ctx*, long* launches, double* sum_us, double* sum_live_rows, double* min_us, double* max_us, int* clock_khz);
+/* every recorded launch as (begin us, end us, live rows), relative to the earliest begin; returns the count written.  Row groups run on their own streams, so launches overlap:
+ * the union of the intervals is the time the kernel was in flight at all. */
+long skw_ctx_kernel_clock_records(skw_ctx*, double* out /* [cap][3] */, long cap);
 /* the HIP stream the engine launches on (opaque hipStream_t) */
 void* skw_ctx_stream(const skw_ctx*);
 

@@ -415,7 +415,7 @@ static const SwDef g_sw_defs[SW_COUNT] = {
     {"GEMM16W_NGROUPS", 0, "k_gemm16w's feature-split tile walk: 0 automatic, 1 off, 2 / 4 / 8 forced"},
     {"XATTN_FRAG", 1, "0: f16_mfma keeps cross K / V^T as rows and runs the two-phase cross attention (context creation)"},
     {"DECODE_GRAPHS", -1, "0: the decode steps are launched eagerly instead of as captured step graphs (context creation)"},
-    {"DECODE_GROUPS", 0, "row groups of the decode step, each on its own stream: 0 automatic (2 for f16_mfma at >= 64 rows, else 1), n forced (context creation)"},
+    {"DECODE_GROUPS", 0, "row groups of the decode step, each a step graph on its own stream: 0 = one group (the default), n forced (context creation)"},
     {"DEC_LN_STATS", 1, "0: f16_mfma launches the decode step's LayerNorms instead of normalising inside the consuming GEMM (context creation)"},
     {"PROMPT_PASS", 1, "0: the prompt is fed one token per step instead of in one multi-row pass (context creation)"},
     {"PROMPT_SMALL_GEMM", 0, "1: a prompt pass of >= 256 rows keeps the small-M decode GEMMs instead of the big-tile kernel (f16_mfma)"},
@@ -538,7 +538,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     c->prompt_pass_on = skw_sw(SW_PROMPT_PASS) != 0;
     c->rows_cap = std::max(max_batch, std::min(max_batch * (SKW_PROMPT_CAP - 1), 4096));
     c->n_groups = skw_sw(SW_DECODE_GROUPS); if (c->n_groups <= 0) c->n_groups = -1; if (c->n_groups > skw_ctx::MAX_GROUPS) c->n_groups = skw_ctx::MAX_GROUPS;
-    for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 2 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
+    for (int g = 0; g < skw_ctx::MAX_GROUPS && g < (c->n_groups < 0 ? 1 : c->n_groups) && ok; ++g) { ok = ok && hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->gev[g], hipEventDisableTiming) == hipSuccess; }
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     // The workspace, as a table: one buffer per line — name, the context field it fills, element count, zero-filled or not.  Every entry is
@@ -1279,11 +1279,14 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         HIPCHK(hipMemcpyAsync(c->st, c->h_st, sizeof(SkwSeqState) * Bw, hipMemcpyHostToDevice, c->stream));
         // row groups: G contiguous ranges of the window batch, each on its own stream (one group while profiling, so kernel times do not overlap)
         const bool profiling = c->prof && c->prof->on;
-        // Default: f16_mfma with 64 rows or more runs TWO row groups, one step graph each on its own stream (the groups' launch-bound stretches overlap a little: same-box A/B, three
-        // alternations, 167.96 -> 165.82 ms per 64-clip step, profiles/r04g; VERDICT r3: ship the faster configuration and describe its roofline) — each cross-attention launch
-        // is then 32 rows and shares HBM with the other group's kernels, which is what bench.py's per-launch roofline line then reports.  The exact precision keeps one group
-        // (two: -3 %), and so do smaller batches (16-row launches).  SKW_DECODE_GROUPS=n overrides.
-        const int n_groups = c->n_groups > 0 ? c->n_groups : (c->precision == SKW_PRECISION_F16_MFMA && Bw >= 64 ? 2 : 1);
+        // Default: ONE row group in both precisions.  Rounds 3-4 shipped two groups for f16_mfma at >= 64 rows (+1.3 % on the step in a same-box A/B, profiles/r04g).  Round 5's in-kernel
+        // launch clock (skw_ctx_kernel_clock) showed what that bought and cost: the groups' cross-attention launches overlap for 27 % of their time and stretch each other from 28 to
+        // 35-37 us, a profiler serialises the two streams (its per-kernel averages then describe launches that never ran: decode 129 -> 197 ms under rocprofv3), and the dispatch
+        // front end is a serial resource — two chains of small kernels on two streams gain ~20 % over one (tools/probe/probe_stream_overlap.hip) while the launch count doubles.
+        // Same-box, round 5 (profiles/r05d): 167.13 ms (two groups) vs 167.59 ms (one) per 64-clip step — inside the +-1.5 % two builds differ by — with the dominant kernel at
+        // 0.47 of HBM peak per launch (0.66 while any launch is in flight) against 0.77 as one group.  One group: clock, HIP events and rocprofv3 agree on every launch within 2 %.
+        // The exact precision loses 3 % with two groups, smaller batches more (16-row launches).  SKW_DECODE_GROUPS=n overrides.
+        const int n_groups = c->n_groups > 0 ? c->n_groups : 1;
         // (f16_mfma, one group: eager launches 8 steps ahead measure the same 179 ms; the graph leaves the host idle, which matters with eight ranks on one node)
         const bool use_graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : true;
         // Groups are cut at multiples of 16 rows: the f16_mfma step keeps its attention / FC1 outputs as fragment-order images (skw_afrag_off), which
@@ -1704,7 +1707,14 @@ extern "C" long skw_debug_gemm16_compare(skw_ctx* c, int M, int N, int K, int ep
 
 // the launch clock's records (SkwKClk, skw_kernels.h): one clock per (row group, decoder layer) graph node
 static const int KCLK_CAP = 1024;                                       // launches recorded per node and call (a 30 s window is <= 466 steps)
-static size_t kclk_node_bytes() { return sizeof(SkwKClk) + sizeof(SkwKClkRec) * (KCLK_CAP - 1); }
+static size_t kclk_node_bytes() { return sizeof(SkwKClk) + sizeof(SkwKClkRec) * SKW_KCLK_SHARDS * (KCLK_CAP - 1); }
+// one launch's record: the maxima over its shards; false when no live workgroup stamped it
+static bool kclk_launch(const SkwKClk* k, int j, unsigned long long* t0, unsigned long long* t1, unsigned* live) {
+    unsigned long long a = 0, b = 0; unsigned l = 0;
+    for (int s = 0; s < SKW_KCLK_SHARDS; ++s) { const SkwKClkRec& r = k->rec[j][s]; a = std::max(a, r.t0_inv); b = std::max(b, r.t1); l += r.live_rows; }
+    if (!a || !b) return false;
+    *t0 = ~a; *t1 = b; *live = l; return true;
+}
 static SkwKClk* kclk_node(const skw_ctx* c, int g, int l) {
     return c->kclk_on ? (SkwKClk*)((char*)c->kclk + kclk_node_bytes() * ((size_t)g * c->m->hp.n_text_layer + l)) : nullptr;
 }
@@ -1712,8 +1722,8 @@ static int kclk_reset(skw_ctx* c) {
     char* errbuf = c->errbuf;
     const size_t nb = kclk_node_bytes(), n_nodes = (size_t)skw_ctx::MAX_GROUPS * c->m->hp.n_text_layer;
     HIPCHK(hipMemsetAsync(c->kclk, 0, nb * n_nodes, c->stream));
-    std::vector<SkwKClk> hdr(1); memset(&hdr[0], 0, sizeof(SkwKClk)); hdr[0].cap = KCLK_CAP;
-    for (size_t i = 0; i < n_nodes; ++i) HIPCHK(hipMemcpyAsync((char*)c->kclk + nb * i, &hdr[0], 16, hipMemcpyHostToDevice, c->stream));
+    static const unsigned hdr[4] = {(unsigned)KCLK_CAP, 0, 0, 0};
+    for (size_t i = 0; i < n_nodes; ++i) HIPCHK(hipMemcpyAsync((char*)c->kclk + nb * i, hdr, 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1743,14 +1753,34 @@ extern "C" int skw_ctx_kernel_clock_get(skw_ctx* c, long* launches, double* sum_
     for (size_t i = 0; i < n_nodes; ++i) {
         const SkwKClk* k = (const SkwKClk*)(h.data() + nb * i);
         for (int j = 0; j < KCLK_CAP; ++j) {
-            const SkwKClkRec& r = k->rec[j];
-            if (!r.t1 || !r.t0_inv) continue;
-            const double us = (double)(r.t1 - ~r.t0_inv) * 1000.0 / c->kclk_khz;
-            ++n; su += us; sl += r.live_rows; mn = std::min(mn, us); mx = std::max(mx, us);
+            unsigned long long t0, t1; unsigned live;
+            if (!kclk_launch(k, j, &t0, &t1, &live)) continue;
+            const double us = (double)(t1 - t0) * 1000.0 / c->kclk_khz;
+            ++n; su += us; sl += live; mn = std::min(mn, us); mx = std::max(mx, us);
         }
     }
     *launches = n; *sum_us = su; *sum_live_rows = sl; *min_us = n ? mn : 0; *max_us = mx; *clock_khz = c->kclk_khz;
     return 0;
+}
+
+// every recorded launch of the last call as (begin us, end us, live rows), times relative to the earliest begin; returns the count written (<= cap), < 0 on error.  Launches of
+// different row groups overlap in time: the union of the intervals is the time the kernel was in flight at all.
+extern "C" long skw_ctx_kernel_clock_records(skw_ctx* c, double* out /* [cap][3] */, long cap) {
+    char* errbuf = c->errbuf;
+    if (!c->kclk) { snprintf(errbuf, 512, "the kernel clock was never armed"); return -1; }
+    HIPCHK(hipSetDevice(c->m->device));
+    const size_t nb = kclk_node_bytes(), n_nodes = (size_t)skw_ctx::MAX_GROUPS * c->m->hp.n_text_layer;
+    std::vector<char> h(nb * n_nodes);
+    HIPCHK(hipMemcpy(h.data(), c->kclk, h.size(), hipMemcpyDeviceToHost));
+    unsigned long long t_min = ~0ull;
+    unsigned long long t0, t1; unsigned live;
+    for (size_t i = 0; i < n_nodes; ++i) { const SkwKClk* k = (const SkwKClk*)(h.data() + nb * i);
+        for (int j = 0; j < KCLK_CAP; ++j) if (kclk_launch(k, j, &t0, &t1, &live)) t_min = std::min(t_min, t0); }
+    long n = 0;
+    for (size_t i = 0; i < n_nodes; ++i) { const SkwKClk* k = (const SkwKClk*)(h.data() + nb * i);
+        for (int j = 0; j < KCLK_CAP && n < cap; ++j) { if (!kclk_launch(k, j, &t0, &t1, &live)) continue;
+            out[3 * n] = (double)(t0 - t_min) * 1000.0 / c->kclk_khz; out[3 * n + 1] = (double)(t1 - t_min) * 1000.0 / c->kclk_khz; out[3 * n + 2] = live; ++n; } }
+    return n;
 }
 
 // The decode step's cross attention alone, B rows, launched back to back over `layers` different K / V^T images (so no launch re-reads what a previous one left in a cache).
@@ -1772,7 +1802,7 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
     const int pv16 = c->kv_frag() ? 2 : c->precision == SKW_PRECISION_F16_MFMA;       // (timing only: the images are random bytes in either layout; Tpad * d elements per slot are allocated above)
     for (int i = 0; i < layers; ++i) skw_dec_cross_attn_vt(q, K + kn * (i % layers), V + vn * (i % layers), B, H, d, nc, Tpad, out, nullptr, c->stream, 0, pv16);
     HIPCHK(hipMemsetAsync(clk, 0, kclk_node_bytes(), c->stream));
-    { SkwKClk hdr; memset(&hdr, 0, sizeof hdr); hdr.cap = KCLK_CAP; HIPCHK(hipMemcpyAsync(clk, &hdr, 16, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+    { static const unsigned hdr[4] = {(unsigned)KCLK_CAP, 0, 0, 0}; HIPCHK(hipMemcpyAsync(clk, hdr, 16, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     float ms = 0;
     std::vector<hipEvent_t> ev(2 * (size_t)iters);
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
@@ -1787,8 +1817,8 @@ extern "C" int skw_debug_xattn(skw_ctx* c, int B, int layers, int probe, int ite
         if (pv16 == 2) {
             int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->m->device));
             std::vector<char> h(kclk_node_bytes()); HIPCHK(hipMemcpy(h.data(), clk, h.size(), hipMemcpyDeviceToHost));
-            const SkwKClk* k = (const SkwKClk*)h.data(); double su = 0; int n = 0;
-            for (int j = 0; j < iters; ++j) if (k->rec[j].t1 && k->rec[j].t0_inv) { su += (double)(k->rec[j].t1 - ~k->rec[j].t0_inv) * 1000.0 / std::max(1, khz); ++n; }
+            const SkwKClk* k = (const SkwKClk*)h.data(); double su = 0; int n = 0; unsigned long long t0, t1; unsigned live;
+            for (int j = 0; j < iters; ++j) if (kclk_launch(k, j, &t0, &t1, &live)) { su += (double)(t1 - t0) * 1000.0 / std::max(1, khz); ++n; }
             if (n) *us_per_launch_clock = (float)(su / n);
         }
     }

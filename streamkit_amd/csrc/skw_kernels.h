@@ -143,12 +143,16 @@ void skw_dec_self_attn(const half_t* q, const half_t* kc, const half_t* vc, cons
 // pv16: P.V on the f16 matrix cores (the f16_mfma precision; the exact one chains f32 MFMAs key by key)
 // pv16: 0 the exact precision (two-phase kernel, f32 P.V chains), 1 f16_mfma over the row layouts (two-phase kernel, f16 P.V), 2 f16_mfma over the fragment-order images (one streaming pass)
 // In-kernel launch clock of the one-pass kernel (bench.py's roofline line must time the launches of the TIMED configuration — step graphs, two row groups on two streams — where no
-// HIP event can sit between captured kernels).  One SkwKClk per graph node (row group, layer); launch n of the node is the n-th group of gridDim workgroups to arrive.  Thread 0 of
-// every live workgroup folds its entry time into t0 (stored inverted, so zeroed memory is the identity of both maxima) and its exit time into t1, on the device's constant-rate
-// counter (wall_clock64, hipDeviceAttributeWallClockRate); live_rows counts the rows that streamed.  t1 - t0 is first-wave-in to last-wave-out: what rocprofv3 calls the duration
-// minus the dispatch and completion-signal edges, which skw_debug_xattn measures (events and clock on the same isolated launches) so that the line can state both.
+// HIP event can sit between captured kernels, and which a profiler serialises).  One SkwKClk per graph node (row group, layer).  Launches of a node are serial on its stream, so
+// every workgroup counts its own launches in a cell of its own (cnt[workgroup]: a plain load and store, nobody else touches it) — that number is the launch's record.  At its end,
+// thread 0 of every live workgroup folds its entry time into t0 (stored inverted, so zeroed memory is the identity of both maxima) and its exit time into t1, on the device's
+// constant-rate counter (wall_clock64, hipDeviceAttributeWallClockRate), in one of SKW_KCLK_SHARDS copies of the record (workgroup % shards: same-address atomics from 256
+// workgroups cost microseconds, a sixteenth of them does not); the host reduces the copies.  live_rows counts the rows that streamed.  t1 - t0 is first wave in to last wave out:
+// what rocprofv3 calls the duration minus the dispatch and completion-signal edges, which skw_debug_xattn measures (events and clock on the same isolated launches).
+#define SKW_KCLK_SHARDS 16
+#define SKW_KCLK_MAX_WG 4096
 struct SkwKClkRec { unsigned long long t0_inv, t1; unsigned live_rows, pad; };
-struct SkwKClk { unsigned arrive, cap, pad0, pad1; SkwKClkRec rec[1]; };      // rec[cap] follows
+struct SkwKClk { unsigned cap, pad0, pad1, pad2; unsigned cnt[SKW_KCLK_MAX_WG]; SkwKClkRec rec[1][SKW_KCLK_SHARDS]; };      // rec[cap][SKW_KCLK_SHARDS] follows
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
     int f32_out = 0, int pv16 = 0, const int* seq = nullptr,
                            // ofrag (one-pass kernel only): the output rows as the fragment-order A image of the projection that follows; events: stamped at the kernel's

@@ -1144,15 +1144,14 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
     constexpr int AUX = 2;
     const int b = blockIdx.y;
     const bool row_live = !(active && !active[b * active_stride]);
-    SkwKClkRec* rec = nullptr;                                          // thread 0 only
+    SkwKClkRec* rec = nullptr; unsigned long long t_in = 0;             // thread 0 only
     if (clk && threadIdx.x == 0) {
-        // every workgroup of the launch takes a ticket (finished rows too: the launch index is ticket / workgroups per launch; launches of one graph node are serial on its stream)
-        const unsigned long long t_in = wall_clock64();
-        const unsigned launch = atomicAdd(&clk->arrive, 1u) / (gridDim.x * gridDim.y);
-        if (row_live && launch < clk->cap) {
-            rec = clk->rec + launch;
-            atomicMax(&rec->t0_inv, ~t_in);                             // earliest begin over the workgroups (stored inverted: the records start as zeros)
-            if (blockIdx.x == 0) atomicAdd(&rec->live_rows, 1u);
+        // this workgroup's own launch count (finished rows count too): launches of one graph node are serial on its stream, the cell is nobody else's
+        t_in = wall_clock64();
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < SKW_KCLK_MAX_WG) {
+            const unsigned launch = clk->cnt[wg]; clk->cnt[wg] = launch + 1;
+            if (row_live && launch < clk->cap) rec = &clk->rec[launch][wg % SKW_KCLK_SHARDS];
         }
     }
     if (!row_live) return;
@@ -1247,7 +1246,10 @@ __global__ __launch_bounds__(256 * HPW, (HPW >= 3) ? 1 : 3 / HPW) void k_dec_cro
         num = __builtin_fmaf(cmb[hs][i][2 + lane], a, num); den = __builtin_fmaf(cmb[hs][i][1], a, den); }
         att_store_m(out, b, ldo, h * 64 + lane, num / den, f32_out, ofrag_k);
     }
-    if (rec) atomicMax(&rec->t1, wall_clock64());                       // latest end over the workgroups (thread 0 sits in a wave that does the final combine and store)
+    if (rec) {      // earliest begin and latest end over the workgroups, off the critical path (thread 0 sits in a wave that does the final combine and store)
+        atomicMax(&rec->t0_inv, ~t_in); atomicMax(&rec->t1, wall_clock64());
+        if (blockIdx.x == 0) atomicAdd(&rec->live_rows, 1u);
+    }
 }
 void skw_dec_cross_attn_vt(const half_t* q, const half_t* ck, const half_t* cvt, int B, int H, int d, int n_ctx, int Tpad, half_t* out, const int* active, hipStream_t s,
     int f32_out, int pv16, const int* seq, hipEvent_t ev_start, hipEvent_t ev_stop, int ofrag, SkwKClk* clk) {

@@ -118,6 +118,7 @@ def lib():
         L.skw_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         L.skw_ctx_kernel_clock.argtypes = [C.c_void_p, C.c_int]
         L.skw_ctx_kernel_clock_get.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.skw_ctx_kernel_clock_records.restype = C.c_long; L.skw_ctx_kernel_clock_records.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
         L.skw_debug_xattn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.skw_debug_switch_name.restype = C.c_char_p; L.skw_debug_switch_name.argtypes = [C.c_int]
         L.skw_debug_switch_what.restype = C.c_char_p; L.skw_debug_switch_what.argtypes = [C.c_int]
@@ -265,6 +266,14 @@ class Context:
         n = C.c_long(); su = C.c_double(); sl = C.c_double(); mn = C.c_double(); mx = C.c_double(); khz = C.c_int()
         self._check(lib().skw_ctx_kernel_clock_get(self.h, C.byref(n), C.byref(su), C.byref(sl), C.byref(mn), C.byref(mx), C.byref(khz)))
         return dict(launches=n.value, sum_us=su.value, sum_live_rows=sl.value, min_us=mn.value, max_us=mx.value, clock_khz=khz.value)
+
+    def kernel_clock_records(self, cap=65536):
+        """[(begin us, end us, live rows)] of every launch the last call recorded"""
+        out = np.zeros((cap, 3), np.float64)
+        n = lib().skw_ctx_kernel_clock_records(self.h, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("skw engine: " + self.last_error())
+        return out[:n].copy()
 
     def stream(self):
         return lib().skw_ctx_stream(self.h)

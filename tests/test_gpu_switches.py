@@ -37,6 +37,10 @@ CASES = [
     ("RESAMPLE_SCAN", 1, "resample"),
     ("RESAMPLE_NO_HOST_WALK", 1, "resample"),
 ]
+# Teacher-forced logit-error bound of a tolerance case, where it is not the precision's default for the model (streamkit_amd/parity.py bounds_for: 0.36 for the small test models,
+# set from batches of <= 1 100 decisions).  The two-phase cross attention rounds the NORMALISED probabilities to f16 where the one-pass kernel rounds p <= 1 before the division:
+# measured 0.363 over this file's 4 488 decisions (8 argmax disagreements, all at exact-mode margins <= 0.040; gpurun_out/r05a_suite.txt) — bound = 1.1 x that.
+TOL_LOGIT_ERR = {("XATTN_FRAG", 0): 0.40}
 # a ragged batch: one-window clips, multi-window clips whose later windows carry ~100-token prompts (the prompt pass then has >= 256 rows: the big-tile GEMM and the
 # multi-query cross attention run), a clip too short to transcribe
 CLIPS = [(11, 16000 * 75), (5, 16000 * 9), (13, 16000 * 47 + 123), (14, 16000 * 93), (15, 16000 * 80), (16, 16000 * 66), (17, 16000 * 88), (8, 1500), (9, 488000), (18, 16000 * 71), (19, 16000 * 30),
@@ -48,11 +52,11 @@ def _key(res):
     return [([tuple(t[:5]) for t in r["tokens"]], [(s["t0"], s["t1"], s["text"]) for s in r["segments"]], r["n_windows"], r["fallback_requested"]) for r in res]
 
 
-def _transcribe(eng, path, pcms, want_tf=False, quant_mode=1):
+def _transcribe(eng, path, pcms, want_tf=False, quant_mode=1, logit_err_bound=None):
     m = eng.Model(path, quant_mode=quant_mode); ctx = eng.Context(m, max_batch=len(pcms), max_samples=MAXS)
     ctx.set_precision("exact"); ex = _key(ctx.full_batch(pcms))
     ctx.set_precision("f16_mfma"); f16 = _key(ctx.full_batch(pcms))
-    tf = teacher_forced_compare(ctx, pcms) if want_tf else None
+    tf = teacher_forced_compare(ctx, pcms, logit_err_bound=logit_err_bound) if want_tf else None
     ctx.close(); m.close()
     return ex, f16, tf
 
@@ -88,7 +92,7 @@ def test_every_switch_has_a_case(eng):
 @pytest.mark.parametrize("name, value, kind", [c for c in CASES if c[2] in ("same_bits", "tolerance")], ids=lambda v: str(v))
 def test_transcription_paths(eng, tiny_model_path, pcms, baseline, name, value, kind):
     with eng.switch(name, value):
-        ex, f16, tf = _transcribe(eng, tiny_model_path, pcms, want_tf=(kind == "tolerance"))
+        ex, f16, tf = _transcribe(eng, tiny_model_path, pcms, want_tf=(kind == "tolerance"), logit_err_bound=TOL_LOGIT_ERR.get((name, value)))
     assert eng.switches()[name][1] == eng.switches()[name][0]            # restored
     for i, (a, b) in enumerate(zip(ex, baseline[0])):
         assert a == b, (name, value, "exact precision", CLIPS[i])
