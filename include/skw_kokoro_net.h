@@ -20,8 +20,14 @@
  * Tensor names follow the PyTorch modules (weight-norm pairs folded into `.weight`, as an export folds them); a real sherpa-onnx export names its
  * initializers by graph node, so binding one would need a name map this build does not have: create() rejects files without these names and says so.
  *
- * Deviations a deterministic checker needs (all in both backends): the source's random initial harmonic phases and additive noise come from a counter-based
- * hash (uniform, unit variance) instead of torch.rand / randn; phases accumulate per frame in f64; dropout is inference-mode identity.
+ * Deviations a deterministic checker needs (all in both backends): the source's additive noise comes from a counter-based hash (uniform, unit variance) instead of
+ * torch.randn; dropout is inference-mode identity.  The harmonic phases follow the published SineGen._f02sine law evaluated in f64 (round 5; rounds 3-4 accumulated a per-sample
+ * phase at piecewise-constant F0, which tests/kokoro_torch_ref.py — an independent restatement of the published modules — showed to be a different signal): per harmonic h and
+ * F0 value m, r = frac(h f0_m / 24000); C_m = sum_{j <= m} r_j (mod 1); sample n sits at x = max(0, (n + 0.5) / 300 - 0.5) between F0 values m0 = floor(x) and
+ * m1 = min(m0 + 1, M - 1): cycles = 300 (C_m0 + (x - m0) (m1 > m0 ? r_m1 : 0)) — torch's linear interpolation (align_corners = False) of the frame-rate phase, times the
+ * up-sampling factor; sine = 0.1 sin(2 pi cycles).  (The published code adds torch.rand initial phases to the FIRST SAMPLE of the sample-rate phase increments, which its
+ * own down-sampling to the frame rate never reads: they have no effect, and there are none here.  torch evaluates the law in f32, where a phase of 1e5 rad has an ulp of
+ * 0.008 rad; f64 is the value the formula defines.)
  *
  * OPERATOR ARITHMETIC (the contract both backends implement; activations are row-major [time][channel] f32)
  *   contraction      every weight product is ONE f32 chain acc = fmaf(w, x, acc) from 0 in ascending k, bias added after; conv k = tap * Cin + ci
@@ -327,7 +333,7 @@ template <class B> struct Net {
         /* ---- generator (ISTFTNet) ---- */
         Buf har = be.source_stft(curves[0], W("decoder.generator.m_source.l_linear.weight"), W("decoder.generator.m_source.l_linear.bias"));   /* [2 F * 60 + 1][22] */
         out->har = har;
-        Buf gx = xd;
+        Buf gx = be.copy(xd);      /* (the activations below work in place: the decoder-output tap must not see them — round 5: the independent torch checker found the tap post-LeakyReLU) */
         for (int i = 0; i < 2; ++i) {
             const std::string I = std::to_string(i);
             be.act(gx, ACT_LEAKY01, nullptr);
@@ -363,7 +369,6 @@ template <class B> struct Net {
                            0.0, -SKW_KOKORO_TW_D, -SKW_KOKORO_TW_C, -SKW_KOKORO_TW_B, -SKW_KOKORO_TW_A, -1.0, -SKW_KOKORO_TW_A, -SKW_KOKORO_TW_B, -SKW_KOKORO_TW_C, -SKW_KOKORO_TW_D}
 
 /* ---- pieces of the source that both backends compute with the same integer arithmetic ---- */
-inline uint32_t hash32(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31; return (uint32_t)(x >> 32); }
 /* uniform in [-sqrt 3, sqrt 3): zero mean, unit variance (stands in for torch.randn: the reference's noise is not reproducible either) */
 #if defined(__HIPCC__)
 __host__ __device__

@@ -191,16 +191,21 @@ struct CpuBackend {
     }
     Buf source_stft(const Buf& f0c, const Tensor& lw, const Tensor& lb) {
         const int M = f0c.T; const long L = (long)M * SRC_UP; const int P = (int)(L / HOP) + 1;
-        std::vector<double> phi(M + 1, 0.0);
-        for (int m = 0; m < M; ++m) { double p = phi[m] + (double)SRC_UP * (double)f0c.data()[m] / (double)SAMPLE_RATE; phi[m + 1] = p - floor(p); }
+        /* the published phase law (skw_kokoro_net.h header): per harmonic the frame-rate cumulative phase C (inclusive, mod 1), linearly interpolated to the sample rate */
+        std::vector<double> C((size_t)N_HARM * M);
+        for (int h = 1; h <= N_HARM; ++h) { double c = 0.0; for (int m = 0; m < M; ++m) { double r = (double)h * (double)f0c.data()[m] / (double)SAMPLE_RATE; r -= floor(r); c += r; c -= floor(c);
+            C[(size_t)(h - 1) * M + m] = c; } }
         std::vector<float> src(L);
 #pragma omp parallel for schedule(static)
         for (long n = 0; n < L; ++n) {
-            const int m = (int)(n / SRC_UP), u = (int)(n % SRC_UP); const float f0 = f0c.data()[m];
-            const double base = phi[m] + (double)u * (double)f0 / (double)SAMPLE_RATE; const float uv = f0 > 10.0f ? 1.0f : 0.0f; const float amp = f0 > 10.0f ? 0.003f : 0.1f / 3.0f;
+            const int m = (int)(n / SRC_UP); const float f0 = f0c.data()[m];
+            const float uv = f0 > 10.0f ? 1.0f : 0.0f; const float amp = f0 > 10.0f ? 0.003f : 0.1f / 3.0f;
+            double x = ((double)n + 0.5) / (double)SRC_UP - 0.5; if (x < 0.0) x = 0.0;
+            const int m0 = (int)x, m1 = m0 + 1 < M ? m0 + 1 : M - 1; const double wq = x - (double)m0;
             float acc = 0.0f;
             for (int h = 1; h <= N_HARM; ++h) {
-                double cyc = (double)h * base + (h > 1 ? (double)hash32((uint64_t)h) / 4294967296.0 : 0.0); cyc -= floor(cyc);
+                double r1 = 0.0; if (m1 > m0) { r1 = (double)h * (double)f0c.data()[m1] / (double)SAMPLE_RATE; r1 -= floor(r1); }
+                double cyc = (double)SRC_UP * (C[(size_t)(h - 1) * M + m0] + wq * r1); cyc -= floor(cyc);
                 const float sine = (float)sin(6.283185307179586476925286766559 * cyc) * 0.1f;
                 const float val = sine * uv + amp * unit_noise((uint64_t)n * 16 + (uint64_t)h);
                 acc = fmaf(lw.host[h - 1], val, acc);

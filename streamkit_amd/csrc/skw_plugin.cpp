@@ -164,16 +164,39 @@ struct SharedEngine {
     // The workspace is sized for the longest segment an instance of this engine can cut (its max_segment_duration_secs) and the largest batch one asked
     // for, not for the schema's maxima: 31 s by default instead of 121 (0.2 GB instead of 0.8 at 64 rows).  An instance that allows longer segments or
     // larger batches grows it, between batches (the engine outlives its instances: lib.rs:170-180).
+    // Grows to max(configured floor, what was held, what is needed), rounded up (whole seconds, multiples of 8 rows) so that a run of slightly longer segments does not
+    // re-create it batch after batch.  When the larger workspace cannot be had, the previous size — or the floor — is restored and only the oversize batch fails.
+    int floor_samples = 0, floor_batch = 0;      // what the instances of this engine were configured for (get_engine); the workspace is never smaller while one is alive
+    std::mutex ws_mu;                            // the workspace is in use (a batch is running) or being re-created / released
+    int live_instances = 0;                      // under ws_mu: plugin instances holding this engine; the last one to go releases the workspace (the MODEL stays, lib.rs:170-180)
     bool ensure_workspace(int need_samples, int need_batch, std::string* err) {
-        if (need_samples <= max_samples && need_batch <= max_batch) return true;
-        const int ns = std::max(need_samples, max_samples), nb = std::max(need_batch, max_batch);
+        if (ctx && need_samples <= max_samples && need_batch <= max_batch) return true;
+        const int was_s = max_samples, was_b = max_batch;
+        const int ns = std::min(kMaxSamples, (std::max(std::max(need_samples, max_samples), floor_samples) + 15999) / 16000 * 16000);
+        const int nb = (std::max(std::max(need_batch, max_batch), floor_batch) + 7) & ~7;
         char ebuf[512] = {0};
         if (ctx) { skw_ctx_free(ctx); ctx = nullptr; max_samples = 0; max_batch = 0; }      // release first: two workspaces need not fit side by side
         skw_ctx* nc = skw_ctx_create(model, nb, ns, ebuf, sizeof ebuf);
-        if (!nc) { *err = std::string("Failed to create Whisper state: ") + ebuf; return false; }
+        if (!nc) {
+            *err = std::string("Failed to create Whisper state: ") + ebuf;
+            const int rs = std::max(was_s, floor_samples), rb = std::max(was_b, floor_batch);
+            if (rs > 0 && rb > 0 && (rs < ns || rb < nb)) {      // back to what there was: later batches of the usual size must not pay for this one
+                char e2[512] = {0};
+                if (skw_ctx* oc = skw_ctx_create(model, rb, rs, e2, sizeof e2)) { skw_ctx_set_precision(oc, precision); ctx = oc; max_samples = rs; max_batch = rb; }
+            }
+            return false;
+        }
         skw_ctx_set_precision(nc, precision);
         ctx = nc; max_samples = ns; max_batch = nb;
         return true;
+    }
+    void instance_added() { std::lock_guard<std::mutex> l(ws_mu); ++live_instances; }
+    // The reference keeps the CONTEXT (weights) for the life of the process and drops each instance's WhisperState with the instance (lib.rs:160-180, 376-380).  Here the
+    // batch workspace plays the state's part for all instances at once: when the last one goes — the prewarm node, or every session after a quiet spell — its device memory
+    // (cross / self K-V caches for max_batch rows: 6.6 GB at 64 rows of Whisper-small) is returned; the next batch re-creates it (~3-20 ms, logged by get_engine).
+    void instance_gone() {
+        std::lock_guard<std::mutex> l(ws_mu);
+        if (--live_instances <= 0) { live_instances = 0; if (ctx) { skw_ctx_free(ctx); ctx = nullptr; max_samples = 0; max_batch = 0; } }
     }
     std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<Job>> queue; bool stop = false; std::thread worker;
     ~SharedEngine() {
@@ -201,6 +224,7 @@ struct SharedEngine {
             try {
                 std::vector<const float*> ptrs(n); std::vector<int32_t> ns(n); std::vector<skw_result> res(n); int need = 0;
                 for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->data(); ns[i] = (int32_t)batch[i]->n; need = std::max(need, (int)ns[i]); }
+                std::lock_guard<std::mutex> wl(ws_mu);
                 if (ensure_workspace(need, n, &why)) {
                     rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
                     if (rc == 0) for (int i = 0; i < n; ++i) batch[i]->result = res[i]; else why = skw_ctx_last_error(ctx);
@@ -237,6 +261,9 @@ void resolve_auto_device(WhisperConfig* cfg) {
 // ------------------------------------------------------------------ the plugin instance (lib.rs:199-221)
 struct WhisperPlugin {
     WhisperConfig config; std::shared_ptr<SharedEngine> engine; skw::Segmenter seg; std::unique_ptr<skw::Vad> vad;
+    // the engine this instance holds, counted (SharedEngine::live_instances): the last holder to let go returns the batch workspace
+    void hold(std::shared_ptr<SharedEngine> e) { if (e) e->instance_added(); if (engine) engine->instance_gone(); engine = std::move(e); }
+    ~WhisperPlugin() { if (engine) engine->instance_gone(); }
     std::unique_ptr<skw::ResamplerCore> front;      // input_sample_rate != 16000: the audio::resampler node's arithmetic on the GPU, feeding the segmenter
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
     void log(CLogLevel lv, const char* fmt, ...) {
@@ -256,6 +283,11 @@ std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, WhisperPlugin
         g_cache_hits.fetch_add(1);
         // additive scheduler params: the most recent instance's
         { std::lock_guard<std::mutex> le(it->second->mu); it->second->batch_limit = cfg.max_batch; it->second->window_ms = cfg.batch_window_ms; }
+        { std::lock_guard<std::mutex> lw(it->second->ws_mu);      // the floor follows the largest configuration seen; the workspace itself grows (or comes back) with the next batch
+          it->second->floor_samples = std::max(it->second->floor_samples, SharedEngine::samples_for(cfg.max_segment_duration_secs));
+          it->second->floor_batch = std::max(it->second->floor_batch, cfg.max_batch);
+          // an engine whose last instance had gone gets its workspace back here, at instance creation — where the reference creates a WhisperState (lib.rs:377-379) — not inside the first batch
+          if (!it->second->ctx && !it->second->ensure_workspace(it->second->floor_samples, it->second->floor_batch, err)) return nullptr; }
         if (who) who->log(SK_LOG_INFO, "CACHE HIT: Reusing cached Whisper context (model_path=%s, gpu_device=%d, precision=%s)", cfg.model_path.c_str(), cfg.gpu_device, cfg.precision.c_str());
         return it->second;
     }
@@ -270,7 +302,8 @@ std::shared_ptr<SharedEngine> get_engine(const WhisperConfig& cfg, WhisperPlugin
     eng->batch_limit = cfg.max_batch;
     eng->window_ms = cfg.batch_window_ms;
     eng->precision = cfg.precision == "f16_mfma" ? SKW_PRECISION_F16_MFMA : SKW_PRECISION_EXACT;
-    if (!eng->ensure_workspace(SharedEngine::samples_for(cfg.max_segment_duration_secs), cfg.max_batch, err)) return nullptr;
+    eng->floor_samples = SharedEngine::samples_for(cfg.max_segment_duration_secs); eng->floor_batch = cfg.max_batch;
+    if (!eng->ensure_workspace(eng->floor_samples, eng->floor_batch, err)) return nullptr;
     const auto t2 = std::chrono::steady_clock::now();
     eng->worker = std::thread([e = eng.get()] { e->run(); });
     cache.map[key] = eng;
@@ -449,7 +482,7 @@ CPluginHandle create_instance_impl(const char* params, CLogCallback log_cb, void
     std::string err;
     if (!parse_config(params, &p->config, &err)) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     resolve_auto_device(&p->config);
-    p->engine = get_engine(p->config, p.get(), &err);
+    p->hold(get_engine(p->config, p.get(), &err));
     if (!p->engine) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
     p->vad = make_vad(p->config, p.get(), &err);
     if (!p->vad) { p->log(SK_LOG_ERROR, "%s", err.c_str()); return nullptr; }
@@ -519,7 +552,7 @@ CResult plugin_update_params(CPluginHandle handle, const char* params) {
         if (nc.model_path != self->config.model_path || nc.precision != self->config.precision || nc.use_gpu != self->config.use_gpu || nc.gpu_device != self->config.gpu_device) {
             auto eng = get_engine(nc, self, &err);
             if (!eng) return err_result("Failed to reload Whisper model: " + err);
-            self->engine = eng;
+            self->hold(eng);
         }
         if (nc.vad_model_path != self->config.vad_model_path || nc.vad_threshold != self->config.vad_threshold || nc.vad_mode != self->config.vad_mode) {
             auto v = make_vad(nc, self, &err);
@@ -559,4 +592,12 @@ extern "C" const CNativePluginAPI* streamkit_native_plugin_api(void) { return &k
 extern "C" void skw_whisper_plugin_cache_stats(int* model_loads, int* cache_hits) {
     if (model_loads) *model_loads = g_model_loads.load();
     if (cache_hits) *cache_hits = g_cache_hits.load();
+}
+// additive, for tests: cached engines (models resident), how many of them hold a batch workspace right now, and live plugin instances over all of them
+extern "C" void skw_whisper_plugin_workspace_stats(int* engines, int* workspaces, int* instances) {
+    EngineCache& cache = engine_cache();
+    std::lock_guard<std::mutex> l(cache.mu);
+    int e = 0, w = 0, n = 0;
+    for (auto& kv : cache.map) { std::lock_guard<std::mutex> lw(kv.second->ws_mu); ++e; w += kv.second->ctx != nullptr; n += kv.second->live_instances; }
+    if (engines) *engines = e; if (workspaces) *workspaces = w; if (instances) *instances = n;
 }

@@ -374,17 +374,23 @@ __global__ void k_tts_durations(const float* lg, int T, int K, float scale, int*
     double s = 0.0; for (int k = 0; k < K; ++k) s += (double)sigmoid_e(lg[(long)t * K + k]);
     const float r = rintf((float)s * scale); dur[t] = r < 1.0f ? 1 : (int)r;
 }
-// source: per-F0-value start phase (sequential f64 walk, M <= 6000), then every sample on its own
-__global__ void k_tts_phase_scan(const float* f0, int M, double* phi) { double p = 0.0;
-for (int m = 0; m < M; ++m) { phi[m] = p; p += (double)SRC_UP * (double)f0[m] / (double)SAMPLE_RATE; p -= floor(p); } }
-__global__ void k_tts_source(const float* f0c, const double* phi, long L, const float* lw, const float* lb, float* src) {
+// source (the published SineGen law in f64, skw_kokoro_net.h header): per harmonic the frame-rate cumulative phase C[h][m] (inclusive, mod 1; one thread per harmonic walks
+// M <= 6000 values), then every sample on its own: C interpolated linearly to the sample rate, times the up-sampling factor
+__global__ void k_tts_phase_scan(const float* f0, int M, double* C) {
+    const int h = threadIdx.x + 1; if (h > N_HARM) return;
+    double c = 0.0;
+    for (int m = 0; m < M; ++m) { double r = (double)h * (double)f0[m] / (double)SAMPLE_RATE; r -= floor(r); c += r; c -= floor(c); C[(long)(h - 1) * M + m] = c; }
+}
+__global__ void k_tts_source(const float* f0c, const double* C, int M, long L, const float* lw, const float* lb, float* src) {
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x; if (n >= L) return;
-    const int m = (int)(n / SRC_UP), u = (int)(n % SRC_UP); const float f0 = f0c[m];
-    const double base = phi[m] + (double)u * (double)f0 / (double)SAMPLE_RATE; const float uv = f0 > 10.0f ? 1.0f : 0.0f; const float amp = f0 > 10.0f ? 0.003f : 0.1f / 3.0f;
+    const int m = (int)(n / SRC_UP); const float f0 = f0c[m];
+    const float uv = f0 > 10.0f ? 1.0f : 0.0f; const float amp = f0 > 10.0f ? 0.003f : 0.1f / 3.0f;
+    double x = ((double)n + 0.5) / (double)SRC_UP - 0.5; if (x < 0.0) x = 0.0;
+    const int m0 = (int)x, m1 = m0 + 1 < M ? m0 + 1 : M - 1; const double wq = x - (double)m0;
     float acc = 0.0f;
     for (int h = 1; h <= N_HARM; ++h) {
-        uint64_t hx = (uint64_t)h + 0x9E3779B97F4A7C15ull; hx = (hx ^ (hx >> 30)) * 0xBF58476D1CE4E5B9ull; hx = (hx ^ (hx >> 27)) * 0x94D049BB133111EBull; hx ^= hx >> 31;      // hash32(h)
-        double cyc = (double)h * base + (h > 1 ? (double)(uint32_t)(hx >> 32) / 4294967296.0 : 0.0); cyc -= floor(cyc);
+        double r1 = 0.0; if (m1 > m0) { r1 = (double)h * (double)f0c[m1] / (double)SAMPLE_RATE; r1 -= floor(r1); }
+        double cyc = (double)SRC_UP * (C[(long)(h - 1) * M + m0] + wq * r1); cyc -= floor(cyc);
         const float sine = (float)sin(6.283185307179586476925286766559 * cyc) * 0.1f;
         const float val = sine * uv + amp * unit_noise((uint64_t)n * 16 + (uint64_t)h);
         acc = __builtin_fmaf(lw[h - 1], val, acc);
@@ -598,10 +604,10 @@ struct GpuBackend {
     }
     Buf source_stft(const Buf& f0c, const Tensor& lw, const Tensor& lb) {
         const int M = f0c.T; const long L = (long)M * SRC_UP; const int P = (int)(L / HOP) + 1;
-        double* phi = (double*)arena_get(t, sizeof(double) * M); float* src = (float*)arena_get(t, sizeof(float) * L); Buf o = make(P, 2 * N_BINS);
+        double* phi = (double*)arena_get(t, sizeof(double) * M * N_HARM); float* src = (float*)arena_get(t, sizeof(float) * L); Buf o = make(P, 2 * N_BINS);
         if (!phi || !src || !o.p) return o;
-        hipLaunchKernelGGL(k_tts_phase_scan, dim3(1), dim3(1), 0, s, f0c.p, M, phi);
-        hipLaunchKernelGGL(k_tts_source, dim3(blocks(L)), dim3(256), 0, s, f0c.p, phi, L, dev(lw), dev(lb), src);
+        hipLaunchKernelGGL(k_tts_phase_scan, dim3(1), dim3(64), 0, s, f0c.p, M, phi);
+        hipLaunchKernelGGL(k_tts_source, dim3(blocks(L)), dim3(256), 0, s, f0c.p, phi, M, L, dev(lw), dev(lb), src);
         hipLaunchKernelGGL(k_tts_stft, dim3(blocks((long)P * N_BINS)), dim3(256), 0, s, src, L, P, o.p);
         return o;
     }
@@ -727,7 +733,9 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
     EventPair ev; if (!ev.create()) return fail("event creation failed");
     t->cur_chunk = 0; t->cur_off = 0; t->arena_failed = false;
     hipEventRecord(ev.a, t->stream);
-    const int row = std::min(T - 2, t->voice_rows - 1);      // the style row is chosen by the token count (Kokoro's voices are indexed by length)
+    // Kokoro's voices are indexed by length: the published pipeline takes pack[len(phonemes) - 1], and the ids carry the pad id at both ends (T = len + 2): row T - 3
+    // (rounds 3-4 took T - 2).  What sherpa-onnx's front end picks for the same text is unpinned.
+    const int row = std::min(T - 3, t->voice_rows - 1);
     const float* style = t->voices + ((size_t)sid * t->voice_rows + (size_t)std::max(0, row)) * 2 * STYLE_DIM;
     GpuBackend be(t); be.word_tab = (const float*)t->w.at("bert.embeddings.word_embeddings.weight").dev;
     Net<GpuBackend> net(be, t->w, t->g); Outputs<GpuBackend::Buf> out; std::string e;

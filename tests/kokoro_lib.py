@@ -61,6 +61,38 @@ def tokenize(text, model_dir):
     return ids
 
 
+def style_row(T):
+    """voices.bin row for T token ids (pad id at both ends): the published pipeline's pack[len(phonemes) - 1] = T - 3"""
+    return max(0, min(T - 3, MAX_TOKENS - 1))
+
+
+def unit_noise(counter):
+    """numpy restatement of the product's stand-in for torch.randn in the harmonic source (include/skw_kokoro_net.h unit_noise: a splitmix64 counter hash, top 24 bits, uniform in
+    [-sqrt 3, sqrt 3)); sample n, harmonic h (1-based) draws unit_noise(16 n + h)"""
+    with np.errstate(over="ignore"):
+        x = np.asarray(counter).astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(40)).astype(np.float32)
+    return ((u * np.float32(1.0 / 8388608.0) - np.float32(1.0)) * np.float32(1.7320508075688772)).astype(np.float32)
+
+
+def source_noise(L, harmonics=9):
+    """[1, L, harmonics] torch tensor: what the published SineGen draws with randn_like, as the product draws it"""
+    import torch
+    n = np.arange(L, dtype=np.uint64)[:, None] * np.uint64(16) + np.arange(1, harmonics + 1, dtype=np.uint64)[None, :]
+    return torch.from_numpy(unit_noise(n)).unsqueeze(0)
+
+
+def load_model_tensors(model_dir):
+    return {name: np.ascontiguousarray(a, np.float32) for _, name, a in onnx_mini.read_tensors(os.path.join(model_dir, "model.onnx"))}
+
+
+def load_voices(model_dir):
+    return np.fromfile(os.path.join(model_dir, "voices.bin"), "<f4").reshape(-1, MAX_TOKENS, 2 * STYLE)
+
+
 class _TensorRef(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("n_dims", C.c_int32), ("dims", C.c_int64 * 4)]
 
@@ -89,7 +121,7 @@ class OracleTts:
 
     def synth(self, text, sid=0, speed=1.0, length_scale=1.0, ids=None):
         ids = np.asarray(tokenize(text, self.dir) if ids is None else ids, np.int32); T = ids.size
-        style = np.ascontiguousarray(self.voices[sid, max(0, min(T - 2, MAX_TOKENS - 1))])
+        style = np.ascontiguousarray(self.voices[sid, style_row(T)])
         dur = np.zeros(T, np.int32); F = C.c_int32()
         cap_f = MAX_FRAMES
         bert = np.zeros(T * self.hid, np.float32); d_en = np.zeros(T * self.d, np.float32); t_en = np.zeros(T * self.d, np.float32)

@@ -132,17 +132,15 @@ def test_golden_tokens(oracle_micro):
         assert r["n_windows"] == case["n_windows"] and r["fallback_requested"] == case["fallback_requested"]
 
 
-def test_hf_whisper_crosscheck(tiny_model_path, oracle_tiny):
-    """Independent implementation check of the ARCHITECTURE (conv stem, attention scaling, LN eps, K without bias, tied
-    logits): HF transformers' Whisper in fp32 with the same weights.  HF uses exact-erf GELU and fp32 activations where
-    ggml uses the f16 tanh-GELU table and f16-rounded matmul operands, so agreement is to ~1e-2, not bitwise."""
-    torch = pytest.importorskip("torch")
-    tr = pytest.importorskip("transformers")
-    hp, _, _, T = read_ggml(tiny_model_path)
+def _hf_whisper_from_ggml(path):
+    """HF transformers' Whisper (fp32) carrying the weights of the GGML file at `path`; returns (model, hparams)."""
+    import torch
+    import transformers as tr
+    hp, _, _, T = read_ggml(path)
     cfg = tr.WhisperConfig(vocab_size=hp["n_vocab"], num_mel_bins=hp["n_mels"], d_model=hp["n_audio_state"], encoder_layers=hp["n_audio_layer"],
                            decoder_layers=hp["n_text_layer"], encoder_attention_heads=hp["n_audio_head"], decoder_attention_heads=hp["n_text_head"],
                            encoder_ffn_dim=4 * hp["n_audio_state"], decoder_ffn_dim=4 * hp["n_text_state"], max_source_positions=hp["n_audio_ctx"],
-                           max_target_positions=hp["n_text_ctx"], activation_function="gelu_new" if False else "gelu", pad_token_id=50257, bos_token_id=50257,
+                           max_target_positions=hp["n_text_ctx"], activation_function="gelu", pad_token_id=50257, bos_token_id=50257,
                            eos_token_id=50257, decoder_start_token_id=50258)
     model = tr.WhisperModel(cfg).eval().float()
     sd = {}
@@ -170,22 +168,54 @@ def test_hf_whisper_crosscheck(tiny_model_path, oracle_tiny):
     assert not unexpected and all(k.endswith("k_proj.bias") for k in missing), (missing, unexpected)   # whisper has no key bias
     for k in missing:
         model.state_dict()[k].zero_()
+    return model, hp
+
+
+def test_hf_whisper_crosscheck(tiny_model_path, oracle_tiny):
+    """Independent implementation check of the ARCHITECTURE (conv stem and padding, positional offsets, attention scaling, LN eps, K without bias, tied logits): HF transformers'
+    Whisper in fp32 with the same weights, compared STAGE BY STAGE — conv stem + positions, encoder layer 0, encoder output, decoder logits — each bound at twice what was
+    measured (the old 3e-2 / 0.1 sigma would have let a subtly wrong pad or offset through).  HF uses exact-erf GELU and fp32 activations where ggml uses the
+    f16 tanh-GELU table and f16-rounded matmul operands, so agreement is ~1e-3 of a stage's range, not bitwise.  Measured (round 5, this container): conv stem 5.5e-4,
+    layer 0 6.7e-4, encoder output 9.2e-4 of the stage's largest magnitude; logits 0.0040 sigma over 29 teacher-forced positions, argmax identical at all of them."""
+    torch = pytest.importorskip("torch")
+    pytest.importorskip("transformers")
+    model, hp = _hf_whisper_from_ggml(tiny_model_path)
     pcm = synth.clip(2, 480000)
     mel, _ = oracle_tiny.log_mel(pcm)
-    enc_o, ck, cv = oracle_tiny.encode(mel)
+    oracle_lib.debug_enable(True)
+    try:
+        x0_o = oracle_tiny.conv_stem(mel)
+        enc_o, ck, cv = oracle_tiny.encode(mel)
+        l0_o = oracle_lib.debug_get("l0.x2").reshape(hp["n_audio_ctx"], -1).copy()
+    finally:
+        oracle_lib.debug_enable(False)
+    p = oracle_tiny.default_params(); p.suppress_nst = 1
+    ids = [50258, 50259, 50359] + [t[0] for t in oracle_tiny.full(pcm, p)["tokens"]][:28]       # the oracle's own greedy transcript as the teacher
+    assert len(ids) >= 23
     with torch.no_grad():
         feats = torch.from_numpy(mel[:, :3000]).unsqueeze(0)
-        enc_h = model.encoder(feats).last_hidden_state[0].numpy()
-        toks = torch.tensor([[50258, 50259, 50359, 50364, 1234]])
-        dec_h = model.decoder(input_ids=toks, encoder_hidden_states=torch.from_numpy(enc_h).unsqueeze(0)).last_hidden_state[0, -1]
-        logits_h = (dec_h @ model.decoder.embed_tokens.weight.T).numpy()
-    rel = np.abs(enc_h - enc_o).max() / np.abs(enc_h).max()
-    assert rel < 3e-2, rel
+        e = model.encoder
+        stem = torch.nn.functional.gelu(e.conv2(torch.nn.functional.gelu(e.conv1(feats)))).permute(0, 2, 1) + e.embed_positions.weight
+        out = e(feats, output_hidden_states=True)
+        assert float((out.hidden_states[0] - stem).abs().max()) == 0.0                           # (what HF feeds its first layer IS conv stem + positions)
+        enc_h = out.last_hidden_state[0].numpy()
+        dec = model.decoder(input_ids=torch.tensor([ids]), encoder_hidden_states=out.last_hidden_state).last_hidden_state[0]
+        logits_h = (dec @ model.decoder.embed_tokens.weight.T).numpy()
+    rel = lambda h, o: float(np.abs(h - o).max() / np.abs(h).max())
+    r_stem, r_l0, r_enc = rel(stem[0].numpy(), x0_o), rel(out.hidden_states[1][0].numpy(), l0_o), rel(enc_h, enc_o)
+    assert r_stem < 1.1e-3, r_stem
+    assert r_l0 < 1.4e-3, r_l0
+    assert r_enc < 1.9e-3, r_enc
     d = oracle_tiny.decoder(ck, cv)
-    logits_o = d.step([50258, 50259, 50359, 50364, 1234], 0)
-    sig = logits_h.std()
-    assert np.abs(logits_h - logits_o).max() < 0.1 * sig, (np.abs(logits_h - logits_o).max(), sig)
-    assert np.corrcoef(logits_h, logits_o)[0, 1] > 0.999
+    worst, agree = 0.0, 0
+    for n in range(3, len(ids) + 1):                                                             # positions 2 .. : every one a decision the greedy decoder makes
+        lo = d.step(ids[:3] if n == 3 else ids[n - 1:n], 0 if n == 3 else n - 1)
+        lh = logits_h[n - 1]
+        worst = max(worst, float(np.abs(lh - lo).max() / lh.std()))
+        agree += int(lh.argmax()) == int(lo.argmax())
+    assert worst < 0.008, worst
+    assert agree == len(ids) - 2 >= 20, (agree, len(ids) - 2)
+    print("HF cross-check: conv stem %.2e, layer 0 %.2e, encoder %.2e of range; logits %.4f sigma over %d positions, argmax agrees at all" % (r_stem, r_l0, r_enc, worst, agree))
 
 
 def test_discrete_distribution_restatement_matches_libstdcxx(tmp_path):

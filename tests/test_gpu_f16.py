@@ -207,7 +207,7 @@ def test_teacher_forced_every_step_of_the_full_size_batch(eng, small_model_path)
     assert r["steps_checked"] >= 64 * 60 and all(c["steps"] > 0 for c in r["per_clip"])
     assert r["max_logit_err"] <= LOGIT_ERR_BOUND, r["max_logit_err"]
     assert r["argmax_disagreements"] == 0 or r["max_margin_at_disagreement"] < MARGIN_BOUND, r["max_margin_at_disagreement"]
-    assert r["argmax_disagreements"] <= r["steps_checked"] // 100                 # near-ties are rare (measured ~0.3 % of decisions)
+    assert r["argmax_disagreements"] <= 30, r["argmax_disagreements"]             # near-ties are rare: 18 of 6 473 decisions measured (rounds 4-5), 21-23 in round 3
     # the forced run's accepted tokens ARE the exact run's: same transcripts out of both
     for a, b in zip(r["results_exact"], r["results_forced"]):
         assert _ids(a) == _ids(b) and _segs(a) == _segs(b)

@@ -335,6 +335,39 @@ def _cache_stats():
     return loads.value, hits.value
 
 
+def _workspace_stats():
+    import ctypes as C
+    import os
+    L = C.CDLL(os.path.join(minihost.ROOT, "streamkit_amd", "libwhisper.so"))
+    e, w, n = C.c_int(), C.c_int(), C.c_int()
+    L.skw_whisper_plugin_workspace_stats(C.byref(e), C.byref(w), C.byref(n))
+    return e.value, w.value, n.value
+
+
+def test_workspace_is_returned_with_the_last_instance_and_the_model_stays(plugin, micro_model_path):
+    """the reference caches the CONTEXT (weights) for the life of the process and drops each instance's WhisperState with the instance (lib.rs:160-180, 376-380).
+    The batch workspace is this build's state: the last instance of an engine to go returns it (6.6 GB at 64 rows of Whisper-small), the model stays cached, and the next instance
+    gets a workspace back at creation — no model load, same transcript."""
+    params = {"model_path": micro_model_path, "vad_mode": "always", "flush_tail": True, "gpu_device": 0, "precision": "exact", "max_batch": 3, "max_segment_duration_secs": 17.0}
+    pcm = synth.clip(6, 16000 * 5)
+    a = plugin.create_node(params); b = plugin.create_node(params)
+    e1, w1, n1 = _workspace_stats()
+    loads1 = _cache_stats()[0]
+    _feed(a, pcm); assert a.flush() == 0; out_a = [o[2] for o in a.outputs()]
+    a.destroy()
+    e2, w2, n2 = _workspace_stats()
+    assert (e2, w2, n2) == (e1, w1, n1 - 1)                 # one instance still holds the engine: its workspace stays
+    b.destroy()
+    e3, w3, n3 = _workspace_stats()
+    assert (e3, w3, n3) == (e1, w1 - 1, n1 - 2)             # the last one gone: workspace returned, engine (model) still cached
+    c = plugin.create_node(params)
+    e4, w4, n4 = _workspace_stats()
+    assert (e4, w4, n4) == (e1, w1, n1 - 1) and _cache_stats()[0] == loads1      # back at creation, without a model load
+    _feed(c, pcm); assert c.flush() == 0
+    assert [o[2] for o in c.outputs()] == out_a and len(out_a) == 1
+    c.destroy()
+
+
 def test_model_cache_outlives_its_instances(plugin, micro_model_path):
     """W5 (lib.rs:170-180, 330-374): the context cache holds strong references for the life of the process, which is what prewarm relies on
     (apps/skit/src/plugins.rs:265-306: the prewarm node is dropped at once, the loaded model stays).  create -> destroy -> create: the second
