@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the SURVEY 8(d) config-2 leg through libwhisper.so (N plugin instances fed 960-sample packets)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--gather", default="torch", choices=["torch", "c_abi"], help="N > 1: the transcript gather through torch.distributed (default) or through libskw_dist.so "
+                    "(include/skw_dist.h: the same RCCL all_gather behind the C ABI a non-Python host binds; the 128-byte id travels by a torch.distributed broadcast)")
     return ap.parse_args()
 
 
@@ -207,6 +209,13 @@ def main():
         # communicator set-up is lazy: force it now, outside the timed region, whatever --warmup is
         _w = torch.zeros(1, device=gdev if args.backend == "nccl" else "cpu")
         dist.all_reduce(_w)
+    cgather = None
+    if world > 1 and args.gather == "c_abi":
+        idt = torch.zeros(128, dtype=torch.uint8, device=gdev if args.backend == "nccl" else "cpu")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(skd.CGather.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        cgather = skd.CGather.rank(bytes(idt.cpu().numpy().tobytes()), rank, world, local_rank)
 
     # model (random-init weights of the Whisper-small architecture in whisper.cpp's GGML container; not timed)
     tool = os.path.join(ROOT, "tools", "make_synth_model")
@@ -254,7 +263,10 @@ def main():
         res = ctx.full_batch(None, params, device_ptrs=ptrs, n_samples=ns)
         if world > 1:   # the one exchange step: fixed-size int32 token buffers to every rank over RCCL
             t = time.perf_counter()
-            skd.gather_tokens(skd.pack_tokens(res), world, device=gdev if args.backend == "nccl" else None)
+            if cgather is not None:
+                skd.table_from_gathered(cgather.gather([skd.pack_tokens(res)])[0], world)
+            else:
+                skd.gather_tokens(skd.pack_tokens(res), world, device=gdev if args.backend == "nccl" else None)
             gather_s[0] += time.perf_counter() - t
         return res
 

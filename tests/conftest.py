@@ -53,7 +53,7 @@ def _ensure_built():
         subprocess.check_call(["gcc", "-O2", "-o", tool, tool + ".c", "-lm"])
     if not os.path.exists(os.path.join(ROOT, "oracle", "libskw_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    for lib in ("libskw_engine.so", "libwhisper.so", "libresampler.so", "libskw_minihost.so", "libskw_vad.so", "libskw_tts.so", "libkokoro.so"):
+    for lib in ("libskw_engine.so", "libwhisper.so", "libresampler.so", "libskw_minihost.so", "libskw_vad.so", "libskw_tts.so", "libkokoro.so", "libskw_dist.so"):
         if not os.path.exists(os.path.join(ROOT, "streamkit_amd", lib)):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "streamkit_amd", "csrc")])
             break

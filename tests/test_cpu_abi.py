@@ -35,6 +35,22 @@ def test_vad_library_exports_every_declared_symbol(built):
         assert hasattr(L, n), "libskw_vad.so lacks %s" % n
 
 
+def test_dist_library_exports_every_declared_symbol_and_fails_loudly_without_a_gpu(built):
+    """include/skw_dist.h (the transcript gather over RCCL as a C ABI): every declared entry point is exported; with no GPU a group cannot be made and says why"""
+    L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libskw_dist.so"))
+    names = _declared_functions("skw_dist.h")
+    assert names == ["skw_dist_all_gather_tokens", "skw_dist_create_local", "skw_dist_create_rank", "skw_dist_free", "skw_dist_last_error", "skw_dist_n_local", "skw_dist_unique_id",
+                     "skw_dist_world"]
+    for n in names:
+        assert hasattr(L, n), "libskw_dist.so lacks %s" % n
+    import torch
+    if not torch.cuda.is_available():
+        from streamkit_amd import dist as skd
+        import pytest
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            skd.CGather.local([0])
+
+
 def test_plugin_exports_the_one_symbol(built):
     assert hasattr(C.CDLL(os.path.join(ROOT, "streamkit_amd", "libresampler.so")), "streamkit_native_plugin_api")
     L = C.CDLL(os.path.join(ROOT, "streamkit_amd", "libwhisper.so"))

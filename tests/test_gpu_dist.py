@@ -87,7 +87,44 @@ def test_sharded_oneshot_rccl_all_visible_gpus(small_model_path, tmp_path):
     _check_tables(many, one, om, 64 * R, 30.0, oracle_clips=list(range(R)) + [64 * R - 1])
 
 
+def _fake_rows(rank, n):
+    rng = np.random.default_rng(1000 + rank)
+    rows = np.full((n, 226), -1, np.int32)
+    for i in range(n):
+        k = int(rng.integers(3, 200)); rows[i, 0] = k; rows[i, 1] = int(rng.integers(1, 6)); rows[i, 2:2 + k] = rng.integers(0, 51865, k)
+    return rows
+
+
+def test_c_abi_gather_in_one_process_over_every_visible_gpu():
+    """include/skw_dist.h, the server's shape: ONE process drives a rank per visible GPU (ncclCommInitAll, every rank's all_gather inside one RCCL group) — no rank processes, so
+    neither the pool's process guard nor a launcher is involved.  On the one-GPU test box the group has one rank (the staging, the group call and the layout are exercised); on an
+    8-GPU node it is configs[2]'s exchange: every rank ends up with every rank's [64 x 226] rows, rank-major, bit for bit what streamkit_amd/dist.py's torch.distributed gather
+    lays out.  Also through the per-rank entry points (unique id + create_rank) with a world of one."""
+    import torch
+    from streamkit_amd import dist as skd
+    n_dev = torch.cuda.device_count()
+    g = skd.CGather.local(list(range(n_dev)))
+    L = skd.CGather.lib()
+    assert L.skw_dist_world(g.h) == n_dev and L.skw_dist_n_local(g.h) == n_dev
+    for n in (64, 7, 64):                                                      # (a smaller call after a larger one reuses the staging buffers)
+        send = [_fake_rows(r, n) for r in range(n_dev)]
+        recv = g.gather(send)
+        want = np.concatenate(send, axis=0)
+        for r in range(n_dev):
+            assert np.array_equal(recv[r], want), (n, r)
+        table = skd.table_from_gathered(recv[0], n_dev)
+        assert sorted(table) == list(range(n * n_dev)) and table[0]["ids"] == send[0][0, 2:2 + send[0][0, 0]].tolist()
+    g.close()
+    g1 = skd.CGather.rank(skd.CGather.unique_id(), 0, 1, 0)
+    rows = _fake_rows(5, 64)
+    assert np.array_equal(g1.gather([rows])[0], rows)
+    g1.close()
+    with pytest.raises(RuntimeError, match="devices asked for"):
+        skd.CGather.local(list(range(n_dev + 1)))
+
+
 @pytest.mark.parametrize("size", ["tiny", "small"])
+def test_dynamic_sessions_eight_paced_streams(size):@pytest.mark.parametrize("size", ["tiny", "small"])
 def test_dynamic_sessions_eight_paced_streams(size):
     """configs[3]: 8 live 16 kHz streams fed in 960-sample packets at real time (60 ms), stream i on GPU i mod n_gpus, replicas only.
     Every stream's transcripts equal the oracle's on the segments the (energy) gate cut, and the segment-end -> transcript latency
