@@ -124,7 +124,6 @@ def test_c_abi_gather_in_one_process_over_every_visible_gpu():
 
 
 @pytest.mark.parametrize("size", ["tiny", "small"])
-def test_dynamic_sessions_eight_paced_streams(size):@pytest.mark.parametrize("size", ["tiny", "small"])
 def test_dynamic_sessions_eight_paced_streams(size):
     """configs[3]: 8 live 16 kHz streams fed in 960-sample packets at real time (60 ms), stream i on GPU i mod n_gpus, replicas only.
     Every stream's transcripts equal the oracle's on the segments the (energy) gate cut, and the segment-end -> transcript latency
