@@ -34,7 +34,8 @@ extern "C" skw_dist* skw_dist_create_local(const int* devices, int n, char* err,
     if (!devices || n < 1 || n > n_dev) { set_err(err, errlen, "skw_dist_create_local: %d devices asked for, %d visible", n, n_dev); return nullptr; }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j)
-            if ((j < i && devices[i] == devices[j]) || devices[i] < 0 || devices[i] >= n_dev) { set_err(err, errlen, "skw_dist_create_local: device list must name %d different visible devices", n); return nullptr; }
+            if ((j < i && devices[i] == devices[j]) || devices[i] < 0 || devices[i] >= n_dev) {
+                set_err(err, errlen, "skw_dist_create_local: device list must name %d different visible devices", n); return nullptr; }
     skw_dist* d = new skw_dist(); d->world = n; d->rank0 = 0; d->dev.assign(devices, devices + n); d->comm.assign(n, nullptr);
     ncclResult_t r = ncclCommInitAll(d->comm.data(), n, d->dev.data());
     if (r != ncclSuccess) { set_err(err, errlen, "ncclCommInitAll: %s", ncclGetErrorString(r)); d->comm.clear(); skw_dist_free(d); return nullptr; }
