@@ -734,7 +734,7 @@ static const skw_tts_audio* generate_impl(skw_tts* t, const char* text, int32_t 
     t->cur_chunk = 0; t->cur_off = 0; t->arena_failed = false;
     hipEventRecord(ev.a, t->stream);
     // Kokoro's voices are indexed by length: the published pipeline takes pack[len(phonemes) - 1], and the ids carry the pad id at both ends (T = len + 2): row T - 3
-    // (rounds 3-4 took T - 2; ADVICE r4).  What sherpa-onnx's front end picks for the same text is unpinned (INTEGRATION.md F-5).
+    // (rounds 3-4 took T - 2; ADVICE r4).  What sherpa-onnx's front end picks for the same text is unpinned (INTEGRATION.md F-7).
     const int row = std::min(T - 3, t->voice_rows - 1);
     const float* style = t->voices + ((size_t)sid * t->voice_rows + (size_t)std::max(0, row)) * 2 * STYLE_DIM;
     GpuBackend be(t); be.word_tab = (const float*)t->w.at("bert.embeddings.word_embeddings.weight").dev;
