@@ -6,6 +6,7 @@
 //   shape A   36 x 4 workgroups, 4 strips each, one pass                      (the product's QKV launch)
 //   shape B   12 x 4 workgroups, 12 strips each = q, k, v of one head, as three passes of four strips over the same normalised rows
 //   shape C   12 x 8 workgroups (8-row tiles: half of every MFMA wasted), three passes     (twice the workgroups, twice the weight reads from L2)
+//   shape D / E   the product shape with 8-row tiles (36 x 8) / with two strips per workgroup (72 x 4): more, lighter workgroups
 // Prints microseconds per launch.  The fused kernel's attention half (reading 16 rows' K / V caches through the same CU) comes on top of B / C.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const half_t* Wf, c
 }
 
 int main(int argc, char** argv) {
-    const int M = 64, K = 768, N = 2304, cycle = 24, iters = 480;      // 24 copies x 3.5 MB = 85 MB of weights walked per chain
+    const int M = 64, K = 768, N = 2304, cycle = 96, iters = 480;      // 96 copies x 3.5 MB = 340 MB of weights walked per chain: past the 256 MB Infinity Cache, every launch streams from HBM
     float *x, *gain, *bias; half_t *W, *out;
     CHK(hipMalloc(&x, (size_t)M * K * 4)); CHK(hipMalloc(&gain, K * 4)); CHK(hipMalloc(&bias, K * 4)); CHK(hipMalloc(&W, (size_t)N * K * 2 * cycle)); CHK(hipMalloc(&out, (size_t)M * N * 2));
     { std::vector<float> h((size_t)M * K); unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; } CHK(hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -117,6 +118,8 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep) {
         run("A  product shape: 36 x 4 workgroups, 4 strips, one pass", [&](const half_t* w) { hipLaunchKernelGGL((k_qkv<4, 1>), dim3(36, 4), dim3(256), 0, st, x, w, gain, bias, out, M, N, K, 16, 0); });
         run("B  per head: 12 x 4 workgroups, q k v of one head as 3 passes of 4 strips", [&](const half_t* w) { hipLaunchKernelGGL((k_qkv<4, 3>), dim3(12, 4), dim3(256), 0, st, x, w, gain, bias, out, M, N, K, 16, 48); });
+        run("D  product shape, 8-row tiles: 36 x 8 workgroups, 4 strips, one pass", [&](const half_t* w) { hipLaunchKernelGGL((k_qkv<4, 1>), dim3(36, 8), dim3(256), 0, st, x, w, gain, bias, out, M, N, K, 8, 0); });
+        run("E  product shape, 2 strips: 72 x 4 workgroups, one pass", [&](const half_t* w) { hipLaunchKernelGGL((k_qkv<2, 1>), dim3(72, 4), dim3(256), 0, st, x, w, gain, bias, out, M, N, K, 16, 0); });
         run("C  per head, 8-row tiles: 12 x 8 workgroups, 3 passes", [&](const half_t* w) { hipLaunchKernelGGL((k_qkv<4, 3>), dim3(12, 8), dim3(256), 0, st, x, w, gain, bias, out, M, N, K, 8, 48); });
     }
     return 0;
