@@ -1098,3 +1098,36 @@ void skwo_math(const skwo_model* m, int kind, const float* in, float* out, long 
         out[i] = y;
     }
 }
+
+/* ---- the f16 matrix cores' arithmetic, restated (include/skw_mfma_model.h): checker for the f16_mfma precision's contractions ---- */
+#include "../include/skw_mfma_model.h"
+float skwo_mfma_f16_element(const uint16_t* a32, const uint16_t* b32, float c) { return skw_mfma_f32_16x16x32_f16_element(a32, b32, c); }
+void skwo_mfma_f16_elements(const uint16_t* a, const uint16_t* b, const float* c, float* d, long n) {
+    for (long i = 0; i < n; ++i) d[i] = skw_mfma_f32_16x16x32_f16_element(a + 32 * i, b + 32 * i, c[i]);
+}
+void skwo_mfma_f16_tiles(const uint16_t* A, const uint16_t* B, const float* C, float* D, long P) {
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < P; ++p)
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                uint16_t b[32];
+                for (int k = 0; k < 32; ++k) b[k] = B[(p * 32 + k) * 16 + j];
+                D[(p * 16 + i) * 16 + j] = skw_mfma_f32_16x16x32_f16_element(A + (p * 16 + i) * 32, b, C[(p * 16 + i) * 16 + j]);
+            }
+}
+int skwo_gemm_f16mfma(const uint16_t* A, long lda, const uint16_t* W, long ldw, int M, int N, int K, int n_split, float* C, long ldc) {
+    if (M < 1 || N < 1 || n_split < 1 || K % (32 * n_split)) return -1;
+    const int kpart = K / n_split;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float tot = 0.0f;
+            for (int s = 0; s < n_split; ++s) {
+                float acc = 0.0f;
+                for (int k0 = s * kpart; k0 < (s + 1) * kpart; k0 += 32) acc = skw_mfma_f32_16x16x32_f16_element(A + (long)m * lda + k0, W + (long)n * ldw + k0, acc);
+                tot = s ? tot + acc : acc;
+            }
+            C[(long)m * ldc + n] = tot;
+        }
+    return 0;
+}

@@ -124,6 +124,16 @@ int skwo_debug_rule_ids(const skwo_model*, int kind, int32_t* ids, int cap);
 /* teacher-forced logits (for margin diagnostics): runs window at `seek` with given token prefix */
 
 /* debug taps of encoder layer 0 (l0.ln1, l0.q, l0.k, l0.v, l0.att, l0.x1, l0.ln2, l0.h, l0.x2), natural layouts */
+/* C[m][n] = the f16 matrix cores' contraction of A[m][:] and W[n][:] as the f16_mfma GEMM kernels order it (include/skw_mfma_model.h): operands in MEMORY order (slot 8 g + e of
+ * a 32-block = memory position 8 g + e: what a lane group loads), one v_mfma_f32_16x16x32_f16 per 32-block in ascending order from a zero accumulator; n_split > 1: the K axis
+ * in n_split contiguous parts, each chained from zero, the partial sums added in f32 in ascending order — the decode kernels' four waves.  K % (32 n_split) == 0. */
+int skwo_gemm_f16mfma(const uint16_t* A, long lda, const uint16_t* W, long ldw, int M, int N, int K, int n_split, float* C, long ldc);
+/* one instruction's output element: 32 operand pairs in slot order + accumulator (tests pin this against committed hardware vectors) */
+float skwo_mfma_f16_element(const uint16_t* a32, const uint16_t* b32, float c);
+/* P whole instructions: A P x [16][32] (row i, slot k), B P x [32][16] (slot k, column j), C / D P x [16][16] */
+/* n single elements: a / b n x [32] in slot order, c / d n */
+void skwo_mfma_f16_elements(const uint16_t* a, const uint16_t* b, const float* c, float* d, long n);
+void skwo_mfma_f16_tiles(const uint16_t* A, const uint16_t* B, const float* C, float* D, long P);
 void skwo_debug_enable(int on);
 long skwo_debug_get(const char* name, float* out, size_t cap);
 

@@ -1705,6 +1705,61 @@ extern "C" long skw_debug_gemm16_compare(skw_ctx* c, int M, int N, int K, int ep
     return diff;
 }
 
+// tests (tests/test_gpu_mfma_model.py): P independent v_mfma_f32_16x16x32_f16 instructions — A: P x [16][32] f16 (row i, slot k), B: P x [32][16] f16 (slot k, column j), C / D: P x [16][16] f32 —
+// what the committed hardware vectors (tests/golden/mfma_f16_hw_vectors.npz) were taken with and are re-taken with on every GPU run
+__global__ void k_debug_mfma16x32(const half_t* A, const half_t* B, const float* C, float* D) {
+    const int p = blockIdx.x, l = threadIdx.x, r16 = l & 15, g = l >> 4;
+    const half_t* a = A + (size_t)p * 512; const half_t* b = B + (size_t)p * 512; const float* c = C + (size_t)p * 256; float* d = D + (size_t)p * 256;
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f16x8 fa, fb;
+    for (int e = 0; e < 8; ++e) { fa[e] = a[r16 * 32 + 8 * g + e]; fb[e] = b[(8 * g + e) * 16 + r16]; }      // lane (row / column r16, group g) holds slots 8 g .. 8 g + 7
+    f32x4 acc; for (int r = 0; r < 4; ++r) acc[r] = c[(4 * g + r) * 16 + r16];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) d[(4 * g + r) * 16 + r16] = acc[r];
+}
+extern "C" int skw_debug_mfma16x32(skw_ctx* c, long P, const uint16_t* A_host, const uint16_t* B_host, const float* C_host, float* D_host) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (P < 1 || P > (1 << 20)) { snprintf(errbuf, 512, "skw_debug_mfma16x32: bad problem count"); return -1; }
+    char* buf = nullptr;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess) { snprintf(errbuf, 512, "skw_debug_mfma16x32: %s", hipGetErrorString(e)); hipFree(buf); return false; } return true; };
+    if (!chk(hipMalloc((void**)&buf, (size_t)P * 4096))) return -1;
+    half_t* A = (half_t*)buf; half_t* B = (half_t*)(buf + P * 1024); float* C = (float*)(buf + P * 2048); float* D = (float*)(buf + P * 3072);
+    if (!chk(hipMemcpy(A, A_host, P * 1024, hipMemcpyHostToDevice)) || !chk(hipMemcpy(B, B_host, P * 1024, hipMemcpyHostToDevice))) return -1;
+    if (!chk(hipMemcpy(C, C_host, P * 1024, hipMemcpyHostToDevice))) return -1;
+    hipLaunchKernelGGL(k_debug_mfma16x32, dim3((unsigned)P), dim3(64), 0, c->stream, A, B, C, D);
+    if (!chk(hipStreamSynchronize(c->stream)) || !chk(hipGetLastError()) || !chk(hipMemcpy(D_host, D, P * 1024, hipMemcpyDeviceToHost))) return -1;
+    hipFree(buf);
+    return 0;
+}
+// tests (tests/test_gpu_mfma_model.py): C = A . W^T through one of the f16_mfma GEMM kernels, plain f32 epilogue (no bias, no residual), operands given as f16 bit patterns in the
+// kernels' memory order ([M][K] and [N][K], K axis as the kernels load it) — to be compared bit for bit with oracle/'s restatement of the matrix cores (skwo_gemm_f16mfma).
+// kernel: 0 = k_gemm16w (weights from a fragment-order image), 1 = k_gemm16 (both operands through LDS), 2 = the decode step's product: k_gemm16_small (four waves split K) for N < 8192,
+// k_gemm16_vocab (one wave chains the whole K) from there on
+extern "C" int skw_debug_gemm16_out(skw_ctx* c, int kernel, int M, int N, int K, const uint16_t* A_host, const uint16_t* W_host, float* C_host) {
+    char* errbuf = c->errbuf; HIPCHK(hipSetDevice(c->m->device));
+    if (M < 1 || (N & 15) || (K & 127) || kernel < 0 || kernel > 2) { snprintf(errbuf, 512, "skw_debug_gemm16_out: bad geometry"); return -1; }
+    half_t *A = nullptr, *W = nullptr, *Wf = nullptr; float* C = nullptr;
+    auto cleanup = [&]() { hipFree(A); hipFree(W); hipFree(Wf); hipFree(C); };
+    auto chk = [&](hipError_t e) { if (e != hipSuccess) { snprintf(errbuf, 512, "skw_debug_gemm16_out: %s", hipGetErrorString(e)); cleanup(); return false; } return true; };
+    if (!chk(hipMalloc((void**)&A, (size_t)M * K * 2)) || !chk(hipMalloc((void**)&W, (size_t)N * K * 2)) || !chk(hipMalloc((void**)&Wf, (size_t)N * K * 2))) return -1;
+    if (!chk(hipMalloc((void**)&C, (size_t)M * N * 4)) || !chk(hipMemset(C, 0xAB, (size_t)M * N * 4))) return -1;
+    if (!chk(hipMemcpy(A, A_host, (size_t)M * K * 2, hipMemcpyHostToDevice)) || !chk(hipMemcpy(W, W_host, (size_t)N * K * 2, hipMemcpyHostToDevice))) return -1;
+    skw_make_wfrag(W, K, N, K, 0, Wf, c->stream);
+    SkwGemmArgs a{}; a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = N; a.epi = EPI_F32; a.scale = 1.0f;
+    (void)skw_sw(0);
+    const int w_was = g_sw_val[SW_GEMM16W];
+    if (kernel == 2) { a.Wf = Wf; if (!skw_gemm16_small(a, c->stream)) { snprintf(errbuf, 512, "skw_debug_gemm16_out: k_gemm16_small does not take this geometry"); cleanup(); return -1; } }
+    else {
+        a.Wf = kernel == 0 ? Wf : nullptr; g_sw_val[SW_GEMM16W] = kernel == 0 ? 1 : 0;
+        if (kernel == 0 && !skw_gemm16_takes_w(a)) { g_sw_val[SW_GEMM16W] = w_was; snprintf(errbuf, 512, "skw_debug_gemm16_out: k_gemm16w does not take this geometry"); cleanup(); return -1; }
+        skw_gemm16(a, c->stream); g_sw_val[SW_GEMM16W] = w_was;
+    }
+    if (!chk(hipStreamSynchronize(c->stream)) || !chk(hipGetLastError()) || !chk(hipMemcpy(C_host, C, (size_t)M * N * 4, hipMemcpyDeviceToHost))) return -1;
+    cleanup();
+    return 0;
+}
+
 // the launch clock's records (SkwKClk, skw_kernels.h): one clock per (row group, decoder layer) graph node
 static const int KCLK_CAP = 1024;                                       // launches recorded per node and call (a 30 s window is <= 466 steps)
 static size_t kclk_node_bytes() { return sizeof(SkwKClk) + sizeof(SkwKClkRec) * SKW_KCLK_SHARDS * (KCLK_CAP - 1); }

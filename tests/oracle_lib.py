@@ -71,6 +71,13 @@ def lib():
         L.skwo_segment_sim.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_void_p, C.c_int]
         L.skwo_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
         L.skwo_debug_enable.argtypes = [C.c_int]
+        L.skwo_mfma_f16_element.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.skwo_mfma_f16_element.restype = C.c_float
+        L.skwo_mfma_f16_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.skwo_mfma_f16_tiles.restype = None
+        L.skwo_mfma_f16_elements.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.skwo_mfma_f16_elements.restype = None
+        L.skwo_gemm_f16mfma.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long]
         L.skwo_debug_get.restype = C.c_long
         L.skwo_debug_get.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         _LIB = L
@@ -213,3 +220,34 @@ class OracleResampler:
         n = lib().skwo_resampler_process(self.h, planar.ctypes.data, out.ctypes.data, cap)
         assert n >= 0
         return out[:, :n].copy()
+
+
+def mfma_f16_tiles(A, B, Cc):
+    """P instructions of v_mfma_f32_16x16x32_f16 as oracle/ restates them: A [P][16][32] u16, B [P][32][16] u16, C [P][16][16] f32 -> D."""
+    A = np.ascontiguousarray(A, np.uint16); B = np.ascontiguousarray(B, np.uint16); Cc = np.ascontiguousarray(Cc, np.float32)
+    P = A.shape[0]
+    assert A.shape == (P, 16, 32) and B.shape == (P, 32, 16) and Cc.shape == (P, 16, 16)
+    D = np.empty((P, 16, 16), np.float32)
+    lib().skwo_mfma_f16_tiles(A.ctypes.data, B.ctypes.data, Cc.ctypes.data, D.ctypes.data, P)
+    return D
+
+
+def mfma_f16_elements(a, b, c):
+    """n single output elements: a, b [n][32] u16 in slot order, c [n] f32 -> d [n]."""
+    a = np.ascontiguousarray(a, np.uint16); b = np.ascontiguousarray(b, np.uint16); c = np.ascontiguousarray(c, np.float32)
+    assert a.shape == b.shape == (len(c), 32)
+    d = np.empty(len(c), np.float32)
+    lib().skwo_mfma_f16_elements(a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, len(c))
+    return d
+
+
+def gemm_f16mfma(A, W, n_split=1):
+    """C[m][n] = the matrix cores' contraction of A[m][:] (u16 f16 bits, [M][K]) and W[n][:] ([N][K]) in the f16_mfma GEMM kernels' order (skwo_gemm_f16mfma)."""
+    A = np.ascontiguousarray(A, np.uint16); W = np.ascontiguousarray(W, np.uint16)
+    M, K = A.shape; N = W.shape[0]
+    assert W.shape[1] == K
+    out = np.empty((M, N), np.float32)
+    r = lib().skwo_gemm_f16mfma(A.ctypes.data, K, W.ctypes.data, K, M, N, K, n_split, out.ctypes.data, N)
+    if r != 0:
+        raise ValueError("skwo_gemm_f16mfma refused M %d N %d K %d n_split %d" % (M, N, K, n_split))
+    return out
