@@ -916,6 +916,83 @@ static void acc_push_seg(acc_t* a, const skwo_model* m, int64_t t0, int64_t t1, 
     for (int i = i0; i < i1; ++i) a->tok[a->n_tok++] = toks[i];
     s->tok_end = a->n_tok; s->text_off = a->n_text; s->text_len = tl; memcpy(a->text + a->n_text, text, tl); a->n_text += tl; a->text[a->n_text] = 0;
 }
+/* One sampled token's effect on the window's bookkeeping (the body of whisper_full_with_state's token loop, between sampling and the next decoder step; recalled — see the file
+ * header): seek_delta / result_len follow the last timestamp token above <|0.00|>, a timestamp that steps BACK fails the pass, the pass completes at <|endoftext|>, at max_tokens,
+ * or when the timestamps reach the end of the audio, and fails when the token budget runs out before half a window is covered.  0 = go on, non-zero = leave the loop
+ * (dc->completed or dc->failed says which).  Shared by skwo_full and by skwo_debug_window, which tests/test_cpu_segment_rules.py holds against an independent implementation. */
+static int token_loop_update(const skwo_model* m, const skwo_params* p, decoder_t* dc, int id, int i, int seek, int seek_end, int n_max) {
+    if (id > m->tok_beg) {
+        const int seek_delta_new = 2 * (id - m->tok_beg);
+        if (dc->has_ts && dc->seek_delta > seek_delta_new && dc->result_len < i) { dc->failed = 1; return 1; }
+        dc->seek_delta = seek_delta_new; dc->result_len = i + 1; dc->has_ts = 1;
+    }
+    if (id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc->has_ts && seek + dc->seek_delta + DELTA_MIN >= seek_end)) {
+        if (dc->result_len == 0 && !p->no_timestamps) {
+            if (seek + dc->seek_delta + DELTA_MIN >= seek_end) dc->result_len = i + 1;
+            else { dc->failed = 1; return 1; }
+        }
+        if (p->single_segment || p->no_timestamps) { dc->result_len = i + 1; dc->seek_delta = 100 * WHISPER_CHUNK_SIZE; }
+        dc->completed = 1; return 1;
+    }
+    if (i == n_max - 1 && (dc->result_len == 0 || dc->seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dc->failed = 1; return 1; }
+    return 0;
+}
+/* The window's output step (whisper_full_with_state after the temperature ladder; recalled): the kept tokens dc->tokens[0 .. n_tokens) are cut into segments at timestamp tokens
+ * above <|0.00|> (a run of timestamps closes one segment; a trailing piece of text ends at seek + seek_delta), and the window advances by seek_delta — or, when the tokens end
+ * "text, timestamp" (nothing spoken after the last timestamp), by what is left of the chunk.  Returns that advance (10 ms frames).  text: scratch of >= 64 KiB. */
+static int window_output(const skwo_model* m, const skwo_params* p, const decoder_t* dc, int seek, int seek_end, int is_no_speech, acc_t* acc, char* text) {
+    int seek_delta = dc->seek_delta; const skwo_token* tc = dc->tokens; const int ntc = dc->n_tokens;
+    if (ntc > 0 && !is_no_speech) {
+        int i0 = 0; int64_t t0 = seek + 2 * (tc[0].tid - m->tok_beg); int tl = 0;
+        for (int i = 0; i < ntc; ++i) {
+            if (tc[i].id < m->tok_eot) { memcpy(text + tl, m->tok_str[tc[i].id], m->tok_len[tc[i].id]); tl += m->tok_len[tc[i].id]; }
+            if (tc[i].id > m->tok_beg && !p->single_segment) {
+                const int64_t t1 = seek + 2 * (tc[i].tid - m->tok_beg);
+                if (tl > 0) acc_push_seg(acc, m, t0, t1, text, tl, tc, i0, i + 1);
+                tl = 0;
+                while (i < ntc && tc[i].id > m->tok_beg) i++;
+                i--; t0 = t1; i0 = i + 1;
+            }
+        }
+        if (tl > 0) { const int64_t t1 = seek + seek_delta; acc_push_seg(acc, m, t0, t1, text, tl, tc, i0, ntc); }
+    }
+    const int single_timestamp_ending = ntc > 1 && tc[ntc - 2].id < m->tok_beg && tc[ntc - 1].id > m->tok_beg;
+    if (single_timestamp_ending) { int a = seek_end - seek, b = WHISPER_CHUNK_SIZE * 100; seek_delta = a < b ? a : b; }
+    return seek_delta;
+}
+
+/* test hook (tests/test_cpu_segment_rules.py): ONE window's bookkeeping and output on a caller-supplied stream of sampled token ids — toks[0 .. n) as whisper_full_with_state's token
+ * loop would have received them one by one (it stops by itself: <|endoftext|>, a timestamp at the end of the audio, a failure) — for a window at `seek` of audio ending at
+ * `seek_end` (10 ms frames).  Out: per segment (t0, t1) in seg_t[2 i ..] and its token ids in seg_tokens[seg_off[i] .. seg_off[i + 1]); the segment count, the advance of seek,
+ * how many tokens were kept, how many of toks the loop consumed, and whether the pass failed (then nothing else is meaningful).  Shares token_loop_update and window_output with
+ * skwo_full.  Buffers: max_seg segments, n token ids. */
+int skwo_debug_window(const skwo_model* m, const skwo_params* p, const int32_t* toks, int n, int seek, int seek_end, int64_t* seg_t, int32_t* seg_off, int32_t* seg_tokens,
+                      int max_seg, int* n_seg, int* advance, int* n_kept, int* n_consumed, int* failed) {
+    decoder_t dc; memset(&dc, 0, sizeof dc);
+    dc.cap = n + 1; dc.tokens = (skwo_token*)calloc(dc.cap, sizeof(skwo_token));
+    dc.seek_delta = 100 * WHISPER_CHUNK_SIZE;
+    const int n_max = m->hp.n_text_ctx / 2 - 4;
+    int i = 0;
+    for (; i < n && i < n_max; ++i) {
+        skwo_token tk; memset(&tk, 0, sizeof tk); tk.id = toks[i]; tk.tid = toks[i] >= m->tok_beg ? toks[i] : (i > 0 ? dc.tokens[i - 1].tid : m->tok_beg);
+        dc.tokens[dc.n_tokens++] = tk;
+        if (token_loop_update(m, p, &dc, tk.id, i, seek, seek_end, n_max)) { ++i; break; }
+    }
+    *n_consumed = i; *failed = dc.failed; *n_seg = 0; *advance = 0; *n_kept = 0;
+    if (dc.failed) { free(dc.tokens); return 0; }
+    dc.n_tokens = dc.result_len; *n_kept = dc.result_len;
+    acc_t acc; memset(&acc, 0, sizeof acc);
+    char* text = (char*)malloc(1 << 16);
+    *advance = window_output(m, p, &dc, seek, seek_end, 0, &acc, text);
+    seg_off[0] = 0;
+    for (int s = 0; s < acc.n_seg && s < max_seg; ++s) {
+        seg_t[2 * s] = acc.seg[s].t0; seg_t[2 * s + 1] = acc.seg[s].t1; seg_off[s + 1] = acc.seg[s].tok_end;
+        for (int k = acc.seg[s].tok_begin; k < acc.seg[s].tok_end; ++k) seg_tokens[k] = acc.tok[k].id;
+    }
+    *n_seg = acc.n_seg < max_seg ? acc.n_seg : max_seg;
+    free(acc.seg); free(acc.tok); free(acc.text); free(text); free(dc.tokens);
+    return 0;
+}
 
 /* whisper_full_with_state, greedy strategy with best_of = 1 (lib.rs:624): one decoder, argmax at t = 0, std::discrete_distribution
  * draws from the decoder's mt19937 on the fallback passes.  DEVIATION D2': the generator is seeded (0) per call; whisper.cpp seeds it
@@ -995,22 +1072,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
                 skwo_token tk = (t_cur < 1e-6f) ? sample_best(m, &dc) : sample_dist(m, &dc, &rng);
                 if (dc.n_tokens == dc.cap) { dc.cap *= 2; dc.tokens = (skwo_token*)realloc(dc.tokens, dc.cap * sizeof(skwo_token)); }
                 dc.tokens[dc.n_tokens++] = tk; dc.sum_logprobs_all += tk.plog;
-                {
-                    if (tk.id > m->tok_beg) {
-                        const int seek_delta_new = 2 * (tk.id - m->tok_beg);
-                        if (dc.has_ts && dc.seek_delta > seek_delta_new && dc.result_len < i) { dc.failed = 1; break; }
-                        dc.seek_delta = seek_delta_new; dc.result_len = i + 1; dc.has_ts = 1;
-                    }
-                    if (tk.id == m->tok_eot || (p->max_tokens > 0 && i >= p->max_tokens) || (dc.has_ts && seek + dc.seek_delta + DELTA_MIN >= seek_end)) {
-                        if (dc.result_len == 0 && !p->no_timestamps) {
-                            if (seek + dc.seek_delta + DELTA_MIN >= seek_end) dc.result_len = i + 1;
-                            else { dc.failed = 1; break; }
-                        }
-                        if (p->single_segment || p->no_timestamps) { dc.result_len = i + 1; dc.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
-                        dc.completed = 1; break;
-                    }
-                }
-                if (i == n_max - 1 && (dc.result_len == 0 || dc.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dc.failed = 1; break; }
+                if (token_loop_update(m, p, &dc, tk.id, i, seek, seek_end, n_max)) break;
                 { int32_t t = tk.id; skwo_dec_step(ds, &t, 1, n_prompt_cur + i, 0, raw); out->n_decode_steps++; }
                 process_logits(m, p, &dc, raw, &no_speech_prob, t_cur);
             }
@@ -1033,22 +1095,8 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
                 for (int i = 0; i < last_take; ++i) prompt_past[n_past_tok++] = keep[i];
                 if (!is_no_speech) for (int i = 0; i < dc.result_len; ++i) prompt_past[n_past_tok++] = tc[i].id;
             }
-            if (ntc > 0 && !is_no_speech) {
-                int i0 = 0; int64_t t0 = seek + 2 * (tc[0].tid - m->tok_beg); int tl = 0;
-                for (int i = 0; i < ntc; ++i) {
-                    if (tc[i].id < m->tok_eot) { memcpy(text + tl, m->tok_str[tc[i].id], m->tok_len[tc[i].id]); tl += m->tok_len[tc[i].id]; }
-                    if (tc[i].id > m->tok_beg && !p->single_segment) {
-                        const int64_t t1 = seek + 2 * (tc[i].tid - m->tok_beg);
-                        if (tl > 0) acc_push_seg(&acc, m, t0, t1, text, tl, tc, i0, i + 1);
-                        tl = 0;
-                        while (i < ntc && tc[i].id > m->tok_beg) i++;
-                        i--; t0 = t1; i0 = i + 1;
-                    }
-                }
-                if (tl > 0) { const int64_t t1 = seek + seek_delta; acc_push_seg(&acc, m, t0, t1, text, tl, tc, i0, ntc); }
-            }
-            const int single_timestamp_ending = ntc > 1 && tc[ntc - 2].id < m->tok_beg && tc[ntc - 1].id > m->tok_beg;
-            if (single_timestamp_ending) { int a = seek_end - seek, b = WHISPER_CHUNK_SIZE * 100; seek_delta = a < b ? a : b; }
+            (void)tc; (void)ntc;
+            seek_delta = window_output(m, p, &dc, seek, seek_end, is_no_speech, &acc, text);
             seek += seek_delta;
         }
         if (dc.min_margin < out->min_margin) out->min_margin = dc.min_margin;

@@ -134,6 +134,9 @@ float skwo_mfma_f16_element(const uint16_t* a32, const uint16_t* b32, float c);
 /* n single elements: a / b n x [32] in slot order, c / d n */
 void skwo_mfma_f16_elements(const uint16_t* a, const uint16_t* b, const float* c, float* d, long n);
 void skwo_mfma_f16_tiles(const uint16_t* A, const uint16_t* B, const float* C, float* D, long P);
+/* test hook: one window's token-loop bookkeeping and segment assembly on a given stream of sampled token ids (skw_oracle.c) */
+int skwo_debug_window(const skwo_model* m, const skwo_params* p, const int32_t* toks, int n, int seek, int seek_end, int64_t* seg_t, int32_t* seg_off, int32_t* seg_tokens,
+                      int max_seg, int* n_seg, int* advance, int* n_kept, int* n_consumed, int* failed);
 void skwo_debug_enable(int on);
 long skwo_debug_get(const char* name, float* out, size_t cap);
 
