@@ -282,6 +282,10 @@ static skw_model* model_load_impl(const char* path, int device, int quant_mode, 
     // fragment-order images of the decoder projections (SkwGemmArgs::Wf); =0: the f16 decode kernels read weight rows
     const bool wfrag_on = skw_sw(SW_DEC_WFRAG) != 0;
     ok = ok && up_lin(m, ts, "encoder.conv1.weight", "encoder.conv1.bias", &m->conv1, err, errlen);
+    // conv1 runs as a product over the im2col image [frames][3 n_mels padded]: the f16 GEMMs step K by 64 (80 bands: 240 -> 256, large-v3's 128: 384)
+    if (ok && ((m->conv1.k_pad & 63) || m->conv1.n_in != 3 * m->hp.n_mels || m->hp.n_mels > 128)) {
+        set_err(err, errlen, "encoder.conv1.weight: 3 x n_mels = %d taps do not pad to a multiple of 64 (n_mels 80 and 128 are supported)", m->conv1.n_in); ok = false;
+    }
     ok = ok && up_lin(m, ts, "encoder.conv2.weight", "encoder.conv2.bias", &m->conv2, err, errlen);
     ok = ok && up_ln(m, ts, "encoder.ln_post.weight", "encoder.ln_post.bias", &m->ln_post, err, errlen);
     m->enc.resize(m->hp.n_audio_layer);
@@ -563,7 +567,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     want("seek", c->seek, B, false);
     want("row_tok", c->row_tok, B, true);
     want("prompt_buf", c->prompt_buf, (size_t)B * SKW_PROMPT_CAP, true);
-    want("im2col", c->im2col, (size_t)B * T * 256, false);
+    want("im2col", c->im2col, (size_t)B * T * c->m->conv1.k_pad, false);
     want("h1", c->h1, (size_t)B * (T + 2) * d, true);
     // encoder
     want("x", c->x, enc_rows * d, false);
@@ -792,8 +796,8 @@ static void run_mel(skw_ctx* c, int n) {
 // buffers are scratch, so the Bw - row0 computed windows sit at their start
 static void run_conv(skw_ctx* c, int Bw_all, int row0 = 0) {
     skw_model* m = c->m; const int nc = m->hp.n_audio_ctx, T = 2 * nc, d = m->hp.n_audio_state; const int Bw = Bw_all - row0;
-    skw_mel_im2col(c->mel, c->clip_idx + row0, c->seek + row0, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, c->im2col, c->stream);
-    SkwGemmArgs a = gemm_args(c->im2col, 256, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
+    skw_mel_im2col(c->mel, c->clip_idx + row0, c->seek + row0, c->n_len, Bw, c->n_len_max, m->hp.n_mels, T, m->conv1.k_pad, c->im2col, c->stream);
+    SkwGemmArgs a = gemm_args(c->im2col, m->conv1.k_pad, m->conv1, Bw * T, c->h1, d, EPI_GELU_F16_KPERM_ROWPAD); a.gelu_tab = m->gelu_tab; a.n_ctx = T;
     GEMM(c, a, m->conv1.n_in);
     SkwGemmArgs b = gemm_args(c->h1, 2L * d, m->conv2, Bw * nc, c->x, d, EPI_CONV2); b.a_rows_per_batch = nc; b.a_batch_stride = (long)(T + 2) * d;
     b.gelu_tab = m->gelu_tab; b.pe = m->e_pe; b.n_ctx = nc;

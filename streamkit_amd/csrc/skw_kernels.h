@@ -115,7 +115,7 @@ void skw_mel_frames(const float* pcm, const long* pcm_off, const int* n_samples,
 // per-clip max -> clamp (max-8) and (x+4)/4, in place; tmp: [B] doubles
 void skw_mel_normalize(float* mel, const int* n_len, int B, int n_len_max, int n_mel, float* clip_max, hipStream_t s);
 // build conv1's im2col rows for the window starting at seek[b]: out f16 [b*T + t][256 kperm] (k = tap*n_mel + c, zero padded to 256)
-void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, half_t* out, hipStream_t s);
+void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, int k_pad, half_t* out, hipStream_t s);
 
 // ---------------- decoder ----------------
 // x[b][d] = f32(te[tok[b]][kperm(i)]) + pe[pos[b]][i]

@@ -734,19 +734,21 @@ void skw_mel_normalize(float* mel, const int* n_len, int B, int n_len_max, int n
     hipLaunchKernelGGL(k_mel_max, dim3(64, B), dim3(256), 0, s, mel, n_len, n_len_max, n_mel, (unsigned*)clip_max);
     hipLaunchKernelGGL(k_mel_norm, dim3(64, B), dim3(256), 0, s, mel, n_len, n_len_max, n_mel, (const unsigned*)clip_max);
 }
-// conv1 im2col: out[(bw*T + t)][kperm(k)], k = tap*n_mel + c (k < 3*n_mel), zero padded to 256
-__global__ void k_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int n_len_max, int n_mel, int T, half_t* out) {
-    const int bw = blockIdx.y, t = blockIdx.x, k = threadIdx.x;   // 256 threads
+// conv1 im2col: out[(bw*T + t)][kperm(k)], k = tap*n_mel + c (k < 3*n_mel), zero padded to k_pad (256 for 80 bands, 384 for large-v3's 128: the width of the conv1 weight image)
+__global__ void k_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int n_len_max, int n_mel, int T, int k_pad, half_t* out) {
+    const int bw = blockIdx.y, t = blockIdx.x;   // 256 threads
     const int clip = clip_idx[bw], sk = seek[bw], nl = n_len[clip];
-    float v = 0.0f;
-    if (k < 3 * n_mel) {
-        int tap = k / n_mel, c = k % n_mel; int tt = t - 1 + tap; int fr = sk + tt;
-        if (tt >= 0 && tt < T && fr < nl) v = mel[((long)clip * n_len_max + fr) * n_mel + c];
+    for (int k = threadIdx.x; k < k_pad; k += blockDim.x) {
+        float v = 0.0f;
+        if (k < 3 * n_mel) {
+            int tap = k / n_mel, c = k % n_mel; int tt = t - 1 + tap; int fr = sk + tt;
+            if (tt >= 0 && tt < T && fr < nl) v = mel[((long)clip * n_len_max + fr) * n_mel + c];
+        }
+        out[((long)bw * T + t) * k_pad + skw_kperm(k)] = f2h(v);
     }
-    out[((long)bw * T + t) * 256 + skw_kperm(k)] = f2h(v);
 }
-void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, half_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_mel_im2col, dim3(T, Bw), dim3(256), 0, s, mel, clip_idx, seek, n_len, n_len_max, n_mel, T, out);
+void skw_mel_im2col(const float* mel, const int* clip_idx, const int* seek, const int* n_len, int Bw, int n_len_max, int n_mel, int T, int k_pad, half_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mel_im2col, dim3(T, Bw), dim3(256), 0, s, mel, clip_idx, seek, n_len, n_len_max, n_mel, T, k_pad, out);
 }
 
 // ------------------------------------------------------------------ decoder pieces

@@ -60,19 +60,22 @@ def _ensure_built():
     return tool
 
 
-def synth_model(size, seed=1234):
+def synth_model(size, seed=1234, vocab=51865, mels=80, layers=None):
+    """vocab 51864: the English-only files' vocabulary (*.en, the reference's default model); 51866 + mels 128: large-v3's; layers=(encoder, decoder): turbo's unequal counts"""
     tool = _ensure_built()
-    path = "/tmp/skw_test_%s_%d.bin" % (size, seed)
+    tag = size + ("" if (vocab, mels) == (51865, 80) else "_v%d_m%d" % (vocab, mels)) + ("_l%d_%d" % layers if layers else "")
+    path = "/tmp/skw_test_%s_%d.bin" % (tag, seed)
     if not os.path.exists(path):
-        subprocess.check_call([tool, path + ".tmp", "--size", size, "--seed", str(seed)])
+        extra = ["--audio-layers", str(layers[0]), "--text-layers", str(layers[1])] if layers else []
+        subprocess.check_call([tool, path + ".tmp", "--size", size, "--seed", str(seed), "--vocab", str(vocab), "--mels", str(mels)] + extra)
         os.replace(path + ".tmp", path)
     return path
 
 
-def quantized_model(size, kind, seed=1234):
+def quantized_model(size, kind, seed=1234, vocab=51865, mels=80):
     """The synthetic model re-encoded with block-quantised 2-D weights (tools/quantize_ggml.py), as whisper.cpp's quantize tool lays them out."""
-    src = synth_model(size, seed)
-    path = "/tmp/skw_test_%s_%d_%s.bin" % (size, seed, kind)
+    src = synth_model(size, seed, vocab, mels)
+    path = src[:-4] + "_%s.bin" % kind
     if not os.path.exists(path):
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "quantize_ggml.py"), src, path + ".tmp", kind])
         os.replace(path + ".tmp", path)

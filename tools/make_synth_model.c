@@ -17,7 +17,7 @@
  * the audio through the full encoder/decoder stack, so parity tests on the
  * emitted token ids exercise every kernel.  See DESIGN.md §"Synthetic model".
  *
- * usage: make_synth_model OUT.bin [--size tiny|base|small] [--seed N] [--f32]
+ * usage: make_synth_model OUT.bin [--size tiny|base|small] [--vocab 51864|51865|51866] [--mels 80|128] [--seed N] [--f32]
  *                         [--key value ...]   (see `knobs` below)
  */
 #include <math.h>
@@ -152,7 +152,7 @@ static void vocab_token(int i, char* buf) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s OUT.bin [--size tiny|base|small] [--seed N] [--f32] [--knob value]...\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s OUT.bin [--size tiny|base|small] [--vocab N] [--mels N] [--seed N] [--f32] [--knob value]...\n", argv[0]); return 2; }
     hparams_t hp = {51865, 1500, 768, 12, 12, 448, 768, 12, 12, 80, 1};
     for (int a = 2; a < argc; ++a) {
         if (!strcmp(argv[a], "--size") && a + 1 < argc) {
@@ -167,6 +167,13 @@ int main(int argc, char** argv) {
             else if (!strcmp(s, "w1280")) { hp.n_audio_state = hp.n_text_state = 1280; hp.n_audio_head = hp.n_text_head = 20; hp.n_audio_layer = hp.n_text_layer = 1; }
             else { fprintf(stderr, "unknown size %s\n", s); return 2; }
         } else if (!strcmp(argv[a], "--seed") && a + 1 < argc) g_seed = strtoull(argv[++a], NULL, 0);
+        /* the other vocabularies and front ends of the model zoo: 51864 = the English-only files (*.en: the reference's default, plugins/native/whisper/src/lib.rs:68-70 — no language /
+         * task tokens, every special id one lower), 51866 = large-v3 (one more language); --mels 128 = large-v3's filterbank */
+        else if (!strcmp(argv[a], "--vocab") && a + 1 < argc) { hp.n_vocab = atoi(argv[++a]); if (hp.n_vocab < 51864 || hp.n_vocab > 51866) { fprintf(stderr, "--vocab 51864 | 51865 | 51866\n"); return 2; } }
+        /* large-v3-turbo keeps large's 32 encoder layers and has 4 decoder layers: the two counts are independent header fields */
+        else if (!strcmp(argv[a], "--audio-layers") && a + 1 < argc) hp.n_audio_layer = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--text-layers") && a + 1 < argc) hp.n_text_layer = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--mels") && a + 1 < argc) { hp.n_mels = atoi(argv[++a]); if (hp.n_mels != 80 && hp.n_mels != 128) { fprintf(stderr, "--mels 80 | 128\n"); return 2; } }
         else if (!strcmp(argv[a], "--f32")) g_f16 = 0;
         else if (!strncmp(argv[a], "--", 2) && a + 1 < argc) {
             int ok = 0; for (knob_t* k = knobs; k->name; ++k) if (!strcmp(k->name, argv[a] + 2)) { *k->v = atof(argv[++a]); ok = 1; break; }
@@ -214,7 +221,8 @@ int main(int argc, char** argv) {
     /* ---------------- decoder ---------------- */
     const int R = 16, D0 = dt - R, c0 = D0, c1 = D0 + 1, ctc = D0 + 2, NF = 4;
     const double freqs[4] = {1.0, 3.0, 9.0, 27.0};
-    const int tok_eot = 50257, tok_beg = 50364;
+    const int multilingual = hp.n_vocab >= 51865;      /* whisper.cpp's is_multilingual(): the special ids sit one lower without it, and large-v3's extra language moves those after the languages up */
+    const int tok_eot = multilingual ? 50257 : 50256, tok_beg = multilingual ? 50364 + (hp.n_vocab - 51865) : 50363;
     { /* positional embedding [n_text_ctx][dt] */
         int ne[2] = {dt, hp.n_text_ctx}; float* d = gen_uniform("decoder.positional_embedding", (size_t)dt * hp.n_text_ctx, k_pos_scale);
         for (int p = 0; p < hp.n_text_ctx; ++p) {
@@ -222,9 +230,10 @@ int main(int argc, char** argv) {
             for (int i = D0; i < dt; ++i) row[i] = 0.0f;
             double t = (p - k_eot_p0) / (k_eot_p1 - k_eot_p0); if (t < 0) t = 0; if (t > 1) t = 1;
             row[c0] = (float)(k_eot_lo + (k_eot_hi - k_eot_lo) * t);
-            int q = p - 2; int on = (q >= 0) && (fmod((double)q, k_ts_period) < 0.5);
+            const int p_first = multilingual ? 2 : 0;      /* position of the last prompt token (sot, language, task | sot alone): the first sampled token's input */
+            int q = p - p_first; int on = (q >= 0) && (fmod((double)q, k_ts_period) < 0.5);
             row[c1] = (float)(on ? k_ts_on : k_ts_off);
-            double ktarget = k_ts_speed * (p - 2); if (ktarget < 0) ktarget = 0;
+            double ktarget = k_ts_speed * (p - p_first); if (ktarget < 0) ktarget = 0;
             for (int m = 0; m < NF; ++m) { double w = 2.0 * M_PI * freqs[m] / 1501.0; row[ctc + 2 * m] = (float)(k_tc_amp * cos(w * ktarget)); row[ctc + 2 * m + 1] = (float)(k_tc_amp * sin(w * ktarget)); }
         }
         write_tensor("decoder.positional_embedding", 2, ne, 0, d); free(d);
