@@ -136,6 +136,24 @@ def test_full_transcription_matches_oracle_ragged_batch(tiny, suppress_nst):
     assert res[5]["segments"] == [] and res[5]["n_windows"] == 0
 
 
+@pytest.mark.parametrize("field, value", [("no_timestamps", 1), ("single_segment", 1), ("max_tokens", 8), ("translate", 1), ("max_initial_ts", 0.4), ("suppress_blank", 0),
+                                          ("temperature_inc", 0.0), ("entropy_thold", 3.5), ("logprob_thold", -0.2), ("no_speech_thold", 1e-9)])
+def test_every_decode_parameter_away_from_its_default_matches_oracle(tiny, field, value):
+    """The reference node sets language, translate = false, suppress_blank and suppress_nst and leaves the rest of whisper_full_params at whisper.cpp's defaults (lib.rs:624-641);
+    skw_full_params exposes the others too, and each is held to the oracle here at a non-default value: no_timestamps (the <|notimestamps|> prompt and its rules), single_segment,
+    a token cap, translate (the task token), another max_initial_ts, the blank rule off, the fallback ladder off, and the three thresholds moved so that they fire."""
+    _, ctx, om = tiny
+    pcms = [synth.clip(c, n) for c, n in [(1, 16000 * 30), (4, 16000 * 11 + 77), (6, 16000 * 31 + 500)]]      # the last one runs a second, short window
+    p = ctx.default_params(); po = om.default_params()
+    setattr(p, field, type(getattr(p, field))(value)); setattr(po, field, type(getattr(po, field))(value))
+    n_tok = 0
+    for pcm, rg in zip(pcms, ctx.full_batch(pcms, params=p)):
+        ro = om.full(pcm, po)
+        assert _same(rg, ro), (field, [t[0] for t in rg["tokens"]][:12], [t[0] for t in ro["tokens"]][:12])
+        n_tok += len(rg["tokens"])
+    assert n_tok > 0 or field == "no_speech_thold"
+
+
 def test_golden_vectors_on_gpu(micro):
     _, ctx, _ = micro
     gold = json.load(open(os.path.join(HERE, "golden", "oracle_micro_seed1234.json")))
