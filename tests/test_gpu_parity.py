@@ -362,6 +362,22 @@ def test_multi_window_clips_advance_by_timestamps(eng, tiny_model_path):
     assert res[0]["n_windows"] >= 3 and res[2]["n_windows"] >= 2 and res[1]["n_windows"] == 1
 
 
+def test_long_form_clips_of_many_windows_match_oracle(eng, tiny_model_path):
+    """2.5 and 4 minutes of audio in one call beside a short clip: 5 - 9 windows per clip, each conditioned on the text of the ones before it (the carried prompt), rows leaving and
+    re-entering the batch at different windows — ids, log-probs, segment times, window counts identical to the oracle's sequential run; in both precisions' control flow (f16_mfma:
+    the same number of windows and a transcript of the same shape, its decisions are checked elsewhere)."""
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=3, max_samples=16000 * 245); om = OracleModel(tiny_model_path)
+    pcms = [synth.clip(11, 16000 * 150 + 311), synth.clip(12, 16000 * 9), synth.clip(13, 16000 * 240)]
+    res = ctx.full_batch(pcms)
+    for pcm, rg in zip(pcms, res):
+        assert _same(rg, om.full(pcm))
+    assert res[0]["n_windows"] >= 5 and res[2]["n_windows"] >= 8 and res[2]["segments"][-1]["t1"] > 20000
+    ctx.set_precision("f16_mfma")
+    for rg, rf in zip(res, ctx.full_batch(pcms)):
+        assert abs(rf["n_windows"] - rg["n_windows"]) <= 1 and len(rf["segments"]) > 0
+    ctx.close(); m.close()
+
+
 def test_language_auto_detection_matches_oracle(tiny):
     """lang_id < 0 = whisper.cpp's language "auto": one extra [sot] step on each clip's first window picks its language; clips of one
     batch may end up with different languages (the prompt's language token is per row)."""
