@@ -1935,7 +1935,12 @@ __global__ void k_resample_lerp(const float* in, int channels, const int* pos, c
 void skw_resample_linear_launch(const float* in, int channels, double last_index, double t_ratio, int chunk, int n_chunks, int* pos, float* frac, int* n_out, double* last_index_out,
                                 float* out, int cap, double* start, int* count, int* offset, int* flag, hipStream_t s, bool host_proposal) {
     const bool force_scan = skw_sw(SW_RESAMPLE_SCAN) != 0;     // the single-lane walk only (the fallback of both proposals; tests hold it to the same bits)
-    if (force_scan) hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
+    if (force_scan) {
+        // both flags set: "both proposals failed" is what this path stands for (skw_dsp_last_scan_fallback reports 2).  They were left as the allocation held them before round 5's
+        // last day: the switch test passed or failed with whatever hipMalloc returned.
+        hipMemsetAsync(flag, 0xFF, 2 * sizeof(int), s);
+        hipLaunchKernelGGL(k_resample_scan, dim3(1), dim3(64), 0, s, last_index, t_ratio, chunk, n_chunks, pos, frac, n_out, last_index_out, cap, (const int*)nullptr);
+    }
     else {
         // flag[0]: 0 = first proposal stands, 1 = it failed, 2 = second proposal to be checked; flag[1]: the second one failed too
         int* fail2 = flag + 1;
