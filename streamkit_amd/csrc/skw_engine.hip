@@ -450,6 +450,11 @@ extern "C" int skw_debug_switch_set(const char* name, int value) { const int i =
 
 // ------------------------------------------------------------------ context / workspace
 struct ProfState;
+// tests (SKW_TEST_ALLOC_POISON=1 in tests/conftest.py): workspace buffers of floating type that the engine does not zero are filled with NaNs when a context is created, so that a
+// kernel reading what no kernel wrote shows up as a changed result instead of passing on whatever hipMalloc returned (round 5: a resampler flag was read that way)
+static int g_alloc_poison = 0; static std::atomic<long> g_alloc_poisoned{0};
+extern "C" void skw_debug_alloc_poison(int on) { g_alloc_poison = on; }
+extern "C" long skw_debug_alloc_poisoned(void) { return g_alloc_poisoned.load(); }      // buffers filled so far
 struct skw_ctx {
     int precision = SKW_PRECISION_EXACT;             // SKW_PRECISION_*: which form of the contractions runs (skw_ctx_set_precision)
     int kv_frag_on = 1;                              // f16_mfma: cross K / V^T as fragment-order images (skw_kernels.h, skw_kfrag_off); SKW_XATTN_FRAG=0 keeps the row layouts
@@ -498,7 +503,7 @@ struct skw_ctx {
     int* forced_dev = nullptr; SkwTraceStep* trace_dev = nullptr;   // [max_batch][max_tok], allocated by the first skw_full_batch_traced
     skw_timing timing{};
     int last_enc_B = 0;
-    struct WsEntry { const char* name; void** slot; size_t bytes; bool zero; };      // one workspace buffer: the field it fills and its size (skw_ctx_create)
+    struct WsEntry { const char* name; void** slot; size_t bytes; bool zero; bool is_float; };      // one workspace buffer: the field it fills and its size (skw_ctx_create)
     std::vector<WsEntry> ws_table;
 };
 struct SkwKClk;
@@ -554,7 +559,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
     c->max_tok = hp.n_text_ctx / 2;
     if (m->quant) c->q8_kmax = kmax;
     auto want = [&](const char* name, auto*& field, size_t count, bool zero) {
-        c->ws_table.push_back(skw_ctx::WsEntry{name, (void**)&field, count * sizeof(*field), zero});
+        c->ws_table.push_back(skw_ctx::WsEntry{name, (void**)&field, count * sizeof(*field), zero, !std::is_integral<std::remove_pointer_t<std::remove_reference_t<decltype(field)>>>::value});
     };
     // front end
     want("pcm", c->pcm, (size_t)B * max_samples, false);
@@ -616,6 +621,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
         if (hipMalloc(&p, e.bytes) != hipSuccess || !p) { ok = false; ws_failed = e.name; ws_failed_bytes = e.bytes; break; }
         c->allocs.push_back(p);
         if (e.zero) (void)hipMemset(p, 0, e.bytes);
+        else if (g_alloc_poison && e.is_float) { (void)hipMemset(p, 0xFF, e.bytes); g_alloc_poisoned.fetch_add(1); }       // tests: every f16 / f32 / f64 buffer the engine does not zero starts as NaNs (skw_debug_alloc_poison)
         *e.slot = p;
     }
     if (ok) ws_failed = ws_first_null(c);

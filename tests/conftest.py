@@ -1,3 +1,4 @@
+import ctypes
 import os
 import subprocess
 import sys
@@ -86,6 +87,22 @@ def quantized_model(size, kind, seed=1234, vocab=51865, mels=80):
 def eng():
     from streamkit_amd import engine
     return engine
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _alloc_poison():
+    """SKW_TEST_ALLOC_POISON=1 python -m pytest tests -m gpu: every floating-point workspace buffer the engine does not zero starts as NaNs (skw_debug_alloc_poison, skw_engine.hip), so a
+    kernel that reads what no kernel wrote changes a result instead of passing on whatever hipMalloc returned.  profiles/r05t holds the suite's log in that mode."""
+    on = os.environ.get("SKW_TEST_ALLOC_POISON") == "1" and HAVE_GPU
+    if on:
+        from streamkit_amd import engine
+        engine.lib().skw_debug_alloc_poison(1)
+    yield
+    if on:
+        engine.lib().skw_debug_alloc_poisoned.restype = ctypes.c_long
+        n = engine.lib().skw_debug_alloc_poisoned()
+        print("\n[alloc poison] %d workspace buffers started as NaNs" % n)
+        assert n > 0
 
 
 @pytest.fixture(scope="session")
