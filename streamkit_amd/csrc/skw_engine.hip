@@ -455,6 +455,7 @@ struct ProfState;
 static int g_alloc_poison = 0; static std::atomic<long> g_alloc_poisoned{0};
 extern "C" void skw_debug_alloc_poison(int on) { g_alloc_poison = on; }
 extern "C" long skw_debug_alloc_poisoned(void) { return g_alloc_poisoned.load(); }      // buffers filled so far
+static void poison_floats(void* p, size_t bytes) { if (g_alloc_poison && p) { (void)hipMemset(p, 0xFF, bytes); g_alloc_poisoned.fetch_add(1); } }
 struct skw_ctx {
     int precision = SKW_PRECISION_EXACT;             // SKW_PRECISION_*: which form of the contractions runs (skw_ctx_set_precision)
     int kv_frag_on = 1;                              // f16_mfma: cross K / V^T as fragment-order images (skw_kernels.h, skw_kfrag_off); SKW_XATTN_FRAG=0 keeps the row layouts
@@ -1133,6 +1134,7 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
             || hipMalloc((void**)&sm, sizeof(int) * 2 * c->max_batch) != hipSuccess) {
             hipFree(sk); hipFree(sv); hipFree(sm); snprintf(errbuf, 512, "temperature retry: staging buffers for the cross K/V move could not be allocated"); return -1;
         }
+        poison_floats(sk, (size_t)L * c->max_batch * ka * 2); poison_floats(sv, (size_t)L * c->max_batch * ve * 2);
         hipFree(c->stageK); hipFree(c->stageV); hipFree(c->slot_map); c->stageK = sk; c->stageV = sv; c->slot_map = sm;
     }
     std::vector<int> h(2 * (size_t)c->max_batch, 0);
@@ -1913,10 +1915,13 @@ hipFree(d->d_flag); hipStreamDestroy(d->stream); delete d; }
 extern "C" const char* skw_dsp_last_error(const skw_dsp* d) { return d->errbuf; }
 static int dsp_reserve(skw_dsp* d, size_t n_in, size_t n_out) {
     char* errbuf = d->errbuf;
-    if (n_in > d->cap_in) { hipFree(d->d_in); d->cap_in = n_in * 2; HIPCHK(hipMalloc((void**)&d->d_in, d->cap_in * sizeof(float))); }
+    if (n_in > d->cap_in) {
+        hipFree(d->d_in); d->cap_in = n_in * 2; HIPCHK(hipMalloc((void**)&d->d_in, d->cap_in * sizeof(float))); poison_floats(d->d_in, d->cap_in * sizeof(float));
+    }
     if (n_out > d->cap_out) { hipFree(d->d_out); hipFree(d->d_frac);
     hipFree(d->d_pos); d->cap_out = n_out * 2; HIPCHK(hipMalloc((void**)&d->d_out, d->cap_out * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&d->d_frac, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_pos, d->cap_out * sizeof(int))); }
+    HIPCHK(hipMalloc((void**)&d->d_frac, d->cap_out * sizeof(float))); HIPCHK(hipMalloc((void**)&d->d_pos, d->cap_out * sizeof(int)));
+    poison_floats(d->d_out, d->cap_out * sizeof(float)); poison_floats(d->d_frac, d->cap_out * sizeof(float)); }
     return 0;
 }
 extern "C" void skw_resampler_init(skw_resampler_state* st, double ratio, int chunk_frames, int channels) {

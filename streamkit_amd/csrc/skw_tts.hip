@@ -445,12 +445,16 @@ static void* dev_upload(skw_tts* t, const void* h, size_t bytes) {
     if (bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
     t->allocs.push_back(d); return d;
 }
+// tests (SKW_TEST_ALLOC_POISON=1, tests/conftest.py): arena chunks start as NaNs (every activation buffer of the synthesiser is a float buffer carved from them)
+static int g_tts_alloc_poison = 0;
+extern "C" void skw_tts_debug_alloc_poison(int on) { g_tts_alloc_poison = on; }
 static void* arena_get(skw_tts* t, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     while (t->cur_chunk < t->chunks.size() && t->cur_off + bytes > t->chunks[t->cur_chunk].cap) { ++t->cur_chunk; t->cur_off = 0; }
     if (t->cur_chunk == t->chunks.size()) {
         const size_t cap = std::max<size_t>(bytes, (size_t)256 << 20); char* p = nullptr;
         if (hipMalloc((void**)&p, cap) != hipSuccess) { t->arena_failed = true; return nullptr; }
+        if (g_tts_alloc_poison) (void)hipMemset(p, 0xFF, cap);
         t->chunks.push_back({p, cap}); t->cur_off = 0;
     }
     void* r = t->chunks[t->cur_chunk].p + t->cur_off; t->cur_off += bytes; return r;

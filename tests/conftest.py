@@ -97,6 +97,8 @@ def _alloc_poison():
     if on:
         from streamkit_amd import engine
         engine.lib().skw_debug_alloc_poison(1)
+        import ctypes as _C
+        _C.CDLL(os.path.join(ROOT, "streamkit_amd", "libskw_tts.so"), mode=_C.RTLD_GLOBAL).skw_tts_debug_alloc_poison(1)
     yield
     if on:
         engine.lib().skw_debug_alloc_poisoned.restype = ctypes.c_long
