@@ -622,7 +622,7 @@ extern "C" skw_ctx* skw_ctx_create(skw_model* m, int max_batch, int max_samples,
         if (hipMalloc(&p, e.bytes) != hipSuccess || !p) { ok = false; ws_failed = e.name; ws_failed_bytes = e.bytes; break; }
         c->allocs.push_back(p);
         if (e.zero) (void)hipMemset(p, 0, e.bytes);
-        else if (g_alloc_poison && e.is_float) { (void)hipMemset(p, 0xFF, e.bytes); g_alloc_poisoned.fetch_add(1); }       // tests: every f16 / f32 / f64 buffer the engine does not zero starts as NaNs (skw_debug_alloc_poison)
+        else if (e.is_float) poison_floats(p, e.bytes);       // tests: every f16 / f32 / f64 buffer the engine does not zero starts as NaNs (skw_debug_alloc_poison)
         *e.slot = p;
     }
     if (ok) ws_failed = ws_first_null(c);
