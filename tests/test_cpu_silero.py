@@ -117,3 +117,45 @@ def test_error_messages_follow_the_reference(built_vad, tmp_path):
     junk = tmp_path / "junk.onnx"; junk.write_bytes(os.urandom(4096))
     with pytest.raises(RuntimeError):
         ProductVad(str(junk))
+
+
+def test_damaged_onnx_files_are_refused_or_run_but_never_crash(built_vad, tmp_path):
+    """`vad_model_path` is a file the operator downloads (README.md:131-140): a truncated download or a corrupted byte must end in skw_vad_create's error string — which the node
+    turns into the reference's "Failed to initialize VAD" (lib.rs:382-383) — or in a gate that runs, never in a crash of the host.  Truncations at 30 points and 300 files with
+    1 - 3 flipped bytes, half of them next to the graph's structure (field tags and lengths around the tensor names), seeded."""
+    import ctypes as C
+    import re
+    good = open(synth_silero_path(), "rb").read()
+    L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "streamkit_amd", "libskw_vad.so"))
+    L.skw_vad_create.restype = C.c_void_p; L.skw_vad_create.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.skw_vad_free.argtypes = [C.c_void_p]; L.skw_vad_process_chunk.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    sites = [m.start() for m in re.finditer(rb"(stft|encoder|decoder)[.]", good)]
+    assert len(sites) >= 10
+    path = str(tmp_path / "damaged.onnx")
+    refused = ran = 0
+
+    def attempt(blob):
+        nonlocal refused, ran
+        with open(path, "wb") as f:
+            f.write(blob)
+        err = C.create_string_buffer(512)
+        h = L.skw_vad_create(path.encode(), err, 512)
+        if not h:
+            assert len(err.value) > 5
+            refused += 1
+            return
+        x = np.zeros(512, np.float32); pr = C.c_float()
+        L.skw_vad_process_chunk(h, x.ctypes.data, C.byref(pr)); L.skw_vad_free(h)
+        ran += 1
+
+    for cut in [0, 1, 7, 100, 1000, len(good) // 3, len(good) // 2, len(good) - 1] + [int(x) for x in rng.integers(0, len(good), 22)]:
+        attempt(good[:cut])
+    assert refused >= 25          # (a cut inside the last tensor's padding may still load)
+    for i in range(300):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            site = int(rng.choice(sites)) + int(rng.integers(-12, 4)) if i % 2 else int(rng.integers(0, len(b)))
+            b[max(0, min(len(b) - 1, site))] = int(rng.integers(0, 256))
+        attempt(bytes(b))
+    assert refused + ran == 330

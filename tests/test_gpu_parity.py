@@ -378,6 +378,48 @@ def test_long_form_clips_of_many_windows_match_oracle(eng, tiny_model_path):
     ctx.close(); m.close()
 
 
+def test_damaged_model_files_are_refused_with_a_message(eng, tiny_model_path, tmp_path):
+    """create_instance hands the host NULL when the model cannot be loaded (lib.rs:354-360 -> "Failed to load Whisper model"): a damaged file must end in an error string, never in a
+    crash of the host process or a half-loaded model.  Truncations at every structural boundary (magic, header, filterbank, vocabulary, inside a tensor header, inside tensor data,
+    one byte short) and field corruptions (magic, absurd header values, a vocabulary string longer than the file, a tensor with absurd dimensions / an unknown type / a name
+    longer than the file)."""
+    import struct
+    good = open(tiny_model_path, "rb").read()
+    hdr = 4 + 11 * 4
+    n_mel, n_fft = struct.unpack_from("<2i", good, hdr)
+    voc0 = hdr + 8 + 4 * n_mel * n_fft
+    n_voc = struct.unpack_from("<i", good, voc0)[0]
+    o = voc0 + 4
+    for _ in range(n_voc):
+        o += 4 + struct.unpack_from("<I", good, o)[0]
+    ten0 = o                                                       # first tensor header: n_dims, name length, type, dims, name, data
+    cases = {}
+    for name, cut in [("empty", 0), ("magic", 3), ("header", hdr - 5), ("filterbank", hdr + 100), ("vocabulary", voc0 + 1000), ("tensor header", ten0 + 6), ("tensor data", ten0 + 5000),
+                      ("middle", len(good) // 2), ("one byte short", len(good) - 1)]:
+        cases["cut: " + name] = good[:cut]
+    def patched(off, fmt, *vals):
+        b = bytearray(good); struct.pack_into(fmt, b, off, *vals); return bytes(b)
+    cases["bad magic"] = patched(0, "<I", 0x12345678)
+    cases["n_vocab huge"] = patched(4, "<i", 2 ** 30)
+    cases["n_audio_state negative"] = patched(4 + 2 * 4, "<i", -768)
+    cases["n_mels zero"] = patched(4 + 9 * 4, "<i", 0)
+    cases["filterbank size"] = patched(hdr, "<2i", 2 ** 20, 2 ** 20)
+    cases["vocabulary count"] = patched(voc0, "<i", 2 ** 28)
+    cases["vocabulary string length"] = patched(voc0 + 4, "<I", 2 ** 31 - 1)
+    cases["tensor n_dims"] = patched(ten0, "<i", 9)
+    cases["tensor name length"] = patched(ten0 + 4, "<i", 2 ** 30)
+    cases["tensor type"] = patched(ten0 + 8, "<i", 77)
+    cases["tensor dims"] = patched(ten0 + 12, "<i", 2 ** 30)
+    for name, blob in cases.items():
+        f = tmp_path / "damaged.bin"; f.write_bytes(blob)
+        with pytest.raises(RuntimeError) as ei:
+            eng.Model(str(f))
+        assert len(str(ei.value)) > 8, name
+    with pytest.raises(RuntimeError):
+        eng.Model(str(tmp_path / "does_not_exist.bin"))
+    m = eng.Model(tiny_model_path); m.close()                      # and the loader still works afterwards
+
+
 def test_language_auto_detection_matches_oracle(tiny):
     """lang_id < 0 = whisper.cpp's language "auto": one extra [sot] step on each clip's first window picks its language; clips of one
     batch may end up with different languages (the prompt's language token is per row)."""
