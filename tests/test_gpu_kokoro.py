@@ -317,3 +317,37 @@ def test_generator_matches_the_torch_restatement_given_the_same_curves(size):
               % (size, ids.size, e_dec, e_mag, float(ph[live].max()), e_post, e_wave))
         assert e_dec < 1e-4 and e_mag < 1e-4 and ph[live].max() < 2e-3 and e_post < 1e-4 and e_wave < 1e-3
     tts.close()
+
+
+def test_damaged_model_directories_are_refused_with_a_message(tmp_path):
+    """kokoro_node.rs:705-745 checks that the files exist and hands their paths on; what is IN them is the library's to survive: a truncated or corrupted model.onnx / voices.bin /
+    tokens.txt / lexicon ends in skw_tts_create's error string (the node: "Failed to create TTS engine"), or in an engine that synthesises, never in a crash of the host."""
+    import shutil
+    src = kokoro_lib.synth_kokoro_dir("micro")
+    rng = np.random.default_rng(11)
+    refused = ran = 0
+    files = ["model.onnx", "voices.bin", "tokens.txt", "lexicon-us-en.txt"]
+    for case in range(40):
+        d = str(tmp_path / ("k%d" % case)); shutil.copytree(src, d)
+        name = files[case % 4]; p = os.path.join(d, name); blob = bytearray(open(p, "rb").read())
+        kind = (case // 4) % 3
+        if kind == 0:
+            blob = blob[:int(rng.integers(0, max(1, len(blob))))]                                     # truncated
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 5))):
+                blob[int(rng.integers(0, min(len(blob), 4096)))] = int(rng.integers(0, 256))          # corrupted near the start (structure)
+        else:
+            blob = bytearray(rng.integers(0, 256, int(rng.integers(1, 5000)), dtype=np.uint8).tobytes())  # not this kind of file at all
+        open(p, "wb").write(bytes(blob))
+        try:
+            t = kokoro_lib.Tts(d)
+        except RuntimeError as e:
+            assert len(str(e)) > 8, (name, kind)
+            refused += 1
+            continue
+        try:
+            t.generate("hello there", 0, 1.0)
+        except RuntimeError as e:
+            assert len(str(e)) > 8
+        t.close(); ran += 1
+    assert refused >= 12 and refused + ran == 40, (refused, ran)
