@@ -378,6 +378,31 @@ def test_long_form_clips_of_many_windows_match_oracle(eng, tiny_model_path):
     ctx.close(); m.close()
 
 
+@pytest.mark.parametrize("precision", ["exact", "f16_mfma"])
+def test_non_finite_and_absurd_samples_do_not_hang_or_poison_batch_mates(tiny, precision):
+    """A decoder upstream can hand the node anything in an f32 buffer.  Clips holding NaNs, infinities, 1e30 and denormals go through the whole path beside a clean clip: the call
+    returns, every token id is a vocabulary entry, and the CLEAN clip's transcript is what it is alone — rows of a batch do not see each other, also when one of them is garbage."""
+    _, ctx, om = tiny
+    ctx.set_precision(precision)
+    try:
+        clean = synth.clip(3, 16000 * 12)
+        bad = []
+        x = synth.clip(4, 16000 * 12).copy(); x[5000:5100] = np.nan; bad.append(x)
+        x = synth.clip(5, 16000 * 12).copy(); x[100] = np.inf; x[70000] = -np.inf; bad.append(x)
+        x = synth.clip(6, 16000 * 12).copy(); x[::977] = 1e30; bad.append(x)
+        bad.append(np.full(16000 * 3, 1e-42, np.float32))
+        bad.append(np.full(16000 * 2, np.nan, np.float32))
+        alone = ctx.full_batch([clean])[0]
+        res = ctx.full_batch([bad[0], clean, bad[1], bad[2], bad[3], bad[4]][:4]) + ctx.full_batch([bad[3], bad[4], clean])
+        NV = om.hp.n_vocab
+        for r in res:
+            assert all(0 <= t[0] < NV for t in r["tokens"]) and r["n_windows"] <= 2
+        for r in (res[1], res[6]):
+            assert [t[0] for t in r["tokens"]] == [t[0] for t in alone["tokens"]] and [(s["t0"], s["t1"]) for s in r["segments"]] == [(s["t0"], s["t1"]) for s in alone["segments"]]
+    finally:
+        ctx.set_precision("exact")
+
+
 def test_damaged_model_files_are_refused_with_a_message(eng, tiny_model_path, tmp_path):
     """create_instance hands the host NULL when the model cannot be loaded (lib.rs:354-360 -> "Failed to load Whisper model"): a damaged file must end in an error string, never in a
     crash of the host process or a half-loaded model.  Truncations at every structural boundary (magic, header, filterbank, vocabulary, inside a tensor header, inside tensor data,
