@@ -1626,7 +1626,7 @@ extern "C" int skw_debug_gemm16(skw_ctx* c, int M, int N, int K, int epi, int pr
     half_t *A = nullptr, *W = nullptr; void* C = nullptr; float *bias = nullptr, *res = nullptr;
     const size_t cbytes = (size_t)M * N * 4 + (size_t)64 * c->Tpad * N;
     // probe bits 12-19 = n (decode shapes): the launches walk n copies of W (n x N x K x 2 bytes > the 256 MB Infinity Cache: every launch finds its weights in HBM, as a decode step does)
-    const int wcycle = M <= 64 ? std::max(1, (probe >> 12) & 255) : 1; probe &= 0xfff;
+    const int wcycle = M <= 64 ? std::max(1, (probe >> 12) & 255) : 1; if (M <= 64) probe &= 0xfff;      // (big shapes: bits 10-16 are k_gemm16w's measurement hooks)
     HIPCHK(hipMalloc((void**)&A, (size_t)M * K * 2)); HIPCHK(hipMalloc((void**)&W, (size_t)N * K * 2 * wcycle));
     HIPCHK(hipMalloc(&C, cbytes)); HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(M, N) * 4)); HIPCHK(hipMalloc((void**)&res, (size_t)M * N * 4));
     { std::vector<uint16_t> h((size_t)std::max(M, N) * K); uint32_t x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = skw_f32_to_f16(((x >> 8) & 0xffff) / 65536.0f - 0.5f); }
