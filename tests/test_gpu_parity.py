@@ -403,6 +403,16 @@ def test_non_finite_and_absurd_samples_do_not_hang_or_poison_batch_mates(tiny, p
         ctx.set_precision("exact")
 
 
+def test_random_clips_and_parameters_match_oracle():
+    """Ten rounds of tools/probe/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
+    model shapes — whatever combination the named tests above do not name."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "probe", "fuzz_parity.py"), "10", "20261005"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_damaged_model_files_are_refused_with_a_message(eng, tiny_model_path, tmp_path):
     """create_instance hands the host NULL when the model cannot be loaded (lib.rs:354-360 -> "Failed to load Whisper model"): a damaged file must end in an error string, never in a
     crash of the host process or a half-loaded model.  Truncations at every structural boundary (magic, header, filterbank, vocabulary, inside a tensor header, inside tensor data,
