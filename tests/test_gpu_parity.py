@@ -343,9 +343,8 @@ def test_model_zoo_vocabularies_and_mel_bands_match_oracle(eng, size, vocab, mel
             ctx.full_batch(pcms[:1], params=p)
         assert all(r["lang_id"] == 0 for r in res)
     if kind is None:
-        # (turbo-shaped: one decoder layer on a three-layer encoder — the seeded weights' logits span twice the range of the layered models the default bound is sized on;
-        #  measured 0.49 with no decision differing among 90, bound 0.6)
-        tf = teacher_forced_compare(ctx, pcms[:2], logit_err_bound=0.6 if layers else None)
+        # (the micro-sized shapes take parity.py's d < 256 bound, 0.70: turbo-shaped measured 0.49 with no decision differing among 90)
+        tf = teacher_forced_compare(ctx, pcms[:2])
         assert tf["ok"] and tf["steps_checked"] > 20, {k: tf[k] for k in ("argmax_disagreements", "max_margin_at_disagreement", "max_logit_err")}
 
 

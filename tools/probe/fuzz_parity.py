@@ -1,5 +1,7 @@
 """Differential hunt: random clips (lengths 0.05 - 65 s, levels from silence to clipping, random batch compositions) and random decode parameters through the engine and through the
-oracle, tiny model, exact precision: every transcript must be identical (ids, log-probs, segment times, window counts).  Usage (GPU box): python tools/probe/fuzz_parity.py [rounds] [seed]"""
+oracle, tiny model, exact precision: every transcript must be identical (ids, log-probs, segment times, window counts).  With a third argument `f16`: the same inputs through
+streamkit_amd.parity.teacher_forced_compare instead — f16_mfma fed the exact precision's tokens, every decision equal or at a near-tie, logits within the precision's bound.
+Usage (GPU box): python tools/probe/fuzz_parity.py [rounds] [seed] [f16 [size]]"""
 import os
 import sys
 import time
@@ -22,11 +24,15 @@ def same(rg, ro):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    f16 = len(sys.argv) > 3 and sys.argv[3] == "f16"
     variants = [dict(), dict(vocab=51864), dict(vocab=51866, mels=128)]
     bad = n = 0; t0 = time.time()
     for r in range(rounds):
         v = variants[r % 3]
-        path = synth_model("tiny" if r % 3 == 0 else "micro", **v)
+        size = "tiny" if r % 3 == 0 else "micro"
+        if f16 and len(sys.argv) > 4:          # f16 mode needs no CPU run: the benchmark geometry (or any size named) can be hunted too
+            size, v = sys.argv[4], dict()
+        path = synth_model(size, **v)
         m = engine.Model(path); ctx = engine.Context(m, max_batch=6, max_samples=16000 * 66); om = OracleModel(path)
         nb = int(rng.integers(1, 7)); clips = []
         for i in range(nb):
@@ -41,6 +47,16 @@ if __name__ == "__main__":
                            ("max_initial_ts", [1.0, 1.0, 0.3]), ("entropy_thold", [2.4, 2.4, 3.2]), ("logprob_thold", [-1.0, -1.0, -0.3])]:
             val = choices[int(rng.integers(0, len(choices)))]
             setattr(p, f, type(getattr(p, f))(val)); setattr(po, f, type(getattr(po, f))(val))
+        if f16:
+            from streamkit_amd.parity import teacher_forced_compare
+            tf = teacher_forced_compare(ctx, clips, params=p); n += len(clips)
+            if not tf["ok"]:
+                bad += 1
+                print("F16 BOUND round %d model %s: %s" % (r, os.path.basename(path), {k: tf[k] for k in ("steps_checked", "argmax_disagreements", "max_margin_at_disagreement", "max_logit_err")}), flush=True)
+            print("round %d: %d clips so far, %d rounds out of bounds; this round %d decisions, %d differ, max logit error %.3f, %.0f s" % (r, n, bad, tf["steps_checked"], tf["argmax_disagreements"],
+                  tf["max_logit_err"], time.time() - t0), flush=True)
+            ctx.close(); m.close(); om.close()
+            continue
         res = ctx.full_batch(clips, params=p)
         for i, (x, rg) in enumerate(zip(clips, res)):
             ro = om.full(x, po); n += 1
