@@ -37,8 +37,8 @@ CASES = [
     ("RESAMPLE_SCAN", 1, "resample"),
     ("RESAMPLE_NO_HOST_WALK", 1, "resample"),
 ]
-# Teacher-forced logit-error bound of a tolerance case, where it is not the precision's default for the model (streamkit_amd/parity.py bounds_for: 0.36 for the small test models,
-# set from batches of <= 1 100 decisions).  The two-phase cross attention rounds the NORMALISED probabilities to f16 where the one-pass kernel rounds p <= 1 before the division:
+# Teacher-forced logit-error bound of a tolerance case, where it is not the precision's default for the model (streamkit_amd/parity.py bounds_for: 0.36 for the small test models in rounds 3-4,
+# set from batches of <= 1 100 decisions; 0.40 since round 5's random-input hunt, which makes this entry redundant — kept as the record of where 0.363 was first seen).  The two-phase cross attention rounds the NORMALISED probabilities to f16 where the one-pass kernel rounds p <= 1 before the division:
 # measured 0.363 over this file's 4 488 decisions (8 argmax disagreements, all at exact-mode margins <= 0.040; gpurun_out/r05a_suite.txt) — bound = 1.1 x that.
 TOL_LOGIT_ERR = {("XATTN_FRAG", 0): 0.40}
 # a ragged batch: one-window clips, multi-window clips whose later windows carry ~100-token prompts (the prompt pass then has >= 256 rows: the big-tile GEMM and the
