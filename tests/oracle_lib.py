@@ -211,11 +211,11 @@ class OracleResampler:
 
     def __init__(self, ratio, chunk_frames, channels):
         self.h = lib().skwo_resampler_new(ratio, chunk_frames, channels)
-        self.chunk, self.ch = chunk_frames, channels
+        self.chunk, self.ch, self.ratio = chunk_frames, channels, ratio
 
     def process(self, planar):
         planar = np.ascontiguousarray(planar, dtype=np.float32).reshape(self.ch, self.chunk)
-        cap = self.chunk * 4 + 64
+        cap = int(self.chunk * max(4.0, 1.1 * self.ratio)) + 64
         out = np.zeros((self.ch, cap), dtype=np.float32)
         n = lib().skwo_resampler_process(self.h, planar.ctypes.data, out.ctypes.data, cap)
         assert n >= 0
