@@ -397,3 +397,33 @@ def test_model_cache_outlives_its_instances(plugin, micro_model_path):
     assert third.flush() == 0
     assert [o[2] for o in third.outputs()] == [o[2] for o in out2] and len(out2) == 1
     third.destroy()
+
+
+@pytest.mark.parametrize("vad_mode, extra", [("always", {}), ("energy", {"min_silence_duration_ms": 320})])
+def test_packetisation_does_not_change_what_comes_out(plugin, tiny_model_path, vad_mode, extra):
+    """The host hands the node whatever packet sizes its upstream produces (960-sample resampler packets in the sample pipelines, 1920 from the WAV demuxer, anything from a codec):
+    the node re-frames to 512 samples (lib.rs:404-416), so the Transcription packets and the telemetry must not depend on how the same samples were cut into packets.  Six random
+    cuttings (1 .. 7 000 samples per packet, empty packets included) of one 70 s stream with pauses against the 960-sample cutting: byte-identical outputs, identical events."""
+    rng = np.random.default_rng(21)
+    parts = [synth.clip(3, 16000 * 31), np.zeros(16000 * 2, np.float32), synth.clip(4, 16000 * 9), np.zeros(16000, np.float32), synth.clip(5, 16000 * 26), np.zeros(16000, np.float32)]
+    pcm = np.concatenate(parts)
+    cfg = dict({"model_path": tiny_model_path, "vad_mode": vad_mode, "emit_vad_events": True}, **extra)
+
+    def run(cuts):
+        node = plugin.create_node(cfg); pos = 0
+        for n in cuts:
+            assert node.process_audio(pcm[pos:pos + n]) == 0, node.last_error()
+            pos += n
+        assert pos >= pcm.size and node.flush() == 0
+        out = ([(o[0], o[1], bytes(o[2])) for o in node.outputs()], node.telemetry())
+        node.destroy()
+        return out
+
+    ref = run([960] * ((pcm.size + 959) // 960))
+    assert len(ref[0]) >= 2
+    for trial in range(6):
+        cuts = []; left = pcm.size
+        while left > 0:
+            n = int(rng.choice([0, 1, 17, 511, 512, 513, 960, 1920, 4096, int(rng.integers(1, 7000))])); n = min(n, left); cuts.append(n); left -= n
+        got = run(cuts)
+        assert got[0] == ref[0] and got[1] == ref[1], (trial, len(got[0]), len(ref[0]))
