@@ -427,3 +427,54 @@ def test_packetisation_does_not_change_what_comes_out(plugin, tiny_model_path, v
             n = int(rng.choice([0, 1, 17, 511, 512, 513, 960, 1920, 4096, int(rng.integers(1, 7000))])); n = min(n, left); cuts.append(n); left -= n
         got = run(cuts)
         assert got[0] == ref[0] and got[1] == ref[1], (trial, len(got[0]), len(ref[0]))
+
+
+def test_many_instances_with_different_parameters_on_threads_keep_their_own_results(plugin, tiny_model_path):
+    """A stress of the scheduler's grouping and routing: 20 instances on 20 OS threads (wrapper.rs:398 calls every instance from blocking-pool threads), with DIFFERENT decode
+    parameters and precisions (a batch shares one parameter set, so the scheduler must split them), different clip lengths, packet sizes and arrival times, some destroyed and
+    re-created while the others are mid-stream.  Every exact-precision instance must emit exactly the oracle's transcript for its own audio and parameters; every f16_mfma one what
+    the same configuration emits when run alone."""
+    import time
+    om = OracleModel(tiny_model_path)
+    rng = np.random.default_rng(33)
+    jobs = []
+    for i in range(20):
+        pcm = synth.clip(40 + i, int(16000 * rng.choice([4, 9, 17, 30])))
+        cfg = {"model_path": tiny_model_path, "vad_mode": "always", "flush_tail": True, "batch_window_ms": int(rng.choice([0, 2, 20])), "max_batch": int(rng.choice([1, 4, 64])),
+               "suppress_blank": bool(rng.integers(0, 2)), "suppress_non_speech_tokens": bool(rng.integers(0, 2)), "language": str(rng.choice(["en", "de", "auto"])),
+               "precision": "f16_mfma" if i % 5 == 4 else "exact"}
+        jobs.append((cfg, pcm, int(rng.choice([480, 960, 1920, 4000])), float(rng.uniform(0, 0.05))))
+
+    def alone(cfg, pcm):
+        node = plugin.create_node(cfg); _feed(node, pcm, 960); assert node.flush() == 0
+        out = [bytes(o[2]) for o in node.outputs()]; node.destroy(); return out
+
+    results = [None] * len(jobs); errors = []
+
+    def worker(k):
+        try:
+            cfg, pcm, packet, delay = jobs[k]
+            time.sleep(delay)
+            if k % 7 == 3:                      # an instance that is dropped and created again mid-way (a pipeline that restarts)
+                tmp = plugin.create_node(cfg); _feed(tmp, pcm[:16000], packet); tmp.destroy()
+            node = plugin.create_node(cfg); _feed(node, pcm, packet); assert node.flush() == 0
+            results[k] = [bytes(o[2]) for o in node.outputs()]; node.destroy()
+        except Exception as e:                  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errors, errors
+    for k, (cfg, pcm, _, _) in enumerate(jobs):
+        if cfg["precision"] == "exact":
+            po = om.default_params(); po.suppress_blank = int(cfg["suppress_blank"]); po.suppress_nst = int(cfg["suppress_non_speech_tokens"])
+            po.lang_id = {"en": 0, "de": 2, "auto": -1}[cfg["language"]]
+            r = om.full(pcm, po)
+            segs = [{"text": s["text"].decode().strip(), "start_time_ms": s["t0"] * 10, "end_time_ms": s["t1"] * 10, "confidence": None} for s in r["segments"] if s["text"].decode().strip()]
+            got = [json.loads(b.decode()) for b in results[k]]
+            assert len(got) == (1 if segs else 0), k
+            if segs:
+                assert got[0]["segments"] == segs and got[0]["text"] == " ".join(s["text"] for s in segs), k
+                assert got[0]["language"] == cfg["language"], k          # the configured string, "auto" included (lib.rs:687: self.config.language.clone())
+        else:
+            assert results[k] == alone(cfg, pcm), k
