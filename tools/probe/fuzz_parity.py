@@ -24,13 +24,13 @@ def same(rg, ro):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    f16 = len(sys.argv) > 3 and sys.argv[3] == "f16"
+    f16 = len(sys.argv) > 3 and sys.argv[3] == "f16"      # (third argument: `f16` or `exact`)
     variants = [dict(), dict(vocab=51864), dict(vocab=51866, mels=128)]
     bad = n = 0; t0 = time.time()
     for r in range(rounds):
         v = variants[r % 3]
         size = "tiny" if r % 3 == 0 else "micro"
-        if f16 and len(sys.argv) > 4:          # f16 mode needs no CPU run: the benchmark geometry (or any size named) can be hunted too
+        if len(sys.argv) > 4:                  # a size named: that geometry only (f16 mode needs no CPU run; `exact small` costs ~6 s of 16 host threads per 30 s clip)
             size, v = sys.argv[4], dict()
         path = synth_model(size, **v)
         m = engine.Model(path); ctx = engine.Context(m, max_batch=6, max_samples=16000 * 66); om = OracleModel(path)
