@@ -1,7 +1,7 @@
 """Differential hunt: random clips (lengths 0.05 - 65 s, levels from silence to clipping, random batch compositions) and random decode parameters through the engine and through the
 oracle, tiny model, exact precision: every transcript must be identical (ids, log-probs, segment times, window counts).  With a third argument `f16`: the same inputs through
 streamkit_amd.parity.teacher_forced_compare instead — f16_mfma fed the exact precision's tokens, every decision equal or at a near-tie, logits within the precision's bound.
-Usage (GPU box): python tools/probe/fuzz_parity.py [rounds] [seed] [f16 [size]]"""
+Usage (GPU box): python tools/probe/fuzz_parity.py [rounds] [seed] [f16 | exact [size [quant kind | all]]]"""
 import os
 import sys
 import time
@@ -33,6 +33,10 @@ if __name__ == "__main__":
         if len(sys.argv) > 4:                  # a size named: that geometry only (f16 mode needs no CPU run; `exact small` costs ~6 s of 16 host threads per 30 s clip)
             size, v = sys.argv[4], dict()
         path = synth_model(size, **v)
+        if len(sys.argv) > 5:                  # a block-quantised re-encoding of the file (ggml's arithmetic in the exact precision): q4_0 | q4_1 | q5_0 | q5_1 | q8_0 | all (in turn)
+            from conftest import quantized_model
+            kinds = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"]
+            path = quantized_model(size, kinds[r % 5] if sys.argv[5] == "all" else sys.argv[5], **v)
         m = engine.Model(path); ctx = engine.Context(m, max_batch=6, max_samples=16000 * 66); om = OracleModel(path)
         nb = int(rng.integers(1, 7)); clips = []
         for i in range(nb):
