@@ -18,7 +18,7 @@ LOGIT_ERR_BOUND = 0.30
 MARGIN_BOUND = 0.15
 # The tiny / micro synthetic models' logits span ~630 (1.5 x the benchmark model's): 0.25 - 0.30 measured on ragged multi-window batches with temperature passes,
 # <= 0.33 where the prompt pass uses the multi-query cross attention.  Same relative error; the absolute bound scales with the range.
-# Round 5's hunt over random clips, levels, batch compositions and decode parameters (tools/probe/fuzz_parity.py f16, profiles/r05v): benchmark geometry 17 692 decisions, 48 differ
+# Round 5's hunt over random clips, levels, batch compositions and decode parameters (tests/hunt/fuzz_parity.py f16, profiles/r05v): benchmark geometry 17 692 decisions, 48 differ
 # (every one inside MARGIN_BOUND), largest logit difference 0.238 — the 0.30 stands; tiny 8 168 decisions, 15 differ, 0.363 (clipped and near-silent clips reach what the
 # benchmark-like ones did not) -> 0.40; the two-layer d = 128 "micro" models 19 703 decisions, 27 differ at margins <= 0.02, 0.61 - 0.63 -> 0.70 (their logits span more, and 128
 # channels average less of the f16 rounding away).

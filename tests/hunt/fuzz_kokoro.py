@@ -1,6 +1,6 @@
 """Differential hunt for the Kokoro node's synthesiser: random texts (words, punctuation, digits, accented and CJK code points, lengths from one symbol to the token cap), random
 voices and speeds through libskw_tts.so and through the CPU checker (oracle/skw_kokoro_oracle.cpp): token ids, durations and every tap through the decoder's output bit for bit,
-generator stages within the tolerances of tests/test_gpu_kokoro.py.  Usage (GPU box): python tools/probe/fuzz_kokoro.py [cases] [seed] [size]"""
+generator stages within the tolerances of tests/test_gpu_kokoro.py.  Usage (GPU box): python tests/hunt/fuzz_kokoro.py [cases] [seed] [size]"""
 import os
 import sys
 import time

@@ -1,7 +1,7 @@
 """Differential hunt: random clips (lengths 0.05 - 65 s, levels from silence to clipping, random batch compositions) and random decode parameters through the engine and through the
 oracle, tiny model, exact precision: every transcript must be identical (ids, log-probs, segment times, window counts).  With a third argument `f16`: the same inputs through
 streamkit_amd.parity.teacher_forced_compare instead — f16_mfma fed the exact precision's tokens, every decision equal or at a near-tie, logits within the precision's bound.
-Usage (GPU box): python tools/probe/fuzz_parity.py [rounds] [seed] [f16 | exact [size [quant kind | all]]]"""
+Usage (GPU box): python tests/hunt/fuzz_parity.py [rounds] [seed] [f16 | exact [size [quant kind | all]]]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 """Differential hunt for the linear resampler (R1): random rate pairs (the audio world's rates and odd ones), chunk sizes, channel counts and call sizes through the GPU path
 (skw_dsp, streaming state carried across calls) and through the oracle's rubato restatement, chunk by chunk: every output sample bit-identical, every output length equal.
-Usage (GPU box): python tools/probe/fuzz_resampler.py [cases] [seed]"""
+Usage (GPU box): python tests/hunt/fuzz_resampler.py [cases] [seed]"""
 import os
 import sys
 import time

@@ -1,7 +1,7 @@
 import os, sys, subprocess
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from streamkit_amd import engine
 from oracle_lib import OracleModel

@@ -1,5 +1,5 @@
 """Runs seeded single-instruction problems on the GPU and on the model (oracle/), and saves every element where they differ (operands in slot order, accumulator, both results)
-to gpurun_out/mfma_mismatch.npz — the input of the next refinement of include/skw_mfma_model.h.  Usage (GPU box): python tools/probe/mfma_mismatch_dump.py [problems per kind [seed offset [kind whose tiles to keep]]]"""
+to gpurun_out/mfma_mismatch.npz — the input of the next refinement of include/skw_mfma_model.h.  Usage (GPU box): python tests/hunt/mfma_mismatch_dump.py [problems per kind [seed offset [kind whose tiles to keep]]]"""
 import os
 import sys
 

@@ -6,7 +6,7 @@ for that pair.  (Every parity claim in this repository is "oracle-exact, parity 
          whisper-cli -m ggml-base.en.bin -f clip.wav -l en -bs 1 -bo 1 -nf -ojf -of clip          (greedy, no temperature fallback, full JSON with token ids -> clip.json)
      (with the fallback ladder left on — the node's setting — drop `-nf`; a clip that needs a temperature > 0 then depends on whisper.cpp's std::mt19937 stream, which the oracle
       restates too; start with -nf.)
-  2. python tools/pin_against_whisper_cpp.py --model ggml-base.en.bin --wav clip.wav --json clip.json [--gpu] [--language en]
+  2. python tests/pin_against_whisper_cpp.py --model ggml-base.en.bin --wav clip.wav --json clip.json [--gpu] [--language en]
 
 What is compared, segment by segment: token ids (the north star's "token ids bit-exact (greedy)"), segment start / end (10 ms units), and the text.  The first divergence is printed
 with both sides' tokens around it and the oracle's top1 - top2 margin there: a divergence at a large margin is a restatement error to fix in oracle/ (and then in the kernels, which

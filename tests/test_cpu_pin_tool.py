@@ -1,4 +1,4 @@
-"""tools/pin_against_whisper_cpp.py — the turnkey comparison with the real reference's output (whisper-cli -ojf) for whoever has a trained model file: its parsing and its
+"""tests/pin_against_whisper_cpp.py — the turnkey comparison with the real reference's output (whisper-cli -ojf) for whoever has a trained model file: its parsing and its
 divergence report, exercised on a JSON of whisper-cli's shape written from the oracle's own result (there is no whisper.cpp here to produce one)."""
 import json
 import os
@@ -11,7 +11,7 @@ import numpy as np
 from streamkit_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "tools", "pin_against_whisper_cpp.py")
+TOOL = os.path.join(ROOT, "tests", "pin_against_whisper_cpp.py")
 
 
 def _ms(cs):

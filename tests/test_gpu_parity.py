@@ -403,12 +403,12 @@ def test_non_finite_and_absurd_samples_do_not_hang_or_poison_batch_mates(tiny, p
 
 
 def test_random_clips_and_parameters_match_oracle():
-    """Ten rounds of tools/probe/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
+    """Ten rounds of tests/hunt/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
     model shapes — whatever combination the named tests above do not name."""
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "probe", "fuzz_parity.py"), "10", "20261005"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tests", "hunt", "fuzz_parity.py"), "10", "20261005"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
 
 
