@@ -103,3 +103,29 @@ def test_one_switchboard_one_getenv():
     readme = open(os.path.join(ROOT, "README.md")).read()
     for name in table:
         assert "SKW_" + name in readme, "README.md does not document SKW_" + name
+
+
+def test_only_test_infrastructure_touches_the_oracle():
+    """The oracle is the checker: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call, link or execute anything under oracle/.  The product
+    (streamkit_amd/: Python host side, C++ / HIP sources, the Makefile) and tools/ never do — they may NAME it in comments; they may not load it."""
+    import re
+    load = re.compile(r"oracle_lib|libskw_oracle|OracleModel|dlopen\([^)]*oracle|-lskw_oracle|#include\s+\"[^\"]*oracle")
+    offenders = []
+    for base in ("streamkit_amd", "tools"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "build" in dp or "__pycache__" in dp:
+                continue
+            for f in fs:
+                if f.endswith((".py", ".hip", ".cpp", ".h", ".c", ".sh")) or f == "Makefile":
+                    p = os.path.join(dp, f)
+                    for n, line in enumerate(open(p, encoding="utf-8", errors="replace"), 1):
+                        if load.search(line) and not line.lstrip().startswith(("//", "#", "*", "/*")):
+                            offenders.append("%s:%d" % (os.path.relpath(p, ROOT), n))
+    assert not offenders, offenders
+    # bench.py: every load of the oracle sits inside the cpu_baseline leg (after its marker comment, before the function that holds it ends)
+    src = open(os.path.join(ROOT, "bench.py"), encoding="utf-8").read().split("\n")
+    hits = [i for i, line in enumerate(src) if load.search(line) and not line.lstrip().startswith("#")]
+    marker = next(i for i, line in enumerate(src) if "CPU baseline: the oracle" in line)
+    assert hits and all(marker < i < marker + 40 for i in hits), (hits, marker)
+    entry = open(os.path.join(ROOT, "__graft_entry__.py"), encoding="utf-8").read()
+    assert entry.index("def smoke") < entry.index("oracle_lib")                              # (build() only compiles the checker)
