@@ -129,6 +129,15 @@ void skw_full_default_params(skw_full_params*);
 int  skw_full_batch(skw_ctx*, const skw_full_params*, const float* const* pcm, const int32_t* n_samples, int n_clips,
                     int pcm_on_device, skw_result* results);
 void skw_result_free(skw_result*);
+/* The temperature ladder's generator as the reference keeps it.  whisper.cpp owns ONE std::mt19937 per whisper_state (decoder 0's, seeded with 0 by whisper_init_state) and lets
+ * it run on across calls of whisper_full_with_state; the reference node creates one state per instance (plugins/native/whisper/src/lib.rs:377-379), so an instance's n-th segment
+ * that needs a sampled pass draws from where its earlier segments left the stream.  skw_full_batch_rng is skw_full_batch with that stream handed in and out per clip:
+ * rng_state[i] = NULL (seed 0 for this call, what skw_full_batch does) or SKW_RNG_STATE_WORDS words — mt[624] and the index, initialised once by skw_rng_state_init — which the
+ * call advances exactly as the reference's generator would advance on this clip.  Rows of a batch never share a stream, so the result does not depend on batch composition. */
+#define SKW_RNG_STATE_WORDS 625
+void skw_rng_state_init(uint32_t* state /* [SKW_RNG_STATE_WORDS] */);
+int  skw_full_batch_rng(skw_ctx*, const skw_full_params*, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device,
+                        uint32_t* const* rng_state /* [n_clips], entries may be NULL */, skw_result* results);
 
 /* ---- decision trace / teacher forcing (parity instrumentation of the hot path; the reference has no counterpart) ----
  * skw_full_batch_traced is skw_full_batch that also returns, per clip, one record for EVERY sampling decision it made, in execution order

@@ -997,7 +997,12 @@ int skwo_debug_window(const skwo_model* m, const skwo_params* p, const int32_t* 
 /* whisper_full_with_state, greedy strategy with best_of = 1 (lib.rs:624): one decoder, argmax at t = 0, std::discrete_distribution
  * draws from the decoder's mt19937 on the fallback passes.  DEVIATION D2': the generator is seeded (0) per call; whisper.cpp seeds it
  * when the state is created and lets it run on across calls. */
-int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out) {
+static int full_impl(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out, uint32_t* rng_state);
+int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out) { return full_impl(m, p, pcm, n_samples, out, NULL); }
+/* whisper_full_with_state on a state whose generator has already been used: rng_state = mt[624] + index (625 words; std::mt19937(0) to begin with: whisper_init_state), advanced
+ * by this call exactly as decoder 0's generator is */
+int skwo_full_rng(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out, uint32_t* rng_state) { return full_impl(m, p, pcm, n_samples, out, rng_state); }
+static int full_impl(const skwo_model* m, const skwo_params* p, const float* pcm, int n_samples, skwo_result* out, uint32_t* rng_state) {
     memset(out, 0, sizeof *out); out->min_margin = INFINITY;
 #ifdef _OPENMP
     if (p->n_threads > 0) omp_set_num_threads(p->n_threads);
@@ -1042,6 +1047,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     int32_t prompt[512];
     char* text = (char*)malloc(1 << 16);
     mt19937_t rng; mt_seed(&rng, 0);
+    if (rng_state) { memcpy(rng.mt, rng_state, sizeof rng.mt); rng.idx = (int)rng_state[624]; }
     while (1) {
         if (seek + DELTA_MIN >= seek_end) break;   /* "if only 100ms left, then stop" */
         skwo_encode(m, mel, n_len, seek, 0, enc_out, ck, cv);
@@ -1103,6 +1109,7 @@ int skwo_full(const skwo_model* m, const skwo_params* p, const float* pcm, int n
     }
     free(prompt_past); free(text); free(mel); free(enc_out); free(ck); free(cv); free(raw); free(dc.logits); free(dc.logprobs); free(dc.probs); free(dc.tokens);
     out->n_segments = acc.n_seg; out->segments = acc.seg; out->n_tokens = acc.n_tok; out->tokens = acc.tok; out->text = acc.text; out->text_len = acc.n_text;
+    if (rng_state) { memcpy(rng_state, rng.mt, sizeof rng.mt); rng_state[624] = (uint32_t)rng.idx; }
     return 0;
 }
 void skwo_result_free(skwo_result* r) { free(r->segments); free(r->tokens); free(r->text); memset(r, 0, sizeof *r); }

@@ -110,6 +110,8 @@ int skwo_dec_step(skwo_dec*, const int32_t* tokens, int n_tokens, int n_past, in
 
 /* K11-K12 + W4: whisper_full_with_state, greedy best_of=1, T=0 pass */
 int skwo_full(const skwo_model*, const skwo_params*, const float* pcm, int n_samples, skwo_result* out);
+/* the same on a state whose std::mt19937 has run before: rng_state[625] = mt[624] + index, in and out (NULL: seeded with 0 for this call) */
+int skwo_full_rng(const skwo_model*, const skwo_params*, const float* pcm, int n_samples, skwo_result* out, uint32_t* rng_state);
 /* test hook: n_draws of std::discrete_distribution<>(probs, probs + n) from std::mt19937(seed), as restated in skw_oracle.c */
 int skwo_discrete_draw(const float* probs, int n, uint32_t seed, int n_draws, int32_t* out);
 void skwo_result_free(skwo_result*);

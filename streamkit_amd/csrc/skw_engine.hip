@@ -1151,7 +1151,7 @@ static int move_retry_slots(skw_ctx* c, const std::vector<int>& old_slots) {
 }
 
 static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results,
-                           const int32_t* const* forced_ids, const int32_t* n_forced, std::vector<std::vector<SkwTraceStep>>* traces) {
+                           const int32_t* const* forced_ids, const int32_t* n_forced, std::vector<std::vector<SkwTraceStep>>* traces, uint32_t* const* rng_state = nullptr) {
     char* errbuf = c->errbuf; errbuf[0] = 0;
     WS_READY(c);
     if (n_clips < 1 || n_clips > c->max_batch) { snprintf(errbuf, 512, "n_clips %d outside [1, %d]", n_clips, c->max_batch); return -1; }
@@ -1182,7 +1182,14 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
     std::vector<int> tidx(n_clips, 0), retry_slot(n_clips, -1);   // retry_slot: the window slot whose cross K/V a retrying clip left behind (-1: not retrying)
     // prompt_past (whisper_full_with_state): text already produced in this call conditions the next window of the same clip
     std::vector<std::vector<int>> prompt_past(n_clips); std::vector<int> last_take(n_clips, 0);
-    skw_rng_seed(c->rng, n_clips, 0u, c->stream);   // DEVIATION D2': seeded per call (whisper.cpp: per state, running on across calls)
+    // the sampled passes' generator: whisper.cpp keeps ONE std::mt19937 per state (decoder 0, seeded with 0 when the state is created) and lets it run on across calls.  A caller
+    // that owns such a stream per clip (the plugin: one per instance, lib.rs:377-379) hands its state in and gets it back (skw_full_batch_rng); without one the stream starts at
+    // seed 0 in every call (D2': what a batch of unrelated clips can do)
+    skw_rng_seed(c->rng, n_clips, 0u, c->stream);
+    if (rng_state) for (int i = 0; i < n_clips; ++i) if (rng_state[i]) {
+        if (rng_state[i][624] > 624u) { snprintf(errbuf, 512, "clip %d: the generator state handed in is not a std::mt19937 state (index %u)", i, rng_state[i][624]); return -1; }
+        HIPCHK(hipMemcpyAsync(c->rng + (size_t)i * SKW_RNG_WORDS, rng_state[i], sizeof(uint32_t) * SKW_RNG_WORDS, hipMemcpyHostToDevice, c->stream));
+    }
     // language: fixed by the caller, or (lang_id < 0, whisper.cpp's "auto") detected per clip from the [sot] step on the first window
     std::vector<int> lang(n_clips, p->lang_id);
     if (p->lang_id < 0) {
@@ -1423,6 +1430,8 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
         }
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    if (rng_state) for (int i = 0; i < n_clips; ++i) if (rng_state[i])
+        HIPCHK(hipMemcpyAsync(rng_state[i], c->rng + (size_t)i * SKW_RNG_WORDS, sizeof(uint32_t) * SKW_RNG_WORDS, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());          // a launch that failed (bad configuration, lost device) must not look like a transcript
     for (int i = 0; i < n_clips; ++i) {
@@ -1443,6 +1452,15 @@ static int full_batch_impl(skw_ctx* c, const skw_full_params* p, const float* co
 extern "C" int skw_full_batch(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device, skw_result* results) {
     try { return full_batch_impl(c, p, pcm, n_samples, n_clips, pcm_on_device, results, nullptr, nullptr, nullptr); }
     catch (const std::exception& e) { snprintf(c->errbuf, 512, "skw_full_batch: %s", e.what()); return -5; }      // nothing may unwind across the C ABI
+}
+extern "C" void skw_rng_state_init(uint32_t* state) {      // std::mt19937(0), as whisper_init_state leaves decoder 0's generator
+    state[0] = 0u; for (int i = 1; i < 624; ++i) state[i] = 1812433253u * (state[i - 1] ^ (state[i - 1] >> 30)) + (uint32_t)i;
+    state[624] = 624u;
+}
+extern "C" int skw_full_batch_rng(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device,
+                                  uint32_t* const* rng_state, skw_result* results) {
+    try { return full_batch_impl(c, p, pcm, n_samples, n_clips, pcm_on_device, results, nullptr, nullptr, nullptr, rng_state); }
+    catch (const std::exception& e) { snprintf(c->errbuf, 512, "skw_full_batch_rng: %s", e.what()); return -5; }
 }
 extern "C" int skw_full_batch_traced(skw_ctx* c, const skw_full_params* p, const float* const* pcm, const int32_t* n_samples, int n_clips, int pcm_on_device,
                                      const int32_t* const* forced_ids, const int32_t* n_forced, skw_trace* traces, skw_result* results) {

@@ -144,6 +144,7 @@ struct PinnedPool {
 struct Job {
     std::vector<float> pcm_pageable; PinnedPool::Buf pinned{nullptr, 0}; size_t n = 0;
     skw_full_params params; std::promise<int> done; skw_result result{}; std::string error;
+    uint32_t* rng = nullptr;      // the owning instance's std::mt19937 stream (WhisperPlugin::rng): continued by this segment's sampled passes, if it needs any
     void set_samples(const std::vector<float>& v) {
         n = v.size(); pinned = PinnedPool::get().acquire(n);
         if (pinned.p) memcpy(pinned.p, v.data(), n * sizeof(float)); else pcm_pageable = v;      // (no page-locked memory to be had: the ordinary copy path)
@@ -226,7 +227,8 @@ struct SharedEngine {
                 for (int i = 0; i < n; ++i) { ptrs[i] = batch[i]->data(); ns[i] = (int32_t)batch[i]->n; need = std::max(need, (int)ns[i]); }
                 std::lock_guard<std::mutex> wl(ws_mu);
                 if (ensure_workspace(need, n, &why)) {
-                    rc = skw_full_batch(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, res.data());
+                    std::vector<uint32_t*> rngs(n); for (int i = 0; i < n; ++i) rngs[i] = batch[i]->rng;
+                    rc = skw_full_batch_rng(ctx, &batch[0]->params, ptrs.data(), ns.data(), n, 0, rngs.data(), res.data());
                     if (rc == 0) for (int i = 0; i < n; ++i) batch[i]->result = res[i]; else why = skw_ctx_last_error(ctx);
                 }
             } catch (const std::exception& e) { rc = -1; why = e.what(); }     // the worker thread must not die with waiters blocked on it
@@ -262,7 +264,11 @@ void resolve_auto_device(WhisperConfig* cfg) {
 struct WhisperPlugin {
     WhisperConfig config; std::shared_ptr<SharedEngine> engine; skw::Segmenter seg; std::unique_ptr<skw::Vad> vad;
     // the engine this instance holds, counted (SharedEngine::live_instances): the last holder to let go returns the batch workspace
-    void hold(std::shared_ptr<SharedEngine> e) { if (e) e->instance_added(); if (engine) engine->instance_gone(); engine = std::move(e); }
+    // whisper.cpp keeps one std::mt19937 per whisper_state (seeded with 0 at whisper_init_state) for the temperature ladder's draws and lets it run on across calls; the
+    // reference creates one state per instance (lib.rs:377-379) and a new one when update_params swaps the context (lib.rs:520-535).  This is that generator: every segment of
+    // this instance continues it (skw_full_batch_rng), whichever batch the segment lands in.
+    uint32_t rng[SKW_RNG_STATE_WORDS];
+    void hold(std::shared_ptr<SharedEngine> e) { if (e) e->instance_added(); if (engine) engine->instance_gone(); engine = std::move(e); skw_rng_state_init(rng); }
     ~WhisperPlugin() { if (engine) engine->instance_gone(); }
     std::unique_ptr<skw::ResamplerCore> front;      // input_sample_rate != 16000: the audio::resampler node's arithmetic on the GPU, feeding the segmenter
     CLogCallback log_cb = nullptr; void* log_ud = nullptr;
@@ -394,6 +400,7 @@ bool transcribe_and_emit(WhisperPlugin* self, const Emit& em, const skw::Segment
     job->params.lang_id = lang; job->params.translate = 0;
     job->params.suppress_blank = self->config.suppress_blank ? 1 : 0; job->params.suppress_nst = self->config.suppress_non_speech_tokens ? 1 : 0;
     job->params.n_threads = (int32_t)self->config.n_threads;
+    job->rng = self->rng;
     if ((int)job->n > SharedEngine::kMaxSamples) { *err = "Whisper inference failed: segment longer than the engine workspace"; return false; }
     std::future<int> fut = job->done.get_future();
     { std::lock_guard<std::mutex> l(self->engine->mu); self->engine->queue.push_back(job); }

@@ -88,6 +88,8 @@ def lib():
         L.skw_ctx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.skw_full_default_params.argtypes = [C.POINTER(FullParams)]
         L.skw_full_batch.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(Result)]
+        L.skw_full_batch_rng.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(Result)]
+        L.skw_rng_state_init.argtypes = [C.c_void_p]
         L.skw_result_free.argtypes = [C.POINTER(Result)]
         L.skw_full_batch_traced.argtypes = [C.c_void_p, C.POINTER(FullParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int, C.c_int,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(Trace), C.POINTER(Result)]
@@ -149,6 +151,13 @@ def _result_to_dict(r):
                 fallback_requested=r.fallback_requested, min_margin=r.min_margin, lang_id=r.lang_id)
 
 
+def rng_state_new():
+    """std::mt19937(0) as a uint32[625] (mt + index): the generator a freshly created whisper_state owns"""
+    s = np.zeros(625, np.uint32)
+    lib().skw_rng_state_init(s.ctypes.data)
+    return s
+
+
 class Model:
     def __init__(self, path, device=0, quant_mode=1):
         """quant_mode (block-quantised files): 1 = ggml's q8 arithmetic in the exact precision (SKW_QUANT_GGML), 0 = the dequantised f16 twin everywhere"""
@@ -203,10 +212,12 @@ class Context:
         lib().skw_full_default_params(C.byref(p))
         return p
 
-    def full_batch(self, clips, params=None, device_ptrs=None, n_samples=None, trace=False, forced=None):
+    def full_batch(self, clips, params=None, device_ptrs=None, n_samples=None, trace=False, forced=None, rng_states=None):
         """clips: list of 1-D float32 numpy arrays (host), or device_ptrs + n_samples for HBM-resident PCM.
         trace=True (or forced=[per-clip int32 id sequences]): skw_full_batch_traced — returns (results, traces), traces[i] a structured
-        array (TRACE_DT) with one record per sampling decision of clip i; with `forced` the decoder is fed those ids (teacher forcing)."""
+        array (TRACE_DT) with one record per sampling decision of clip i; with `forced` the decoder is fed those ids (teacher forcing).
+        rng_states=[uint32[625] or None per clip] (rng_state_new()): the temperature ladder's std::mt19937 stream of each clip's OWNER, continued and updated in place
+        (skw_full_batch_rng: whisper.cpp keeps one generator per state and lets it run on across calls)."""
         p = params or self.default_params()
         if device_ptrs is not None:
             n = len(device_ptrs)
@@ -233,6 +244,10 @@ class Context:
                 a = np.frombuffer((C.c_char * (tr[i].n * TRACE_DT.itemsize)).from_address(tr[i].steps), dtype=TRACE_DT).copy() if tr[i].n else np.zeros(0, TRACE_DT)
                 traces.append(a)
                 lib().skw_trace_free(C.byref(tr[i]))
+        elif rng_states is not None:
+            assert len(rng_states) == n and all(s is None or (s.dtype == np.uint32 and s.size == 625 and s.flags["C_CONTIGUOUS"]) for s in rng_states)
+            sp = (C.c_void_p * n)(*[None if s is None else s.ctypes.data for s in rng_states])
+            self._check(lib().skw_full_batch_rng(self.h, C.byref(p), ptrs, ns, n, on_dev, sp, res))
         else:
             self._check(lib().skw_full_batch(self.h, C.byref(p), ptrs, ns, n, on_dev, res))
         out = [_result_to_dict(res[i]) for i in range(n)]

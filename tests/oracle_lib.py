@@ -63,6 +63,7 @@ def lib():
         L.skwo_dec_free.argtypes = [C.c_void_p]
         L.skwo_dec_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.skwo_full.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int, C.POINTER(Result)]
+        L.skwo_full_rng.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int, C.POINTER(Result), C.c_void_p]
         L.skwo_result_free.argtypes = [C.POINTER(Result)]
         L.skwo_resampler_new.restype = C.c_void_p
         L.skwo_resampler_new.argtypes = [C.c_double, C.c_int, C.c_int]
@@ -148,11 +149,16 @@ class OracleModel:
     def decoder(self, ck, cv):
         return OracleDecoder(self, ck, cv)
 
-    def full(self, pcm, params=None):
+    def full(self, pcm, params=None, rng_state=None):
+        """rng_state: a uint32[625] std::mt19937 state (mt + index) that the call continues and updates in place — whisper.cpp's per-state generator; None: seeded with 0"""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         p = params or self.default_params()
         r = Result()
-        rc = lib().skwo_full(self.h, C.byref(p), pcm.ctypes.data, pcm.size, C.byref(r))
+        if rng_state is not None:
+            assert rng_state.dtype == np.uint32 and rng_state.size == 625 and rng_state.flags["C_CONTIGUOUS"]
+            rc = lib().skwo_full_rng(self.h, C.byref(p), pcm.ctypes.data, pcm.size, C.byref(r), rng_state.ctypes.data)
+        else:
+            rc = lib().skwo_full(self.h, C.byref(p), pcm.ctypes.data, pcm.size, C.byref(r))
         if rc != 0:
             raise RuntimeError("skwo_full rc=%d" % rc)
         text = C.string_at(r.text, r.text_len) if r.text else b""

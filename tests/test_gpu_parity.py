@@ -227,6 +227,37 @@ def test_temperature_fallback_ladder_matches_oracle(tiny):
         assert [t[2] for t in rg["tokens"]] == [t[2] for t in ro["tokens"]]          # sampled-token probabilities, bit for bit
 
 
+def test_ladder_generator_runs_on_across_calls_like_whisper_cpps(tiny, eng):
+    """whisper.cpp keeps ONE std::mt19937 per whisper_state (seeded with 0 when the state is created) for the sampled passes and lets it run on across calls; the reference node has
+    one state per instance (lib.rs:377-379), so its n-th segment draws from where the earlier ones stopped.  skw_full_batch_rng hands that stream in and out per clip: three
+    "instances" send three segments each through three batched calls (a different batch composition every time); every segment equals the oracle's sequential run of that instance
+    on a generator that is never re-seeded — and differs from what a per-call seed gives, or the test would not see the stream at all."""
+    _, ctx, om = tiny
+    p = ctx.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0            # no pass is accepted: every window walks the ladder and draws
+    po = om.default_params(); po.logprob_thold = 1.0; po.no_speech_thold = 2.0
+    segs = [[synth.clip(10 * i + k, 16000 * (6 + 3 * k + i)) for k in range(3)] for i in range(3)]      # segs[instance][call]
+    gpu_state = [eng.rng_state_new() for _ in range(3)]; cpu_state = [eng.rng_state_new() for _ in range(3)]
+    assert gpu_state[0][624] == 624 and gpu_state[0][1] == 1812433253 * (0 ^ 0) + 1
+    seen_difference = False
+    for call in range(3):
+        order = [(call + j) % 3 for j in range(3)]                                       # instance order inside the batch changes from call to call
+        res = ctx.full_batch([segs[i][call] for i in order], p, rng_states=[gpu_state[i] for i in order])
+        for i, rg in zip(order, res):
+            ro = om.full(segs[i][call], po, rng_state=cpu_state[i])
+            assert ro["fallback_requested"] > 0 and _same(rg, ro), (call, i)
+            assert [t[2] for t in rg["tokens"]] == [t[2] for t in ro["tokens"]]
+            assert np.array_equal(gpu_state[i], cpu_state[i])                             # the stream stands where the oracle's stands
+            if call > 0 and not _same(rg, om.full(segs[i][call], po)):
+                seen_difference = True
+    assert seen_difference
+    # no state handed in: the documented per-call seed (what a batch of unrelated clips gets), and a NULL entry inside a batch that has states
+    r0 = ctx.full_batch([segs[0][2], segs[1][2]], p, rng_states=[None, eng.rng_state_new()])
+    assert _same(r0[0], om.full(segs[0][2], po)) and _same(r0[1], om.full(segs[1][2], po))
+    bad = eng.rng_state_new(); bad[624] = 9999
+    with pytest.raises(RuntimeError, match="not a std::mt19937 state"):
+        ctx.full_batch([segs[0][0]], p, rng_states=[bad])
+
+
 def test_fallback_only_for_the_clips_that_need_it(tiny):
     """A threshold between the clips' average log-probs sends some clips up the ladder while their batch mates keep the greedy pass."""
     _, ctx, om = tiny

@@ -1,6 +1,7 @@
 """GPU tests of the drop-in boundary: libwhisper.so driven through the StreamKit native-plugin C ABI by the C++ mini-host,
 replaying the reference host's call sequence (wrapper.rs) and the config-1 node chain around it."""
 import json
+import os
 import threading
 
 import numpy as np
@@ -478,3 +479,39 @@ def test_many_instances_with_different_parameters_on_threads_keep_their_own_resu
                 assert got[0]["language"] == cfg["language"], k          # the configured string, "auto" included (lib.rs:687: self.config.language.clone())
         else:
             assert results[k] == alone(cfg, pcm), k
+
+
+def test_an_instance_continues_its_own_ladder_generator_across_segments(plugin):
+    """The reference node owns one whisper_state per instance (lib.rs:377-379) and whisper.cpp's sampled passes draw from that state's std::mt19937, which is never re-seeded: the
+    second segment of a stream that needs the temperature ladder draws from where the first stopped.  A model whose greedy pass fails the default log-prob threshold (every window
+    needs one sampled pass) through two instances at once, three forced-cut segments each: every Transcription equals the oracle's run of THAT instance's segments in order on
+    one continuing generator — whichever batch a segment landed in — and the second and third differ from what a freshly seeded generator would give."""
+    from conftest import _ensure_built
+    import subprocess
+    path = "/tmp/skw_test_micro_gamma8.bin"
+    if not os.path.exists(path):
+        subprocess.check_call([_ensure_built(), path + ".tmp", "--size", "micro", "--gamma_text", "8"]); os.replace(path + ".tmp", path)
+    om = OracleModel(path); po = om.default_params(); po.suppress_nst = 1
+    from streamkit_amd import engine
+    streams = [synth.clip(61, 16000 * 26), synth.clip(62, 16000 * 25)]
+    cfg = {"model_path": path, "vad_mode": "always", "max_segment_duration_secs": 8.0, "batch_window_ms": 40}
+    nodes = [plugin.create_node(cfg) for _ in streams]
+    ths = [threading.Thread(target=_feed, args=(n, s, 960)) for n, s in zip(nodes, streams)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    differs_from_fresh = 0
+    for node, pcm in zip(nodes, streams):
+        outs = [json.loads(o[2].decode()) for o in node.outputs()]
+        cuts = oracle_lib.segment_sim(np.ones(pcm.size // 512, np.float32), 0.5, 700, 8.0)
+        assert len(cuts) == 3 and len(outs) == 3
+        state = engine.rng_state_new(); pos = 0
+        for k, (cut, got) in enumerate(zip(cuts, outs)):
+            seg = pcm[pos:pos + cut[2]]; pos += cut[2]
+            r = om.full(seg, po, rng_state=state)
+            assert r["fallback_requested"] >= 1
+            want = [{"text": s["text"].decode().strip(), "start_time_ms": cut[0] + s["t0"] * 10, "end_time_ms": cut[0] + s["t1"] * 10, "confidence": None} for s in r["segments"] if s["text"].decode().strip()]
+            assert got["segments"] == want, k
+            fresh = om.full(seg, po)
+            if k > 0 and [s["text"] for s in fresh["segments"]] != [s["text"] for s in r["segments"]]:
+                differs_from_fresh += 1
+        node.destroy()
+    assert differs_from_fresh >= 2
