@@ -9,6 +9,7 @@
 #pragma once
 #include "../../include/skw_engine.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <functional>
 #include <string>
@@ -33,10 +34,23 @@ struct ResamplerCore {
         while (output_buffer.size() - off >= fs) { if (!sink(output_buffer.data() + off, fs, err)) return false; off += fs; }
         output_buffer.erase(output_buffer.begin(), output_buffer.begin() + off); return true;
     }
+    // frames each of the next n_chunks chunks will produce: the index recurrence of rubato's FastFixedIn (the engine walks the same IEEE additions on long calls, skw_engine.hip
+    // skw_resample_linear) replayed on the host from the state BEFORE the call — so that a batched GPU call can still be handed on chunk by chunk
+    static void chunk_counts(const skw_resampler_state& s, int n_chunks, std::vector<int>* counts) {
+        const double t_ratio = 1.0 / s.ratio, end_idx = (double)(s.chunk_frames - 9) - std::ceil(t_ratio); double x0 = s.last_index;
+        counts->assign((size_t)n_chunks, 0);
+        for (int c = 0; c < n_chunks; ++c) { double x = x0; int n = 0; while (x < end_idx) { x += t_ratio; ++n; } (*counts)[(size_t)c] = n; x0 = x - (double)s.chunk_frames; }
+    }
+    std::vector<int> last_counts;      // per chunk of the last run_chunks call
     bool run_chunks(skw_resampler_state* s, const float* in, int n_chunks, std::vector<float>* out, std::string* err) {
         const double ratio = s->ratio; const int cap = (int)((double)n_chunks * s->chunk_frames * ratio) + 64;
+        chunk_counts(*s, n_chunks, &last_counts);
         out->resize((size_t)cap * channels); int n = 0;
         if (skw_resample_linear(dsp, s, in, n_chunks, out->data(), cap, &n) != 0) { *err = std::string("Resampling failed: ") + skw_dsp_last_error(dsp); return false; }
+        long sum = 0; for (int c : last_counts) sum += c;
+        if (sum != n) {
+            *err = "Resampling failed: the host's replay of the index recurrence disagrees with the device (" + std::to_string(sum) + " vs " + std::to_string(n) + " frames)"; return false;
+        }
         out->resize((size_t)n * channels); return true;
     }
     // streaming polyphase: every output whose filter support has arrived (all of them at end of stream); the input tail that later
@@ -49,10 +63,14 @@ struct ResamplerCore {
         if (skw_polyphase_stream_push(pp, in, n_frames, final_call ? 1 : 0, out->data(), cap, &got) != 0) { *err = std::string("Resampling failed: ") + skw_dsp_last_error(dsp); return false; }
         out->resize((size_t)got * channels); return true;
     }
-    bool deliver(const Sink& sink, std::string* err) {      // scratch -> re-chunker or straight out
-        if (scratch.empty()) return true;
-        if (out_frame > 0) { output_buffer.insert(output_buffer.end(), scratch.begin(), scratch.end()); return drain(sink, err); }
-        return sink(scratch.data(), scratch.size(), err);
+    // scratch -> re-chunker, or straight out.  Without re-chunking the reference sends ONE packet per processed chunk (resampler.rs:471-510), also when a chunk produced no
+    // frame; per_chunk: scratch holds the output of last_counts.size() chunks back to back (the linear mode); else one packet (the additive polyphase mode, which has no chunks)
+    bool deliver(const Sink& sink, std::string* err, bool per_chunk = false) {
+        if (out_frame > 0) { if (scratch.empty()) return true; output_buffer.insert(output_buffer.end(), scratch.begin(), scratch.end()); return drain(sink, err); }
+        if (!per_chunk) return scratch.empty() ? true : sink(scratch.data(), scratch.size(), err);
+        size_t off = 0;
+        for (int n : last_counts) { if (!sink(scratch.data() + off, (size_t)n * channels, err)) return false; off += (size_t)n * channels; }
+        return true;
     }
 
     // one input packet (resampler.rs:247-527).  false + *err on failure.
@@ -86,8 +104,7 @@ struct ResamplerCore {
         if (n_chunks > 0) {
             if (!run_chunks(&st, sample_buffer.data(), n_chunks, &scratch, err)) return false;
             sample_buffer.erase(sample_buffer.begin(), sample_buffer.begin() + (size_t)n_chunks * cs);
-            // (without re-chunking the reference emits one packet per processed chunk; chunk boundaries are recovered from the frame counts)
-            if (!deliver(sink, err)) return false;
+            if (!deliver(sink, err, true)) return false;
         }
         return true;
     }
@@ -102,7 +119,7 @@ struct ResamplerCore {
             if (rem >= 1) {   // fresh resampler sized to the remainder: zero history, last_index = -4 (resampler.rs:564-570)
                 skw_resampler_state t; skw_resampler_init(&t, (double)target / (double)rate, (int)rem, channels);
                 if (!run_chunks(&t, sample_buffer.data(), 1, &scratch, err)) return false;
-                if (!deliver(sink, err)) return false;
+                if (!deliver(sink, err, true)) return false;
             }
             sample_buffer.clear();
         }

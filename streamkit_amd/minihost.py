@@ -155,7 +155,7 @@ class Resampler:
         for i in range(lib().mh_resampler_out_count(self.h)):
             n = C.c_size_t(); ts = C.c_uint64(); has = C.c_int(); dur = C.c_uint64(); seq = C.c_uint64()
             p = lib().mh_resampler_out(self.h, i, C.byref(n), C.byref(ts), C.byref(has), C.byref(dur), C.byref(seq))
-            out.append(dict(samples=np.ctypeslib.as_array(p, shape=(n.value,)).copy(), timestamp_us=ts.value if has.value else None, duration_us=dur.value, sequence=seq.value))
+            out.append(dict(samples=(np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)), timestamp_us=ts.value if has.value else None, duration_us=dur.value, sequence=seq.value))
         if clear:
             lib().mh_resampler_clear(self.h)
         return out

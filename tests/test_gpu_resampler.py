@@ -121,6 +121,26 @@ def test_resampler_plugin_equals_host_node(dsp):
     n2.destroy()
 
 
+@pytest.mark.parametrize("in_rate,out_rate,ch,chunk,packet", [(32000, 44100, 1, 160, 4000), (8000, 96000, 1, 960, 2897), (48000, 16000, 2, 480, 5000), (44100, 16000, 1, 1024, 300)])
+def test_resampler_plugin_without_rechunking_sends_one_packet_per_chunk(dsp, in_rate, out_rate, ch, chunk, packet):
+    """output_frame_size = 0: the reference sends what each processed chunk produced as a packet of its own (resampler.rs:471-510), also when an input packet held many chunks.  The
+    plugin resamples all the chunks of a packet in ONE GPU call, so it has to cut the result back into the per-chunk packets (the host replays the index recurrence for the
+    counts).  Round 5's differential hunt (tests/hunt/fuzz_resampler_plugin.py) found it sending one packet per call instead: same samples, different packets."""
+    p = minihost.Plugin(minihost.os.path.join(minihost.ROOT, "streamkit_amd", "libresampler.so"))
+    x = _signal((in_rate + 777) * ch, ch, seed=in_rate + chunk)
+    node = p.create_node({"target_sample_rate": out_rate, "chunk_frames": chunk, "output_frame_size": 0})
+    ref = minihost.Resampler(out_rate, chunk, 0)
+    for i in range(0, x.size, packet * ch):
+        assert node.process_audio(x[i:i + packet * ch], in_rate, ch) == 0, node.last_error()
+        ref.push(x[i:i + packet * ch], in_rate, ch)
+    assert node.flush() == 0
+    ref.finish()
+    got = [np.frombuffer(o[2], dtype=np.float32) for o in node.outputs()]; exp = [pk["samples"] for pk in ref.packets()]
+    assert len(exp) >= (in_rate + 777) // chunk and [g.size for g in got] == [e.size for e in exp]
+    assert all(np.array_equal(g.view(np.uint32), e.view(np.uint32)) for g, e in zip(got, exp))
+    node.destroy()
+
+
 @pytest.mark.parametrize("in_rate,ch,packet", [(48000, 1, 960), (44100, 1, 1111), (48000, 2, 500), (8000, 1, 160)])
 def test_resampler_plugin_polyphase_streaming_equals_whole_buffer(dsp, in_rate, ch, packet):
     """mode = polyphase (additive): the plugin filters a stream packet by packet, carrying only the input its later outputs need;
