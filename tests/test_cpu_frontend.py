@@ -41,6 +41,43 @@ def test_segmenter_product_equals_oracle_random(built):
         assert oracle_lib.segment_sim(prob, thr, ms, mx) == minihost.segment_sim(prob, thr, ms, mx)
 
 
+def test_segmenter_agrees_with_a_third_restatement_of_the_reference_loop(built):
+    """The product's segmenter and the oracle's simulator against a third restatement, written from plugins/native/whisper/src/lib.rs:404-494 in Python for this test: a frame
+    is speech when its probability reaches the threshold; only speech frames are buffered; the maximum duration is checked with the time of the frame that was just buffered
+    (before the 32 ms advance) and ends the segment at that time + 32; silence_threshold_frames = min_silence_duration_ms / 32 (integer) non-speech frames close a segment at
+    abs - (silence_frames - 1) * 32.  One cut = [start_ms, end_ms, samples handed to Whisper, reason (0 max duration, 1 silence), silence ms or -1, index of the closing frame]."""
+    def loop(prob, thr, min_silence_ms, max_secs):
+        cuts = []; n_buf = 0; abs_ms = 0; start = 0; silence = 0
+        sil_thr = min_silence_ms // 32; max_ms = int(np.float32(max_secs) * np.float32(1000.0))
+        for f, pr in enumerate(prob):
+            if pr >= np.float32(thr):
+                silence = 0
+                if n_buf == 0:
+                    start = abs_ms
+                n_buf += 1
+                if abs_ms - start >= max_ms:
+                    cuts.append([start, abs_ms + 32, n_buf * 512, 0, -1, f]); n_buf = 0; silence = 0
+            else:
+                silence += 1
+                if n_buf and silence >= sil_thr:
+                    cuts.append([start, abs_ms - (silence - 1) * 32, n_buf * 512, 1, silence * 32, f]); n_buf = 0; silence = 0
+            abs_ms += 32
+        return cuts
+    rng = np.random.default_rng(17)
+    n_cuts = 0
+    for trial in range(120):
+        n = int(rng.integers(1, 3000))
+        prob = np.zeros(n, dtype=np.float32); i = 0; state = rng.random() < 0.5
+        while i < n:
+            run = int(rng.integers(1, 300)); prob[i:i + run] = rng.random(min(run, n - i)) * 0.5 + (0.5 if state else 0.0) if trial % 2 else rng.random() * 0.5 + (0.5 if state else 0.0)
+            i += run; state = not state
+        thr = float(rng.choice([0.3, 0.5, 0.5, 0.7, 0.75])); ms = int(rng.choice([31, 32, 100, 320, 700, 1000])); mx = float(rng.choice([0.5, 5.0, 9.5, 12.5, 30.0]))
+        want = loop(prob, thr, ms, mx); n_cuts += len(want)
+        assert minihost.segment_sim(prob, thr, ms, mx, max_cuts=4096) == want, (trial, thr, ms, mx)
+        assert oracle_lib.segment_sim(prob, thr, ms, mx, max_cuts=4096) == want, (trial, thr, ms, mx)
+    assert n_cuts > 300
+
+
 def test_resampler_reference_length_golden(built):
     # resampler.rs:816-837: 960 interleaved stereo samples (480 frames) 48k->24k, chunk_frames 960, output_frame_size 0
     # -> remainder path with a fresh FastFixedIn(480 frames): |len - 480| < 10, rate/channels preserved
