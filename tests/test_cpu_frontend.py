@@ -146,6 +146,24 @@ def test_json_helpers_match_serde_shapes(built):
     assert L.mh_utf8_valid(b"ok \xe2\x99\xaa", 6) == 1 and L.mh_utf8_valid(b"\xe2\x99", 2) == 0
 
 
+def test_json_quote_and_trim_against_pythons_own_on_random_strings(built):
+    """serde_json writes a string with the quote and the backslash escaped, backspace / form feed / newline / carriage return / tab in their short forms, the other control
+    characters as six-character lower-case hex escapes, and everything else — DEL and all non-ASCII included — as it stands; json.dumps(ensure_ascii=False) follows the same rules,
+    so it serves as the second implementation.  str::trim removes Unicode White_Space at both ends — U+0009..000D, 0020, 0085, 00A0, 1680, 2000..200A, 2028, 2029, 202F, 205F,
+    3000; NOT U+001C..001F, which Python's own strip() also removes — so the comparison strips that set explicitly.  500 random strings over an alphabet of awkward characters."""
+    import json
+    L = minihost.lib()
+    rng = np.random.default_rng(23)
+    alphabet = [chr(c) for c in (0x61, 0x62, 0x20, 0x5a, 0x30, 0x39, 0x22, 0x5c, 0x2f, 0x08, 0x0c, 0x0a, 0x0d, 0x09, 0x01, 0x1f, 0x7f, 0x27, 0x3c, 0x3e, 0x26, 0xe9, 0xdf, 0x4f60, 0x597d,
+                                         0x266a, 0xa0, 0x2028, 0x3000, 0xfeff, 0x1f600, 0x20)]
+    WS = "".join(chr(c) for c in list(range(0x09, 0x0e)) + [0x20, 0x85, 0xa0, 0x1680] + list(range(0x2000, 0x200b)) + [0x2028, 0x2029, 0x202f, 0x205f, 0x3000])
+    alphabet += [chr(0x85), chr(0x2003), chr(0x202f), chr(0x1c)]
+    for _ in range(500):
+        s = "".join(rng.choice(alphabet) for _ in range(int(rng.integers(0, 40))))
+        assert L.mh_json_quote(s.encode()).decode() == json.dumps(s, ensure_ascii=False), repr(s)
+        assert L.mh_utf8_trim(s.encode()).decode() == s.strip(WS), repr(s)
+
+
 def test_binade_stepping_equals_the_sequential_index_walk():
     """The arithmetic k_resample_starts uses to propose every chunk's start index (whole binades of the f64 index per step, round-to-even
     ties included) against rubato's sequential `idx += t_ratio` walk, restated here in Python floats (IEEE f64, same roundings): identical
