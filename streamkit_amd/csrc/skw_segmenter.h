@@ -90,10 +90,24 @@ inline std::string json_quote(const std::string& s) {
     return o + "\"";
 }
 // an f32 as serde_json prints it without arbitrary_precision: widened to f64, shortest round-trip digits, always a fraction or exponent
+// an f32 as serde_json writes it inside a `json!` value: widened to f64 (Value holds f64), then ryu's shortest round-trip digits in ryu's layout — plain decimals while the
+// decimal point lies within 16 digits to the right or 5 zeros to the left of the first digit ("0.5", "0.699999988079071", "100000.0", "0.00001"), else d[.ddd]e[-]x without
+// padding or plus sign ("1e-6", "1.5e16").  (Rounds 2-4 used printf's %g layout, which agrees on every value a threshold or a speech probability takes and differs outside.)
 inline std::string json_f32(float f) {
     double d = (double)f; if (!std::isfinite(d)) return "null";
-    char buf[40]; for (int prec = 1; prec <= 17; ++prec) { snprintf(buf, sizeof buf, "%.*g", prec, d); if (strtod(buf, nullptr) == d) break; }
-    std::string s = buf; if (s.find('.') == std::string::npos && s.find('e') == std::string::npos && s.find("inf") == std::string::npos) s += ".0"; return s;
+    if (d == 0.0) return std::signbit(d) ? "-0.0" : "0.0";
+    char buf[48]; int prec = 0; for (prec = 0; prec <= 16; ++prec) { snprintf(buf, sizeof buf, "%.*e", prec, std::fabs(d)); if (strtod(buf, nullptr) == std::fabs(d)) break; }
+    std::string digits; int e10 = 0;
+    { const char* p = buf; for (; *p && *p != 'e'; ++p) if (*p >= '0' && *p <= '9') digits.push_back(*p); e10 = atoi(p + 1); }
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const int length = (int)digits.size(), k = e10 - (length - 1), kk = length + k;
+    std::string r = d < 0 ? "-" : "";
+    if (0 <= k && kk <= 16) r += digits + std::string((size_t)k, '0') + ".0";
+    else if (0 < kk && kk <= 16) r += digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+    else if (-5 < kk && kk <= 0) r += "0." + std::string((size_t)(-kk), '0') + digits;
+    else if (length == 1) r += digits + "e" + std::to_string(kk - 1);
+    else r += digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+    return r;
 }
 
 // ------------------------------------------------------------------ UTF-8

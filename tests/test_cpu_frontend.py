@@ -141,9 +141,48 @@ def test_json_helpers_match_serde_shapes(built):
     L = minihost.lib()
     assert L.mh_json_quote('a"b\\c\n\t\x01é'.encode()).decode() == '"a\\"b\\\\c\\n\\t\\u0001é"'
     assert L.mh_json_f32(0.5) == b"0.5" and L.mh_json_f32(1.0) == b"1.0"
-    assert float(L.mh_json_f32(np.float32(0.7))) == float(np.float32(0.7))
     assert L.mh_utf8_trim(" \t hello world 　".encode()).decode() == "hello world"
     assert L.mh_utf8_valid(b"ok \xe2\x99\xaa", 6) == 1 and L.mh_utf8_valid(b"\xe2\x99", 2) == 0
+
+
+def test_json_f32_is_the_widened_value_in_ryus_layout(built):
+    """`json!({"threshold": self.config.vad_threshold})` holds the f32 widened to f64 (serde_json's Value), and serde_json prints f64 with ryu: shortest round-trip digits, plain
+    decimals while the point lies within 16 digits right / 5 zeros left of the first digit, else d[.ddd]e[-]x.  Second implementation: Python's repr() for the digits (also shortest
+    round-trip) laid out by those rules."""
+    import ctypes as C
+    L = minihost.lib(); L.mh_json_f32.restype = C.c_char_p; L.mh_json_f32.argtypes = [C.c_float]
+
+    def ryu64(d):
+        if d == 0:
+            return "-0.0" if np.signbit(d) else "0.0"
+        m, _, e = ("%r" % abs(float(d))).partition("e")
+        if e:
+            digits = m.replace(".", ""); e10 = int(e)
+            if "." in m and m.endswith(".0"):
+                digits = m[:-2]
+        else:
+            ip, _, fp = m.partition("."); fp = "" if fp == "0" else fp
+            s = (ip + fp).lstrip("0"); e10 = len(ip.lstrip("0")) - 1 if ip.strip("0") else -(len(fp) - len(fp.lstrip("0")) + 1)
+            digits = s
+        digits = digits.rstrip("0") or "0"
+        length = len(digits); k = e10 - (length - 1); kk = length + k; sign = "-" if d < 0 else ""
+        if 0 <= k and kk <= 16:
+            return sign + digits + "0" * k + ".0"
+        if 0 < kk <= 16:
+            return sign + digits[:kk] + "." + digits[kk:]
+        if -5 < kk <= 0:
+            return sign + "0." + "0" * (-kk) + digits
+        return sign + (digits if length == 1 else digits[0] + "." + digits[1:]) + "e" + str(kk - 1)
+
+    assert [L.mh_json_f32(v).decode() for v in (0.5, 1.0, 0.25, 100000.0, 0.0)] == ["0.5", "1.0", "0.25", "100000.0", "0.0"]
+    assert L.mh_json_f32(np.float32(0.7)).decode() == "0.699999988079071" and L.mh_json_f32(np.float32(1e-5)).decode() == "9.999999747378752e-6" and L.mh_json_f32(np.float32(0.0001)).decode() == "0.00009999999747378752"
+    assert L.mh_json_f32(np.float32(1e-7)).decode() == "1.0000000116860974e-7" and L.mh_json_f32(np.float32(2.0 ** 53)).decode() == "9007199254740992.0"
+    assert L.mh_json_f32(np.float32(2.0 ** 60)).decode() == "1.152921504606847e18"
+    rng = np.random.default_rng(29)
+    vals = list(rng.random(2000).astype(np.float32)) + list(np.exp(rng.uniform(-60, 60, 2000)).astype(np.float32) * rng.choice([-1.0, 1.0], 2000).astype(np.float32))
+    for v in vals:
+        assert L.mh_json_f32(float(v)).decode() == ryu64(float(np.float32(v))), repr(float(np.float32(v)))
+        assert float(L.mh_json_f32(float(v)).decode()) == float(np.float32(v))
 
 
 def test_json_quote_and_trim_against_pythons_own_on_random_strings(built):
