@@ -515,3 +515,31 @@ def test_an_instance_continues_its_own_ladder_generator_across_segments(plugin):
                 differs_from_fresh += 1
         node.destroy()
     assert differs_from_fresh >= 2
+
+
+def test_instance_churn_does_not_grow_device_or_host_memory(plugin, micro_model_path):
+    """A server creates and drops instances for every Oneshot request and every session: 60 cycles of (4 instances, 3 s of audio each, flush, destroy) after a warm-up cycle must
+    leave the device's free memory and the process's resident set where they were (the model stays cached by design; the workspace, the pinned staging buffers, the per-instance
+    VAD and generator state and the results must all come back)."""
+    import torch
+    import psutil
+    cfg = {"model_path": micro_model_path, "vad_mode": "always", "flush_tail": True, "batch_window_ms": 1}
+    pcm = synth.clip(70, 16000 * 3)
+
+    def cycle():
+        nodes = [plugin.create_node(cfg) for _ in range(4)]
+        for n in nodes:
+            _feed(n, pcm, 960); assert n.flush() == 0; assert len(n.outputs()) == 1
+        for n in nodes:
+            n.destroy()
+
+    keep = plugin.create_node(cfg)                      # one instance stays: the engine's workspace is not torn down and rebuilt every cycle
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]; rss0 = psutil.Process().memory_info().rss
+    for _ in range(60):
+        cycle()
+    torch.cuda.synchronize(); free1 = torch.cuda.mem_get_info()[0]; rss1 = psutil.Process().memory_info().rss
+    keep.destroy()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %.1f MB over 240 instances" % ((free0 - free1) / 2 ** 20)
+    assert rss1 - rss0 < 96 << 20, "resident set grew by %.1f MB over 240 instances" % ((rss1 - rss0) / 2 ** 20)
