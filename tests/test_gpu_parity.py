@@ -443,6 +443,29 @@ def test_random_clips_and_parameters_match_oracle():
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_model_and_context_churn_returns_device_memory(eng, micro_model_path):
+    """skw_model_free / skw_ctx_free give back everything skw_model_load / skw_ctx_create took (weights and their images, the workspace table, step graphs, retry staging, trace
+    buffers, the launch clock): 25 load - create - transcribe - trace - free cycles in both precisions leave the device's free memory where it was."""
+    import torch
+    pcm = synth.clip(5, 16000 * 6)
+
+    def cycle(k):
+        m = eng.Model(micro_model_path); ctx = eng.Context(m, max_batch=4, max_samples=16000 * 32)
+        if k % 2:
+            ctx.set_precision("f16_mfma")
+        p = ctx.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0          # (walks the ladder: retry staging and sampled passes)
+        assert len(ctx.full_batch([pcm, pcm[:16000 * 2]], p)) == 2
+        ctx.full_batch([pcm], trace=True)
+        ctx.close(); m.close()
+
+    cycle(0); cycle(1)
+    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    for k in range(25):
+        cycle(k)
+    torch.cuda.synchronize(); free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 << 20, "device memory shrank by %.1f MB over 25 cycles" % ((free0 - free1) / 2 ** 20)
+
+
 def test_damaged_model_files_are_refused_with_a_message(eng, tiny_model_path, tmp_path):
     """create_instance hands the host NULL when the model cannot be loaded (lib.rs:354-360 -> "Failed to load Whisper model"): a damaged file must end in an error string, never in a
     crash of the host process or a half-loaded model.  Truncations at every structural boundary (magic, header, filterbank, vocabulary, inside a tensor header, inside tensor data,
