@@ -1,6 +1,6 @@
 import os, sys, numpy as np
 os.environ.setdefault("OMP_NUM_THREADS", "16")
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import kokoro_lib
 d = kokoro_lib.synth_kokoro_dir("micro")
 tts = kokoro_lib.Tts(d); orc = kokoro_lib.OracleTts(d); tts.taps(True)

@@ -109,7 +109,7 @@ def test_only_test_infrastructure_touches_the_oracle():
     """The oracle is the checker: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call, link or execute anything under oracle/.  The product
     (streamkit_amd/: Python host side, C++ / HIP sources, the Makefile) and tools/ never do — they may NAME it in comments; they may not load it."""
     import re
-    load = re.compile(r"oracle_lib|libskw_oracle|OracleModel|dlopen\([^)]*oracle|-lskw_oracle|#include\s+\"[^\"]*oracle")
+    load = re.compile(r"oracle_lib|libskw_oracle|Oracle(Model|Tts|Silero|Resampler|Decoder)|dlopen\([^)]*oracle|-lskw_oracle|#include\s+\"[^\"]*oracle")
     offenders = []
     for base in ("streamkit_amd", "tools"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
