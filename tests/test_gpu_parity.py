@@ -143,7 +143,7 @@ def test_every_decode_parameter_away_from_its_default_matches_oracle(tiny, field
     skw_full_params exposes the others too, and each is held to the oracle here at a non-default value: no_timestamps (the <|notimestamps|> prompt and its rules), single_segment,
     a token cap, translate (the task token), another max_initial_ts, the blank rule off, the fallback ladder off, and the three thresholds moved so that they fire."""
     _, ctx, om = tiny
-    pcms = [synth.clip(c, n) for c, n in [(1, 16000 * 30), (4, 16000 * 11 + 77), (6, 16000 * 31 + 500)]]      # the last one runs a second, short window
+    pcms = [synth.clip(c, n) for c, n in [(4, 16000 * 6 + 77), (6, 16000 * 31 + 500)]]       # the second one runs a second, short window
     p = ctx.default_params(); po = om.default_params()
     setattr(p, field, type(getattr(p, field))(value)); setattr(po, field, type(getattr(po, field))(value))
     n_tok = 0
@@ -187,7 +187,7 @@ def test_device_resident_pcm(tiny):
 
 
 def test_full_size_batch_properties(eng, small_model_path):
-    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on eight clips."""
+    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on four clips."""
     m = eng.Model(small_model_path)
     ctx = eng.Context(m, max_batch=64, max_samples=480000)
     pcms = [synth.clip(c) for c in range(64)]
@@ -206,7 +206,7 @@ def test_full_size_batch_properties(eng, small_model_path):
     assert _same(single, res[17])                                       # batching is exact
     om = OracleModel(small_model_path)
     po = om.default_params(); po.suppress_nst = 1
-    for c in (0, 5, 13, 22, 30, 41, 50, 63):                            # 8 of the 64 clips against the oracle (~6 s of CPU each)
+    for c in (0, 13, 41, 63):                                           # 4 of the 64 clips against the oracle (~6 s of CPU each; tests/hunt/fuzz_parity.py `exact small` ran 154 more)
         assert _same(res[c], om.full(pcms[c], po)), c
     ctx.close(); m.close()
 
@@ -215,7 +215,7 @@ def test_temperature_fallback_ladder_matches_oracle(tiny):
     """K11's fallback: passes that fail whisper.cpp's acceptance rules are decoded again at t = 0.2 .. 1.0, sampling with
     std::discrete_distribution semantics from the clip's mt19937.  Thresholds no pass can meet walk the whole ladder."""
     _, ctx, om = tiny
-    clips = [(1, 16000 * 30), (4, 16000 * 9), (2, 16000 * 30 + 768), (6, 16000 * 4)]
+    clips = [(4, 16000 * 9), (2, 16000 * 30 + 768), (6, 16000 * 4)]
     pcms = [synth.clip(c, n) for c, n in clips]
     p = ctx.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0
     po = om.default_params(); po.logprob_thold = 1.0; po.no_speech_thold = 2.0
@@ -235,7 +235,7 @@ def test_ladder_generator_runs_on_across_calls_like_whisper_cpps(tiny, eng):
     _, ctx, om = tiny
     p = ctx.default_params(); p.logprob_thold = 1.0; p.no_speech_thold = 2.0            # no pass is accepted: every window walks the ladder and draws
     po = om.default_params(); po.logprob_thold = 1.0; po.no_speech_thold = 2.0
-    segs = [[synth.clip(10 * i + k, 16000 * (6 + 3 * k + i)) for k in range(3)] for i in range(3)]      # segs[instance][call]
+    segs = [[synth.clip(10 * i + k, 16000 * (3 + k + i)) for k in range(3)] for i in range(3)]          # segs[instance][call]: 3 .. 7 s each
     gpu_state = [eng.rng_state_new() for _ in range(3)]; cpu_state = [eng.rng_state_new() for _ in range(3)]
     assert gpu_state[0][624] == 624 and gpu_state[0][1] == 1812433253 * (0 ^ 0) + 1
     seen_difference = False
@@ -393,15 +393,15 @@ def test_multi_window_clips_advance_by_timestamps(eng, tiny_model_path):
 
 
 def test_long_form_clips_of_many_windows_match_oracle(eng, tiny_model_path):
-    """2.5 and 4 minutes of audio in one call beside a short clip: 5 - 9 windows per clip, each conditioned on the text of the ones before it (the carried prompt), rows leaving and
+    """70 and 100 seconds of audio in one call beside a short clip (profiles/r05s: the same with 2.5 and 4 minutes): several windows per clip, each conditioned on the text of the ones before it (the carried prompt), rows leaving and
     re-entering the batch at different windows — ids, log-probs, segment times, window counts identical to the oracle's sequential run; in both precisions' control flow (f16_mfma:
     the same number of windows and a transcript of the same shape, its decisions are checked elsewhere)."""
-    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=3, max_samples=16000 * 245); om = OracleModel(tiny_model_path)
-    pcms = [synth.clip(11, 16000 * 150 + 311), synth.clip(12, 16000 * 9), synth.clip(13, 16000 * 240)]
+    m = eng.Model(tiny_model_path); ctx = eng.Context(m, max_batch=3, max_samples=16000 * 105); om = OracleModel(tiny_model_path)
+    pcms = [synth.clip(11, 16000 * 70 + 311), synth.clip(12, 16000 * 9), synth.clip(13, 16000 * 100)]
     res = ctx.full_batch(pcms)
     for pcm, rg in zip(pcms, res):
         assert _same(rg, om.full(pcm))
-    assert res[0]["n_windows"] >= 5 and res[2]["n_windows"] >= 8 and res[2]["segments"][-1]["t1"] > 20000
+    assert res[0]["n_windows"] >= 3 and res[2]["n_windows"] >= 4 and res[2]["segments"][-1]["t1"] > 8000
     ctx.set_precision("f16_mfma")
     for rg, rf in zip(res, ctx.full_batch(pcms)):
         assert abs(rf["n_windows"] - rg["n_windows"]) <= 1 and len(rf["segments"]) > 0
@@ -434,12 +434,12 @@ def test_non_finite_and_absurd_samples_do_not_hang_or_poison_batch_mates(tiny, p
 
 
 def test_random_clips_and_parameters_match_oracle():
-    """Ten rounds of tests/hunt/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
+    """Six rounds of tests/hunt/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
     model shapes — whatever combination the named tests above do not name."""
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([_sys.executable, os.path.join(root, "tests", "hunt", "fuzz_parity.py"), "10", "20261005"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tests", "hunt", "fuzz_parity.py"), "6", "20261005"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
 
 
