@@ -161,7 +161,7 @@ def test_multi_window_and_language_detection_identical(eng, tiny_model_path):
 
 def test_full_size_batch_tokens(eng, small_model_path):
     """BASELINE.json configs[1] (Whisper-small dims, 64 x 30 s) in f16_mfma against the exact mode on all 64 clips (the exact mode is
-    itself checked against the oracle on 4 of them in test_gpu_parity.py) and against the oracle on 3 clips: identical transcripts,
+    itself checked against the oracle on 3 of them in test_gpu_parity.py) and against the oracle on 2 clips: identical transcripts,
     except from a near-tie of the checker's argmax on."""
     m = eng.Model(small_model_path)
     ctx = eng.Context(m, max_batch=64, max_samples=480000)
@@ -179,11 +179,11 @@ def test_full_size_batch_tokens(eng, small_model_path):
     om = OracleModel(small_model_path)
     po = om.default_params(); po.suppress_nst = 1
     n_ok = 0
-    for c in [c for c in range(64) if same[c]][:3]:
+    for c in [c for c in range(64) if same[c]][:2]:
         ro = om.full(pcms[c], po)
         assert _ids(fast[c]) == _ids(ro) and _segs(fast[c]) == _segs(ro), c
         n_ok += 1
-    assert n_ok == 3
+    assert n_ok == 2
     ctx.close(); m.close()
 
 

@@ -143,7 +143,8 @@ def test_every_decode_parameter_away_from_its_default_matches_oracle(tiny, field
     skw_full_params exposes the others too, and each is held to the oracle here at a non-default value: no_timestamps (the <|notimestamps|> prompt and its rules), single_segment,
     a token cap, translate (the task token), another max_initial_ts, the blank rule off, the fallback ladder off, and the three thresholds moved so that they fire."""
     _, ctx, om = tiny
-    pcms = [synth.clip(c, n) for c, n in [(4, 16000 * 6 + 77), (6, 16000 * 31 + 500)]]       # the second one runs a second, short window
+    # a short clip for every parameter; the two-window clip only where the parameter touches how windows end and follow each other
+    pcms = [synth.clip(4, 16000 * 6 + 77)] + ([synth.clip(6, 16000 * 31 + 500)] if field in ("no_timestamps", "single_segment", "max_tokens", "entropy_thold") else [])
     p = ctx.default_params(); po = om.default_params()
     setattr(p, field, type(getattr(p, field))(value)); setattr(po, field, type(getattr(po, field))(value))
     n_tok = 0
@@ -187,7 +188,7 @@ def test_device_resident_pcm(tiny):
 
 
 def test_full_size_batch_properties(eng, small_model_path):
-    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on four clips."""
+    """BASELINE.json configs[1] at full size (Whisper-small dims, 64 x 30 s): size-independent properties, plus the oracle on three clips."""
     m = eng.Model(small_model_path)
     ctx = eng.Context(m, max_batch=64, max_samples=480000)
     pcms = [synth.clip(c) for c in range(64)]
@@ -206,7 +207,7 @@ def test_full_size_batch_properties(eng, small_model_path):
     assert _same(single, res[17])                                       # batching is exact
     om = OracleModel(small_model_path)
     po = om.default_params(); po.suppress_nst = 1
-    for c in (0, 13, 41, 63):                                           # 4 of the 64 clips against the oracle (~6 s of CPU each; tests/hunt/fuzz_parity.py `exact small` ran 154 more)
+    for c in (0, 41, 63):                                               # 3 of the 64 clips against the oracle (~6 s of CPU each; tests/hunt/fuzz_parity.py `exact small` ran 154 more)
         assert _same(res[c], om.full(pcms[c], po)), c
     ctx.close(); m.close()
 
@@ -237,9 +238,10 @@ def test_ladder_generator_runs_on_across_calls_like_whisper_cpps(tiny, eng):
     po = om.default_params(); po.logprob_thold = 1.0; po.no_speech_thold = 2.0
     segs = [[synth.clip(10 * i + k, 16000 * (3 + k + i)) for k in range(3)] for i in range(3)]          # segs[instance][call]: 3 .. 7 s each
     gpu_state = [eng.rng_state_new() for _ in range(3)]; cpu_state = [eng.rng_state_new() for _ in range(3)]
+    n_calls = 2                                                                                         # (three calls in profiles/r05z's earlier logs; two keep the suite short)
     assert gpu_state[0][624] == 624 and gpu_state[0][1] == 1812433253 * (0 ^ 0) + 1
     seen_difference = False
-    for call in range(3):
+    for call in range(n_calls):
         order = [(call + j) % 3 for j in range(3)]                                       # instance order inside the batch changes from call to call
         res = ctx.full_batch([segs[i][call] for i in order], p, rng_states=[gpu_state[i] for i in order])
         for i, rg in zip(order, res):
@@ -434,12 +436,12 @@ def test_non_finite_and_absurd_samples_do_not_hang_or_poison_batch_mates(tiny, p
 
 
 def test_random_clips_and_parameters_match_oracle():
-    """Six rounds of tests/hunt/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
+    """Four rounds of tests/hunt/fuzz_parity.py (its long runs: profiles/r05v, 1 528 clips, no mismatch): random lengths, levels, batch compositions and decode parameters over three
     model shapes — whatever combination the named tests above do not name."""
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([_sys.executable, os.path.join(root, "tests", "hunt", "fuzz_parity.py"), "6", "20261005"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tests", "hunt", "fuzz_parity.py"), "4", "20261005"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-2000:]
 
 
