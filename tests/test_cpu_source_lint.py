@@ -129,3 +129,19 @@ def test_only_test_infrastructure_touches_the_oracle():
     assert hits and all(marker < i < marker + 40 for i in hits), (hits, marker)
     entry = open(os.path.join(ROOT, "__graft_entry__.py"), encoding="utf-8").read()
     assert entry.index("def smoke") < entry.index("oracle_lib")                              # (build() only compiles the checker)
+
+
+def test_every_python_tool_and_hunt_script_compiles():
+    """tools/ and tests/hunt/ are run by hand on the GPU box, rarely: a syntax error there would only show up in the middle of a measurement."""
+    bad = []
+    files = [os.path.join(ROOT, f) for f in ("bench.py", "__graft_entry__.py", os.path.join("tests", "pin_against_whisper_cpp.py"))]
+    for base in ("tools", os.path.join("tests", "hunt"), "streamkit_amd"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            if "__pycache__" not in dp:
+                files += [os.path.join(dp, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        try:
+            compile(open(f, encoding="utf-8").read(), f, "exec")
+        except SyntaxError as e:
+            bad.append("%s:%s: %s" % (os.path.relpath(f, ROOT), e.lineno, e.msg))
+    assert len(files) > 30 and not bad, bad
